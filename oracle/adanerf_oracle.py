@@ -1,0 +1,667 @@
+"""CPU restatement of the AdaNeRF inference hot path (numpy, fp32).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``adanerf_amd/`` may import this
+module: it is the checker for the HIP path (``tests/``, ``__graft_entry__.smoke``
+and ``bench.py``'s ``cpu_baseline`` leg are the only legal callers).
+
+Parity status: PINNED.  ``oracle/gen_golden.py`` imports the reference's own
+PyTorch path (``/root/reference/src``) in the build container, drives
+``TrainConfig.inference`` on seeded ray batches and commits the resulting
+vectors under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks every
+function below against them (indices exact, floats to the stated tolerance).
+
+Each function cites the reference file:line it restates (paths relative to
+``/root/reference``).  Arithmetic is float32 wherever the reference's is
+(torch default dtype), float64 only where the reference uses numpy float64
+(ray table).
+"""
+from __future__ import annotations
+
+import math
+import os
+import struct
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+F32 = np.float32
+D_BINS = 128  # multiDepthFeatures (src/nerf_raymarch_common.py:710-712)
+
+
+# --------------------------------------------------------------------------------------
+# Exported model directory format (config.ini / dataset_info.txt / model{0,1}.onnx)
+# --------------------------------------------------------------------------------------
+
+def _parse_list(value: str) -> List[str]:
+    """``[a, b]`` list syntax of adanerf_real_time_viewer/src/config.cpp:150-199."""
+    s = value.strip()
+    if s.startswith("["):
+        s = s[1:s.index("]")]
+    return [t.strip() for t in s.split(",")] if s.strip() != "" else []
+
+
+def parse_kv_file(path: str) -> Dict[str, str]:
+    """``key = value`` lines, whitespace stripped from both sides
+    (adanerf_real_time_viewer/src/config.cpp:200-204, 284-295).  Section
+    headers / comments have no '=' or are ignored by key lookup."""
+    out: Dict[str, str] = {}
+    with open(path, "r") as f:
+        for line in f:
+            if "=" not in line:
+                continue
+            k, v = line.split("=", 1)
+            k = "".join(k.split())
+            v = "".join(v.split())
+            if k and not k.startswith(";") and not k.startswith("#"):
+                out[k] = v
+    return out
+
+
+@dataclass
+class Scene:
+    """Scalar scene/config metadata: SURVEY §8a row A9
+    (src/datasets.py:136-213, src/export.py:47-54, viewer include/config.h:10-63)."""
+    view_cell_center: Tuple[float, float, float]
+    view_cell_size: Tuple[float, float, float]
+    depth_range: Tuple[float, float]        # warped range (dataset_info.txt `depth_range`)
+    fov: float
+    max_depth: float
+    num_samples: int = 8                    # numRaymarchSamples[1]
+    threshold: float = 0.2                  # adaptiveSamplingThreshold
+    z_near: float = 0.001
+    z_far: float = 1.0
+    use_ndc: bool = False
+    depth_transform: str = "log"            # "log" | "linear"
+    pos_enc: Tuple[Tuple[int, int], Tuple[int, int]] = ((10, 4), (10, 4))
+    normalization: str = "InverseSqrtDistCentered"   # rayMarchNormalization[1]
+    accumulation_mult: str = "alpha"
+
+    @property
+    def radius(self) -> float:
+        # src/features.py:761  ||view_cell_size / 2||_2 (float64 numpy -> torch float64 tensor)
+        return float(np.linalg.norm(np.array(self.view_cell_size, dtype=np.float64) / 2.0))
+
+    @property
+    def n_in0(self) -> int:
+        fp, fd = self.pos_enc[0]
+        return 3 + 6 * fp + 3 + 6 * fd
+
+    @property
+    def n_in1(self) -> int:
+        fp, fd = self.pos_enc[1]
+        return 3 + 6 * fp + 3 + 6 * fd
+
+
+def load_scene(model_dir: str, num_samples: Optional[int] = None,
+               threshold: Optional[float] = None) -> Scene:
+    """config.ini then dataset_info.txt, later keys win
+    (adanerf_real_time_viewer/src/config.cpp:270-344)."""
+    kv = parse_kv_file(os.path.join(model_dir, "config.ini"))
+    kv.update(parse_kv_file(os.path.join(model_dir, "dataset_info.txt")))
+    fl = lambda k: [float(x) for x in _parse_list(kv[k])]
+    enc = []
+    for item in _parse_list(kv.get("posEncArgs", "[10-4,10-4]")):
+        if item == "none":
+            enc.append((4, 0))      # config.cpp:142-146
+        else:
+            a, b = item.split("-")
+            enc.append((int(a), int(b)))
+    norm = _parse_list(kv.get("rayMarchNormalization", "[None,None]"))
+    sc = Scene(
+        view_cell_center=tuple(fl("view_cell_center")),
+        view_cell_size=tuple(fl("view_cell_size")),
+        depth_range=tuple(fl("depth_range")),
+        fov=float(kv["fov"]),
+        max_depth=float(kv["max_depth"]),
+        num_samples=int(_parse_list(kv["numRaymarchSamples"])[-1]),
+        threshold=float(kv.get("adaptiveSamplingThreshold", "-1")),
+        z_near=float(_parse_list(kv.get("zNear", "[0.001,0.001]"))[-1]),
+        z_far=float(_parse_list(kv.get("zFar", "[1.0,1.0]"))[-1]),
+        use_ndc=kv.get("useNDC", "False") == "True",
+        depth_transform=kv.get("depthTransform", "linear"),
+        pos_enc=(enc[0], enc[1]),
+        normalization=norm[-1] if norm else "None",
+        accumulation_mult=kv.get("accumulationMult", ""),
+    )
+    if num_samples is not None:
+        sc.num_samples = num_samples
+    if threshold is not None:
+        sc.threshold = threshold
+    return sc
+
+
+# --- minimal protobuf reader for ONNX graph.initializer (src/export.py:78-83 writes these) ---
+
+def _rv(b: bytes, i: int) -> Tuple[int, int]:
+    r = 0
+    s = 0
+    while True:
+        c = b[i]
+        i += 1
+        r |= (c & 0x7F) << s
+        s += 7
+        if c < 0x80:
+            return r, i
+
+
+def _fields(b: bytes):
+    i = 0
+    n = len(b)
+    while i < n:
+        k, i = _rv(b, i)
+        f, w = k >> 3, k & 7
+        if w == 0:
+            v, i = _rv(b, i)
+        elif w == 2:
+            l, i = _rv(b, i)
+            v = b[i:i + l]
+            i += l
+        elif w == 5:
+            v = b[i:i + 4]
+            i += 4
+        elif w == 1:
+            v = b[i:i + 8]
+            i += 8
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % w)
+        yield f, w, v
+
+
+def read_onnx_initializers(path: str) -> Dict[str, np.ndarray]:
+    """ModelProto.graph(7) -> GraphProto.initializer(5) -> TensorProto{dims=1,
+    data_type=2 (1=FLOAT), name=8, raw_data=9, float_data=4}.  PyTorch [out,in] layout."""
+    with open(path, "rb") as f:
+        b = f.read()
+    out: Dict[str, np.ndarray] = {}
+    for f1, w1, v1 in _fields(b):
+        if f1 != 7 or w1 != 2:
+            continue
+        for f2, w2, v2 in _fields(v1):
+            if f2 != 5 or w2 != 2:
+                continue
+            dims: List[int] = []
+            name = None
+            raw = None
+            fdata: List[float] = []
+            dt = 1
+            for f3, w3, v3 in _fields(v2):
+                if f3 == 1:
+                    if w3 == 0:
+                        dims.append(v3)
+                    else:
+                        j = 0
+                        while j < len(v3):
+                            d, j = _rv(v3, j)
+                            dims.append(d)
+                elif f3 == 2:
+                    dt = v3
+                elif f3 == 8:
+                    name = v3.decode()
+                elif f3 == 9:
+                    raw = v3
+                elif f3 == 4:
+                    if w3 == 2:
+                        fdata.extend(struct.unpack("<%df" % (len(v3) // 4), v3))
+                    else:
+                        fdata.append(struct.unpack("<f", v3)[0])
+            if dt != 1 or name is None:
+                continue
+            if raw is not None:
+                arr = np.frombuffer(raw, dtype="<f4").copy()
+            else:
+                arr = np.array(fdata, dtype=F32)
+            out[name] = arr.reshape(dims if dims else ())
+    return out
+
+
+def write_onnx_initializers(path: str, tensors: Dict[str, np.ndarray]) -> None:
+    """Writes a minimal ONNX-shaped protobuf that carries only graph.initializer
+    entries (enough for every loader in this repo; used for synthetic-weight
+    model directories in tests/bench).  Same field numbers as above."""
+    def vint(x: int) -> bytes:
+        o = bytearray()
+        while True:
+            c = x & 0x7F
+            x >>= 7
+            if x:
+                o.append(c | 0x80)
+            else:
+                o.append(c)
+                return bytes(o)
+
+    def ld(fn: int, payload: bytes) -> bytes:
+        return vint((fn << 3) | 2) + vint(len(payload)) + payload
+
+    graph = bytearray()
+    for name, arr in tensors.items():
+        a = np.ascontiguousarray(arr, dtype="<f4")
+        t = bytearray()
+        for d in a.shape:
+            t += vint((1 << 3) | 0) + vint(int(d))
+        t += vint((2 << 3) | 0) + vint(1)
+        t += ld(8, name.encode())
+        t += ld(9, a.tobytes())
+        graph += ld(5, bytes(t))
+    model = vint((1 << 3) | 0) + vint(4) + ld(7, bytes(graph))
+    with open(path, "wb") as f:
+        f.write(model)
+
+
+@dataclass
+class Weights:
+    """fp32 weights in PyTorch [out,in] layout, named as the exported ONNX names them."""
+    net0: Dict[str, np.ndarray] = field(default_factory=dict)   # layers.{0..7}.{weight,bias}
+    net1: Dict[str, np.ndarray] = field(default_factory=dict)   # pts_linears.*, alpha_linear, ...
+
+
+def load_weights(model_dir: str) -> Weights:
+    return Weights(read_onnx_initializers(os.path.join(model_dir, "model0.onnx")),
+                   read_onnx_initializers(os.path.join(model_dir, "model1.onnx")))
+
+
+def synthetic_weights(seed: int, n_in0: int = 90, n_in1_pos: int = 63, n_in1_dir: int = 27,
+                      oracle_bias: float = 0.0, oracle_scale: float = 1.0) -> Weights:
+    """Seeded Kaiming-normal weights in the exported layout (nn.init.kaiming_normal_ as
+    src/models.py:77-78, 246-250: std = sqrt(2/fan_in)); biases U(-1/sqrt(fan_in), ..) like
+    nn.Linear's default.  ``oracle_bias`` is added to the sampling net's last bias so a
+    chosen fraction of outputs clears the threshold (SURVEY §8d "W-syn")."""
+    rng = np.random.default_rng(seed)
+
+    def lin(n_out, n_in, scale=1.0):
+        w = (rng.standard_normal((n_out, n_in)) * math.sqrt(2.0 / n_in) * scale).astype(F32)
+        bnd = 1.0 / math.sqrt(n_in)
+        b = rng.uniform(-bnd, bnd, size=(n_out,)).astype(F32)
+        return w, b
+
+    n0: Dict[str, np.ndarray] = {}
+    dims = [n_in0] + [256] * 7 + [128]
+    for i in range(8):
+        w, b = lin(dims[i + 1], dims[i], oracle_scale if i == 7 else 1.0)
+        if i == 7:
+            b = (b + oracle_bias).astype(F32)
+        n0["layers.%d.weight" % i] = w
+        n0["layers.%d.bias" % i] = b
+    n1: Dict[str, np.ndarray] = {}
+    for i in range(8):
+        k = n_in1_pos if i == 0 else (256 + n_in1_pos if i == 5 else 256)
+        w, b = lin(256, k)
+        n1["pts_linears.%d.weight" % i] = w
+        n1["pts_linears.%d.bias" % i] = b
+    for nm, (o, k) in {"views_linears.0": (128, 256 + n_in1_dir), "feature_linear": (256, 256),
+                       "alpha_linear": (1, 256), "rgb_linear": (3, 128)}.items():
+        w, b = lin(o, k)
+        n1[nm + ".weight"] = w
+        n1[nm + ".bias"] = b
+    return Weights(n0, n1)
+
+
+def write_model_dir(path: str, scene: Scene, weights: Weights) -> None:
+    """Writes config.ini / dataset_info.txt / model{0,1}.onnx in the exported format
+    (minimal 19-key config form of sample_pavillon_16/config.ini; dataset_info.txt as
+    src/export.py:47-54)."""
+    os.makedirs(path, exist_ok=True)
+    sampler = "FromClassifiedDepthAdaptiveNoDepthRange" if scene.use_ndc else "FromClassifiedDepthAdaptive"
+    with open(os.path.join(path, "config.ini"), "w") as f:
+        f.write("posEnc = [nerf, nerf]\n")
+        f.write("posEncArgs = [%d-%d, %d-%d]\n" % (scene.pos_enc[0] + scene.pos_enc[1]))
+        f.write("inFeatures = [SpherePosDir, RayMarchFromPoses]\n")
+        f.write("outFeatures = [Raw, RGBARayMarch]\n")
+        f.write("rayMarchSampler = [none, %s]\n" % sampler)
+        f.write("rayMarchNormalization = [InverseSqrtDistCentered, %s]\n" % scene.normalization)
+        f.write("numRaymarchSamples = [%d, %d]\n" % (scene.num_samples, scene.num_samples))
+        f.write("rayMarchSamplingStep = [0.0078125, 0.0078125]\n")
+        f.write("rayMarchSamplingNoise = [0.0, 0.0]\n")
+        f.write("raySampleInput = [0, 0]\n")
+        f.write("depthTransform = %s\n" % scene.depth_transform)
+        f.write("zNear = [%r, %r]\n" % (scene.z_near, scene.z_near))
+        f.write("zFar = [%r, %r]\n" % (scene.z_far, scene.z_far))
+        f.write("adaptiveSamplingThreshold = %r\n" % scene.threshold)
+        f.write("multiDepthFeatures = [128, 128]\n")
+        f.write("multiDepthIgnoreValue = [1.01, 1.01]\n")
+        f.write("accumulationMult = %s\n" % scene.accumulation_mult)
+        f.write("useNDC = %s\n" % ("True" if scene.use_ndc else "False"))
+    with open(os.path.join(path, "dataset_info.txt"), "w") as f:
+        f.write("view_cell_center = [%r, %r, %r]\n" % tuple(scene.view_cell_center))
+        f.write("view_cell_size = [%r, %r, %r]\n" % tuple(scene.view_cell_size))
+        f.write("depth_range = [%r, %r]\n" % tuple(scene.depth_range))
+        f.write("fov = %r\n" % scene.fov)
+        f.write("focal = 0.0\ncamera_scale = 1.0\n")
+        f.write("max_depth = %r\n" % scene.max_depth)
+    write_onnx_initializers(os.path.join(path, "model0.onnx"), weights.net0)
+    write_onnx_initializers(os.path.join(path, "model1.onnx"), weights.net1)
+
+
+# --------------------------------------------------------------------------------------
+# A1  pixel ray table
+# --------------------------------------------------------------------------------------
+
+def focal_from_fov(w: int, fov: float) -> float:
+    """src/datasets.py:182  focal = .5*w / tan(.5*fov)  (python float64)."""
+    return 0.5 * w / math.tan(0.5 * fov)
+
+
+def generate_ray_directions(w: int, h: int, fov: float, focal: Optional[float] = None) -> np.ndarray:
+    """src/util/raygeneration.py:10-26, float64 then cast to float32 by the dataset
+    (src/datasets.py:190-192).  Row-major [h*w, 3]; ray id = row*w + col."""
+    if focal is None:
+        focal = focal_from_fov(w, fov)
+    x_dist = np.tan(fov / 2) * focal
+    y_dist = x_dist * (h / w)
+    x_pp = x_dist / (w / 2)
+    y_pp = y_dist / (h / 2)
+    col = np.arange(w, dtype=np.float64)[None, :].repeat(h, 0)
+    row = np.arange(h, dtype=np.float64)[:, None].repeat(w, 1)
+    v = np.empty((h, w, 3), dtype=np.float64)
+    v[..., 0] = -(x_dist - x_pp / 2) + x_pp * col
+    v[..., 1] = -(y_dist - y_pp / 2) + y_pp * row
+    v[..., 2] = focal
+    v /= np.linalg.norm(v, axis=2)[..., None]
+    v[..., 1] *= -1.0
+    v[..., 2] *= -1.0
+    return v.reshape(h * w, 3).astype(F32)
+
+
+def camera_rotation(yaw_deg: float, pitch_deg: float) -> np.ndarray:
+    """c2w rotation for a z-up world, camera looking along -z with +y up:
+    columns = (right, up, -forward).  Direction from yaw/pitch as the viewer's
+    Camera::UpdateFeatureRot (adanerf_real_time_viewer/src/camera.cpp:143-158)."""
+    y, p = math.radians(yaw_deg), math.radians(pitch_deg)
+    fwd = np.array([math.cos(y) * math.cos(p), math.sin(y) * math.cos(p), math.sin(p)])
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, np.array([0.0, 0.0, 1.0]))
+    right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    return np.stack([right, up, -fwd], axis=1).astype(F32)
+
+
+# --------------------------------------------------------------------------------------
+# A2  world ray + sphere exit + oracle features
+# --------------------------------------------------------------------------------------
+
+def positional_encoding(x: np.ndarray, n_freqs: int) -> np.ndarray:
+    """src/util/feature_encoding.py:54-73: [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(F-1) x),
+    cos(2^(F-1) x)], each a 3-vector; freq bands 2**linspace(0, F-1, F) (exact powers of 2)."""
+    x = x.astype(F32)
+    parts = [x]
+    for k in range(n_freqs):
+        f = F32(2.0 ** k)
+        parts.append(np.sin(x * f).astype(F32))
+        parts.append(np.cos(x * f).astype(F32))
+    return np.concatenate(parts, axis=-1)
+
+
+def world_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: Scene):
+    """src/features.py:845-866 (bmm) + compute_ray_offset :769-791.
+    Returns (nds [R,3] un-normalised world dirs, p [R,3] sphere-exit points)."""
+    rot = rot.astype(F32)
+    nds = (dirs_cam.astype(F32) @ rot.T).astype(F32)            # R * d per ray
+    c = np.array(scene.view_cell_center, dtype=F32)
+    o = pose.astype(F32)
+    omc = (o - c).astype(F32)
+    udot = np.sum(omc[None, :] * nds, axis=1, dtype=F32)
+    # view_cell_radius is a float64 0-d tensor in the reference; radius**2 promotes the
+    # scalar term only (result dtype stays float32 because the other operand is a tensor).
+    rad2 = F32(np.float64(scene.radius) ** 2)
+    delta = (udot ** 2 - (np.sum(omc ** 2, dtype=F32) - rad2)).astype(F32)
+    sq = np.sqrt(np.maximum(delta, F32(0))).astype(F32)
+    dist = (-udot + sq).astype(F32)
+    p = (o[None, :] + nds * dist[:, None]).astype(F32)
+    return nds, p
+
+
+def oracle_features(nds: np.ndarray, p: np.ndarray, scene: Scene) -> np.ndarray:
+    """src/features.py:868-874: [PE_dir(nds/||nds||) | PE_pos(p)]."""
+    fp, fd = scene.pos_enc[0]
+    nrm = np.sqrt(np.sum(nds * nds, axis=-1, keepdims=True, dtype=F32)).astype(F32)
+    return np.concatenate([positional_encoding((nds / nrm).astype(F32), fd),
+                           positional_encoding(p, fp)], axis=-1).astype(F32)
+
+
+# --------------------------------------------------------------------------------------
+# A3 / A6  the two MLPs
+# --------------------------------------------------------------------------------------
+
+def _linear(x, w, b):
+    return (x @ w.T + b).astype(F32)
+
+
+def sampling_mlp(x: np.ndarray, net0: Dict[str, np.ndarray]) -> np.ndarray:
+    """src/models.py:183-195 (BaseNet.forward, no skips): 7x(Linear+ReLU) + Linear; raw output."""
+    h = x.astype(F32)
+    n = len([k for k in net0 if k.endswith(".weight")])
+    for i in range(n):
+        h = _linear(h, net0["layers.%d.weight" % i], net0["layers.%d.bias" % i])
+        if i + 1 < n:
+            h = np.maximum(h, F32(0))
+    return h
+
+
+def shading_mlp(x: np.ndarray, net1: Dict[str, np.ndarray], n_pos: int = 63) -> np.ndarray:
+    """src/models.py:254-277 (NeRF.forward, skips=[4], use_viewdirs=True) -> [rgb(3), alpha(1)] raw."""
+    x = x.astype(F32)
+    pts, views = x[:, :n_pos], x[:, n_pos:]
+    h = pts
+    for i in range(8):
+        h = np.maximum(_linear(h, net1["pts_linears.%d.weight" % i], net1["pts_linears.%d.bias" % i]), F32(0))
+        if i == 4:
+            h = np.concatenate([pts, h], axis=-1)
+    alpha = _linear(h, net1["alpha_linear.weight"], net1["alpha_linear.bias"])
+    feat = _linear(h, net1["feature_linear.weight"], net1["feature_linear.bias"])
+    h = np.concatenate([feat, views], axis=-1)
+    h = np.maximum(_linear(h, net1["views_linears.0.weight"], net1["views_linears.0.bias"]), F32(0))
+    rgb = _linear(h, net1["rgb_linear.weight"], net1["rgb_linear.bias"])
+    return np.concatenate([rgb, alpha], axis=-1).astype(F32)
+
+
+# --------------------------------------------------------------------------------------
+# A4  adaptive selection + compaction
+# --------------------------------------------------------------------------------------
+
+def select_adaptive(orc: np.ndarray, n_max: int, thr: float):
+    """src/nerf_raymarch_common.py:699-757 (thr > 0 branch), restated as a set rule:
+    rank bins by value descending (ties: lower bin first -- the reference's torch.sort is
+    unstable there, SURVEY §0, so tie rows at the N-cutoff are implementation-defined and we
+    define 'lower bin id wins'); keep the first n_max whose value >= thr; if none is >= thr
+    keep the arg-max alone; emit kept bins in ascending depth order.
+
+    Returns (count [R] int32, bins [R,n_max] int16 (-1 padded, ascending),
+             weight [R,n_max] float32 (oracle value of the kept bin, 0 padded))."""
+    orc = orc.astype(F32)
+    r, d = orc.shape
+    order = np.argsort(-orc, axis=1, kind="stable")[:, :n_max]
+    vals = np.take_along_axis(orc, order, axis=1)
+    keep = vals >= F32(thr)
+    none = ~keep.any(axis=1)
+    keep[none, 0] = True
+    count = keep.sum(axis=1).astype(np.int32)
+    big = np.where(keep, order, d + 1)
+    srt = np.argsort(big, axis=1, kind="stable")
+    bins = np.take_along_axis(big, srt, axis=1)
+    wts = np.take_along_axis(np.where(keep, vals, F32(0)), srt, axis=1)
+    bins = np.where(bins > d, -1, bins).astype(np.int16)
+    return count, bins, wts.astype(F32)
+
+
+def compact(count: np.ndarray, bins: np.ndarray, wts: np.ndarray):
+    """Ray-major, depth-ascending flat order == ``embedded[mapping]`` order of
+    src/features.py:438-446, 481-484.  Returns (ray_offset [R] int32 exclusive prefix,
+    sample_ray [S] int32, sample_bin [S] int16, sample_w [S] float32)."""
+    r, n = bins.shape
+    off = np.zeros(r, dtype=np.int64)
+    off[1:] = np.cumsum(count.astype(np.int64))[:-1]
+    mask = np.arange(n)[None, :] < count[:, None]
+    ray = np.repeat(np.arange(r, dtype=np.int32)[:, None], n, 1)[mask]
+    return off.astype(np.int32), ray, bins[mask].astype(np.int16), wts[mask].astype(F32)
+
+
+def bin_t(bins: np.ndarray) -> np.ndarray:
+    """(k + .5) * cell_size with cell_size = 1/128 in float32
+    (src/nerf_raymarch_common.py:722-723, 737-741)."""
+    return ((bins.astype(F32) + F32(0.5)) * F32(1.0 / D_BINS)).astype(F32)
+
+
+def dense_t(scene: Scene, n: int = D_BINS) -> np.ndarray:
+    """thr == 0 branch, src/nerf_raymarch_common.py:708-720:
+    t = linspace(0,1,n+1)[:-1] + .5/n ; z = near*(1-t) + far*t."""
+    t = (np.linspace(0.0, 1.0, n + 1, dtype=F32)[:-1] + F32(0.5 / n)).astype(F32)
+    return (F32(scene.z_near) * (F32(1.0) - t) + F32(scene.z_far) * t).astype(F32)
+
+
+def to_world_depth(t: np.ndarray, scene: Scene) -> np.ndarray:
+    """src/util/depth_transformations.py:37-48 (log) / :57-58 (linear); NDC sampler
+    (…NoDepthRange, src/nerf_raymarch_common.py:796-851) returns t unchanged."""
+    t = t.astype(F32)
+    if scene.use_ndc:
+        return t
+    d0, d1 = scene.depth_range
+    if scene.depth_transform == "log":
+        max_v = d1 - d0
+        return (np.power(F32(max_v + 1), t).astype(F32) - F32(1.0) + F32(d0)).astype(F32)
+    return (t * F32(d1 - d0) + F32(d0)).astype(F32)
+
+
+# --------------------------------------------------------------------------------------
+# A5  sample position + normalisation + shading PE
+# --------------------------------------------------------------------------------------
+
+def ndc_rays(h: int, w: int, focal: float, near: float, rays_o: np.ndarray, rays_d: np.ndarray):
+    """src/nerf_raymarch_common.py:71-88."""
+    rays_o = rays_o.astype(F32)
+    rays_d = rays_d.astype(F32)
+    t = (-(F32(near) + rays_o[:, 2]) / rays_d[:, 2]).astype(F32)
+    rays_o = (rays_o + t[:, None] * rays_d).astype(F32)
+    sw = F32(-1.0 / (w / (2.0 * focal)))
+    sh = F32(-1.0 / (h / (2.0 * focal)))
+    o0 = sw * rays_o[:, 0] / rays_o[:, 2]
+    o1 = sh * rays_o[:, 1] / rays_o[:, 2]
+    o2 = F32(1.0) + F32(2.0 * near) / rays_o[:, 2]
+    d0 = sw * (rays_d[:, 0] / rays_d[:, 2] - rays_o[:, 0] / rays_o[:, 2])
+    d1 = sh * (rays_d[:, 1] / rays_d[:, 2] - rays_o[:, 1] / rays_o[:, 2])
+    d2 = F32(-2.0 * near) / rays_o[:, 2]
+    return (np.stack([o0, o1, o2], -1).astype(F32), np.stack([d0, d1, d2], -1).astype(F32))
+
+
+def shading_inputs(p: np.ndarray, nds: np.ndarray, sample_ray: np.ndarray, z: np.ndarray,
+                   scene: Scene, w: int = 0, h: int = 0) -> np.ndarray:
+    """src/features.py:420-479: x = o + d*z; normalise; [PE_pos(x^) | PE_dir(dir)].
+    ``z`` is the per-sample world depth (to_world_depth of the bin's t)."""
+    fp, fd = scene.pos_enc[1]
+    o, d = p, nds
+    dir_pe = nds
+    if scene.use_ndc:
+        o, d = ndc_rays(h, w, focal_from_fov(w, scene.fov), 1.0, p, nds)
+        dir_pe = (d / np.sqrt(np.sum(d * d, -1, keepdims=True, dtype=F32))).astype(F32)
+    x = (o[sample_ray] + d[sample_ray] * z[:, None]).astype(F32)
+    if scene.normalization == "InverseSqrtDistCentered":
+        # src/nerf_raymarch_common.py:226-230
+        c = np.array(scene.view_cell_center, dtype=F32)
+        loc = (x - c).astype(F32)
+        local = np.sqrt(np.sqrt(np.sum(loc * loc, -1, dtype=F32))).astype(F32)
+        x = (loc / (F32(math.sqrt(scene.max_depth)) * local[:, None])).astype(F32)
+    elif scene.normalization != "None":
+        raise NotImplementedError(scene.normalization)
+    return np.concatenate([positional_encoding(x, fp),
+                           positional_encoding(dir_pe[sample_ray], fd)], -1).astype(F32)
+
+
+# --------------------------------------------------------------------------------------
+# A7  compositing
+# --------------------------------------------------------------------------------------
+
+def sigmoid(x):
+    x = x.astype(F32)
+    return (F32(1.0) / (F32(1.0) + np.exp(-x, dtype=F32))).astype(F32)
+
+
+def composite(raw: np.ndarray, sample_w: np.ndarray, ray_offset: np.ndarray, count: np.ndarray,
+              accumulation_mult: str = "alpha") -> np.ndarray:
+    """src/nerf_raymarch_common.py:91-144 (adaptive_raw2outputs): sigmoid on all four
+    channels, alpha *= oracle value, w = alpha * cumprod(1 - alpha + 1e-10) (exclusive),
+    rgb = sum w*c.  Inactive slots contribute alpha 0.  fp32, unclamped.  [R,3]."""
+    r = count.shape[0]
+    n = int(count.max()) if r else 0
+    sg = sigmoid(raw)
+    rgb = np.zeros((r, 3), dtype=F32)
+    trans = np.ones(r, dtype=F32)
+    for s in range(n):
+        act = count > s
+        idx = np.where(act, ray_offset + s, 0)
+        a = np.where(act, sg[idx, 3], F32(0)).astype(F32)
+        if accumulation_mult == "alpha":
+            a = (a * np.where(act, sample_w[idx], F32(0))).astype(F32)
+        wgt = (a * trans).astype(F32)
+        if accumulation_mult == "weights":
+            wgt = (wgt * np.where(act, sample_w[idx], F32(0))).astype(F32)
+        rgb += (wgt[:, None] * np.where(act[:, None], sg[idx, :3], F32(0))).astype(F32)
+        trans = (trans * (F32(1.0) - a + F32(1e-10))).astype(F32)
+    return rgb
+
+
+def to_rgba8(rgb: np.ndarray) -> np.ndarray:
+    """Viewer output contract (adaptive_cuda_kernels.cu:846-851): (uchar)(clamp(v,0,1)*255), A=255."""
+    v = np.clip(rgb.astype(F32), F32(0), F32(1)) * F32(255.0)
+    out = np.full((rgb.shape[0], 4), 255, dtype=np.uint8)
+    out[:, :3] = v.astype(np.uint8)
+    return out
+
+
+def psnr(a: np.ndarray, b: np.ndarray) -> float:
+    """src/evaluate.py:49-54: 10*log10(1/mse), mse over all values."""
+    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    return float("inf") if mse == 0 else 10.0 * math.log10(1.0 / mse)
+
+
+# --------------------------------------------------------------------------------------
+# A8  frame / chunk driver
+# --------------------------------------------------------------------------------------
+
+def render_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: Scene,
+                weights: Weights, w: int = 0, h: int = 0, chunk: int = 8192,
+                keep: bool = False):
+    """TrainConfig.inference (src/train_data.py:278-299) over chunks
+    (src/evaluate.py:206-241).  Returns dict with rgb [R,3], count [R] and, when ``keep``,
+    every intermediate the golden fixtures hold."""
+    out_rgb = []
+    out_cnt = []
+    kept: Dict[str, list] = {}
+    n_pos = 3 + 6 * scene.pos_enc[1][0]
+    for s in range(0, dirs_cam.shape[0], chunk):
+        dc = dirs_cam[s:s + chunk]
+        nds, p = world_rays(dc, pose, rot, scene)
+        feat0 = oracle_features(nds, p, scene)
+        orc = sampling_mlp(feat0, weights.net0)
+        if scene.threshold == 0.0:
+            r = orc.shape[0]
+            count = np.full(r, D_BINS, dtype=np.int32)
+            bins = np.repeat(np.arange(D_BINS, dtype=np.int16)[None], r, 0)
+            wts = orc
+            tt = np.repeat(dense_t(scene)[None], r, 0)
+        else:
+            count, bins, wts = select_adaptive(orc, scene.num_samples, scene.threshold)
+            tt = bin_t(bins)
+        off, sray, sbin, sw = compact(count, bins, wts)
+        mask = np.arange(bins.shape[1])[None, :] < count[:, None]
+        z = to_world_depth(tt[mask], scene)
+        feat1 = shading_inputs(p, nds, sray, z, scene, w, h)
+        raw = shading_mlp(feat1, weights.net1, n_pos)
+        rgb = composite(raw, sw, off, count, scene.accumulation_mult)
+        out_rgb.append(rgb)
+        out_cnt.append(count)
+        if keep:
+            for k, v in dict(nds=nds, p=p, feat0=feat0, orc=orc, bins=bins, wts=wts, z=z,
+                             feat1=feat1, raw=raw).items():
+                kept.setdefault(k, []).append(v)
+    res = {"rgb": np.concatenate(out_rgb), "count": np.concatenate(out_cnt)}
+    if keep:
+        for k, v in kept.items():
+            res[k] = np.concatenate(v)
+    return res
+
+
+def render_frame(scene: Scene, weights: Weights, w: int, h: int, pose: np.ndarray, rot: np.ndarray,
+                 chunk: int = 8192, rows: Optional[Tuple[int, int]] = None):
+    dirs = generate_ray_directions(w, h, scene.fov)
+    if rows is not None:
+        dirs = dirs[rows[0] * w: rows[1] * w]
+    return render_rays(dirs, pose, rot, scene, weights, w, h, chunk)

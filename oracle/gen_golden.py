@@ -1,0 +1,385 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by IMPORTING the reference's PyTorch path from
+/root/reference/src (build container only -- the reference never travels) and driving
+``TrainConfig.inference`` (src/train_data.py:278-299) on seeded ray batches.
+
+This script is ours; nothing of the reference is copied.  The six third-party modules the
+reference imports at module top but never executes on the inference path are stubbed with
+empty modules.  Also records the reference's own CPU timing for
+BASELINE configs 1-3 into tests/golden/reference_cpu_timing.json (``--timing``).
+
+Usage:  python oracle/gen_golden.py [--timing]
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+import types
+from types import SimpleNamespace
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+
+import adanerf_oracle as O  # noqa: E402  (for the ONNX reader, scene parser and ray table only)
+
+
+def import_reference():
+    for m in ["configargparse", "cv2", "imageio", "transforms3d", "ptflops", "pyrtools",
+              "onnx", "onnxruntime", "tqdm", "matplotlib", "matplotlib.pyplot"]:
+        if m not in sys.modules:
+            try:
+                __import__(m)
+            except Exception:
+                mod = types.ModuleType(m)
+                if m == "tqdm":
+                    mod.tqdm = lambda x, *a, **k: x
+                sys.modules[m] = mod
+    sys.path.insert(0, os.path.join(REF, "src"))
+    import torch  # noqa
+    import features, models, nerf_raymarch_common, train_data  # noqa
+    import util.depth_transformations as dt  # noqa
+    return SimpleNamespace(torch=torch, features=features, models=models,
+                           nrc=nerf_raymarch_common, train_data=train_data, dt=dt)
+
+
+def make_config(scene: O.Scene):
+    n = scene.num_samples
+    sampler = "FromClassifiedDepthAdaptiveNoDepthRange" if scene.use_ndc else "FromClassifiedDepthAdaptive"
+    return SimpleNamespace(
+        inFeatures=["SpherePosDir", "RayMarchFromPoses"], outFeatures=["Raw", "RGBARayMarch"],
+        posEnc=["nerf", "nerf"],
+        posEncArgs=["%d-%d" % scene.pos_enc[0], "%d-%d" % scene.pos_enc[1]],
+        raySampleInput=[0, 0], multiDepthFeatures=[128, 128], multiDepthIgnoreValue=[1.01, 1.01],
+        multiDepthWindowSize=[], activation=["relu", "nerf"], layers=[8, 8], layerWidth=[256, 256],
+        skips=["", "auto"], losses=["NeRFWeightMultiplicationLoss", "MSE"],
+        numRaymarchSamples=[n, n], rayMarchSampler=["none", sampler],
+        rayMarchSamplingStep=[1 / 128.0, 1 / 128.0], rayMarchSamplingNoise=[0.0, 0.0],
+        rayMarchNormalization=["InverseSqrtDistCentered", scene.normalization],
+        rayMarchNormalizationCenter=[], adaptiveSamplingThreshold=scene.threshold,
+        accumulationMult=scene.accumulation_mult, zNear=[scene.z_near, scene.z_near],
+        zFar=[scene.z_far, scene.z_far], trainWithGTDepth=False, deterministicSampling=False,
+        useNDC=scene.use_ndc, perturb=False, device="cpu", storeFullData=True,
+        depthTransform=scene.depth_transform)
+
+
+class Wrapper:
+    def __init__(self, d):
+        self.d = d
+
+    def get_batch_input(self, i):
+        return self.d
+
+
+def build_reference(R, scene: O.Scene, weights: O.Weights, w, h):
+    torch = R.torch
+    cfg = make_config(scene)
+    f_in, f_out = R.features.FeatureSet.get_sets(cfg, "cpu")
+    view = SimpleNamespace(fov=scene.fov, focal=O.focal_from_fov(w, scene.fov),
+                           view_cell_center=list(scene.view_cell_center),
+                           view_cell_size=list(scene.view_cell_size))
+    di = SimpleNamespace(w=w, h=h, view=view, depth_max=scene.max_depth,
+                         depth_range=list(scene.depth_range), depth_range_warped=list(scene.depth_range),
+                         depth_transform=R.dt.LogTransform if scene.depth_transform == "log" else R.dt.LinearTransform,
+                         use_warped_depth_range=[True, True])
+    for f in f_in:
+        f.initialize(cfg, di, "cpu")
+    tc = R.train_data.TrainConfig()
+    tc.f_in, tc.f_out = f_in, f_out
+    n_in = [f.n_feat for f in f_in]
+    m0 = R.models.ModelSelection.getModel(cfg, n_in[0], 128, "cpu", 0)
+    m1 = R.models.ModelSelection.getModel(cfg, n_in[1], 4, "cpu", 1)
+    m0.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in weights.net0.items()})
+    m1.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in weights.net1.items()})
+    m0.eval()
+    m1.eval()
+    tc.models = [m0, m1]
+    return tc
+
+
+def run_reference(R, tc, dirs, pose, rot, chunk=8192):
+    torch = R.torch
+    K = R.features.FeatureSetKeyConstants
+    acc = {}
+    for s in range(0, dirs.shape[0], chunk):
+        dc = dirs[s:s + chunk]
+        batch = {"ImagePose": torch.from_numpy(pose[None].copy()),
+                 "ImageRotation": torch.from_numpy(rot[None].copy()),
+                 "RayDirectionsSamples": torch.from_numpy(dc[None].copy())}
+        with torch.no_grad():
+            outs, dicts = tc.inference(Wrapper(batch), gradient=False, is_inference=True)
+        d0, d1 = dicts
+        n = dc.shape[0]
+        item = dict(feat0=d0[K.input_feature_batch], orc=d0[K.network_output],
+                    p=d0[K.input_feature_ray_origins], nds=d0[K.input_feature_ray_directions],
+                    rgb=outs[1])
+        raw = d1[K.network_output]
+        zv = d1[K.nerf_input_feature_z_vals]
+        f1 = d1[K.input_feature_batch]
+        ow = d1[K.oracle_weights]
+        if raw.dim() == 3:   # adaptive path restored to [R, N, 4] with zero fill / NaN markers
+            fin = torch.isfinite(zv)
+            item["count"] = fin.sum(1).to(torch.int32)
+            item["z"] = zv[fin]
+            item["raw"] = raw[fin]
+            item["feat1"] = f1[fin]
+            item["wts_slot"] = ow
+            item["z_slot"] = torch.nan_to_num(zv, nan=0.0)
+        else:                # dense path [R*128, ...]
+            item["count"] = torch.full((n,), 128, dtype=torch.int32)
+            item["z"] = zv.reshape(-1)
+            item["raw"] = raw
+            item["feat1"] = f1
+            item["wts_slot"] = ow
+            item["z_slot"] = zv
+        for k, v in item.items():
+            acc.setdefault(k, []).append(v.numpy())
+    return {k: np.concatenate(v) for k, v in acc.items()}
+
+
+def z_to_bins(z_slot, count, scene: O.Scene, n_max):
+    """Recover the kept bin ids from the reference's z values (slot-major [R,N], active
+    slots first in ascending depth): invert to_world and round to the bin centre."""
+    z = z_slot.astype(np.float64)
+    if scene.use_ndc:
+        t = z
+    elif scene.depth_transform == "log":
+        d0, d1 = scene.depth_range
+        t = np.log(np.maximum(z - d0 + 1.0, 1e-30)) / math.log(d1 - d0 + 1.0)
+    else:
+        d0, d1 = scene.depth_range
+        t = (z - d0) / (d1 - d0)
+    k = np.rint(t * 128.0 - 0.5).astype(np.int64)
+    mask = np.arange(n_max)[None, :] < count[:, None]
+    return np.where(mask, k, -1).astype(np.int16)
+
+
+def classroom_scene(n, thr):
+    return O.load_scene(os.path.join(REF, "adanerf_real_time_viewer", "sample_pavillon_16") + "/", n, thr)
+
+
+def subset_dirs(w, h, fov, x0, y0, cw, ch, stride=1):
+    """[ch, cw] rays starting at pixel (x0, y0), every ``stride``-th pixel in both axes."""
+    dirs = O.generate_ray_directions(w, h, fov).reshape(h, w, 3)
+    return np.ascontiguousarray(dirs[y0:y0 + ch * stride:stride, x0:x0 + cw * stride:stride].reshape(-1, 3))
+
+
+def save_case(name, scene, meta, dirs, pose, rot, ref, n_max, weights_tag):
+    count = ref["count"].astype(np.int32)
+    if scene.threshold == 0.0:
+        bins = np.repeat(np.arange(128, dtype=np.int16)[None], count.shape[0], 0)
+        wts = ref["wts_slot"].astype(np.float32)
+    else:
+        bins = z_to_bins(ref["z_slot"], count, scene, n_max)
+        wts = ref["wts_slot"].astype(np.float32)
+    m = dict(meta)
+    m.update(dict(view_cell_center=list(scene.view_cell_center), view_cell_size=list(scene.view_cell_size),
+                  depth_range=list(scene.depth_range), fov=scene.fov, max_depth=scene.max_depth,
+                  num_samples=scene.num_samples, threshold=scene.threshold, z_near=scene.z_near,
+                  z_far=scene.z_far, use_ndc=scene.use_ndc, depth_transform=scene.depth_transform,
+                  pos_enc=[list(scene.pos_enc[0]), list(scene.pos_enc[1])],
+                  normalization=scene.normalization, accumulation_mult=scene.accumulation_mult,
+                  weights=weights_tag))
+    n_f = min(64, ref["feat0"].shape[0])
+    m_f = min(64, ref["feat1"].shape[0])
+    raw = ref["raw"].astype(np.float32)
+    if raw.shape[0] > 40000:      # dense: keep the first 32 rays' samples only
+        raw = raw[:32 * 128]
+    np.savez_compressed(
+        os.path.join(GOLD, name + ".npz"),
+        meta=np.frombuffer(json.dumps(m).encode(), dtype=np.uint8),
+        pose=pose.astype(np.float32), rot=rot.astype(np.float32), ray_dirs=dirs.astype(np.float32),
+        nds=ref["nds"].astype(np.float32), p=ref["p"].astype(np.float32),
+        oracle_in=ref["feat0"][:n_f].astype(np.float32), oracle_out=ref["orc"].astype(np.float32),
+        sel_count=count.astype(np.uint8), sel_bins=bins, sel_weight=wts,
+        z_world=ref["z"][:4096].astype(np.float32), shade_in=ref["feat1"][:m_f].astype(np.float32),
+        shade_out=raw, rgb=ref["rgb"].astype(np.float32))
+    sz = os.path.getsize(os.path.join(GOLD, name + ".npz"))
+    print("wrote %s.npz (%d KB)  rays=%d samples=%d mean=%.2f" %
+          (name, sz // 1024, count.shape[0], int(count.sum()), float(count.mean())))
+
+
+def gen_selection_edge_cases(R):
+    """Synthetic oracle rows through the reference sampler alone
+    (FromClassifiedDepthAdaptive.generate, src/nerf_raymarch_common.py:699-757):
+    none >= thr, exact-threshold values, > N above thr, ties inside the top-N (not at the
+    cutoff), plus random rows.  Rows whose tie straddles the N-cutoff are excluded (the
+    reference's unstable sort makes them implementation-defined)."""
+    torch = R.torch
+    rng = np.random.default_rng(1234)
+    out = {}
+    for n_max, thr in [(1, 0.3), (4, 0.15), (8, 0.2), (16, 0.15), (32, 0.1)]:
+        rows = []
+        rows.append(rng.uniform(-0.5, thr - 0.01, size=(64, 128)))                    # none >= thr
+        a = rng.uniform(-0.5, 1.8, size=(128, 128))                                    # random
+        rows.append(a)
+        b = rng.uniform(-0.5, thr - 0.05, size=(64, 128))                              # exact thr
+        for i in range(64):
+            idx = rng.choice(128, size=rng.integers(1, n_max + 1), replace=False)
+            b[i, idx] = thr
+        rows.append(b)
+        rows.append(rng.uniform(thr + 0.01, 1.8, size=(64, 128)))                     # all above thr
+        c = rng.uniform(-0.5, 0.1, size=(64, 128))                                    # ties inside top-N
+        for i in range(64):
+            if n_max >= 3:
+                idx = rng.choice(128, size=3, replace=False)
+                c[i, idx[:2]] = 1.5
+                c[i, idx[2]] = 1.7
+        rows.append(c)
+        d = rng.uniform(-0.5, 1.8, size=(128, 128)) * (rng.uniform(size=(128, 128)) < 0.08)  # sparse peaks
+        rows.append(d)
+        orc = np.concatenate(rows).astype(np.float32)
+        # drop rows with a tie straddling the N cutoff
+        srt = -np.sort(-orc, axis=1)
+        ok = np.ones(orc.shape[0], dtype=bool)
+        if n_max < 128:
+            ok &= ~((srt[:, n_max - 1] == srt[:, n_max]) & (srt[:, n_max - 1] >= np.float32(thr)))
+        ok &= ~((srt[:, 0] == srt[:, 1]) & (srt[:, 0] < np.float32(thr)))            # arg-max tie in 'none' rows
+        orc = orc[ok]
+        scene = O.Scene((0, 0, 0), (1, 1, 1), (0.25, 9.5), 1.0, 10.0, n_max, thr)
+        cfg = make_config(scene)
+        smp = R.nrc.FromClassifiedDepthAdaptive(0.001, 1.0, n_max, 1 / 128.0, 0.0, config=cfg, net_idx=1)
+        z, probs = smp.generate(orc.shape[0], "cpu", depth=torch.from_numpy(orc.copy()),
+                                depth_range=list(scene.depth_range), depth_transform=R.dt.LogTransform)
+        z = z.numpy()
+        count = np.isfinite(z).sum(1).astype(np.int32)
+        bins = z_to_bins(np.where(np.isfinite(z), z, 0.0), count, scene, n_max)
+        key = "n%d" % n_max
+        out[key + "_orc"] = orc
+        out[key + "_thr"] = np.float32(thr)
+        out[key + "_count"] = count.astype(np.uint8)
+        out[key + "_bins"] = bins
+        out[key + "_weight"] = probs.numpy().astype(np.float32)
+        out[key + "_z"] = np.where(np.isfinite(z), z, 0.0).astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "selection_edge_cases.npz"), **out)
+    print("wrote selection_edge_cases.npz (%d KB)" % (os.path.getsize(os.path.join(GOLD, "selection_edge_cases.npz")) // 1024))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--timing", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    R = import_reference()
+    torch = R.torch
+    torch.manual_seed(0)
+
+    classroom = os.path.join(REF, "adanerf_real_time_viewer", "sample_pavillon_16") + "/"
+    barber = os.path.join(REF, "adanerf_real_time_viewer", "sample") + "/"
+    w_class = O.load_weights(classroom)
+    w_barb = O.load_weights(barber)
+
+    # real exported weights travel as data fixtures (the GPU box has no /root/reference)
+    for tag, wts in [("sample_pavillon_16", w_class), ("sample", w_barb)]:
+        d = {"n0/" + k: v for k, v in wts.net0.items()}
+        d.update({"n1/" + k: v for k, v in wts.net1.items()})
+        np.savez_compressed(os.path.join(GOLD, "weights_%s.npz" % tag), **d)
+        sc0 = O.load_scene(classroom if tag == "sample_pavillon_16" else barber)
+        with open(os.path.join(GOLD, "scene_%s.json" % tag), "w") as f:
+            json.dump(dict(view_cell_center=sc0.view_cell_center, view_cell_size=sc0.view_cell_size,
+                           depth_range=sc0.depth_range, fov=sc0.fov, max_depth=sc0.max_depth,
+                           num_samples=sc0.num_samples, threshold=sc0.threshold), f, indent=1)
+
+    # --- case A: classroom weights, 800x800 frame, 48x32 crop, N=8 thr .2 (BASELINE config 2)
+    sc = classroom_scene(8, 0.2)
+    pose = np.array(sc.view_cell_center, dtype=np.float32)
+    rot = O.camera_rotation(100.0, 0.0)
+    dirs = subset_dirs(800, 800, sc.fov, 8, 10, 48, 32, 16)
+    tc = build_reference(R, sc, w_class, 800, 800)
+    ref = run_reference(R, tc, dirs, pose, rot)
+    save_case("classroom_n8_thr02", sc, dict(w=800, h=800, crop=[8, 10, 48, 32, 16], yaw=100.0, pitch=0.0),
+              dirs, pose, rot, ref, 8, "sample_pavillon_16")
+
+    # --- case B: classroom weights N=16 thr .15 (shipped config), off-centre pose
+    sc = classroom_scene(16, 0.15)
+    pose_b = (np.array(sc.view_cell_center) + np.array([0.2, -0.1, 0.05])).astype(np.float32)
+    rot_b = O.camera_rotation(-80.0, 10.0)
+    dirs = subset_dirs(400, 400, sc.fov, 4, 6, 32, 24, 12)
+    tc = build_reference(R, sc, w_class, 400, 400)
+    ref = run_reference(R, tc, dirs, pose_b, rot_b)
+    save_case("classroom_n16_thr015", sc, dict(w=400, h=400, crop=[4, 6, 32, 24, 12], yaw=-80.0, pitch=10.0),
+              dirs, pose_b, rot_b, ref, 16, "sample_pavillon_16")
+
+    # --- case C: dense 128 (BASELINE config 3), small crop
+    sc = classroom_scene(128, 0.0)
+    dirs = subset_dirs(800, 800, sc.fov, 400, 400, 16, 8)
+    tc = build_reference(R, sc, w_class, 800, 800)
+    ref = run_reference(R, tc, dirs, pose, rot)
+    save_case("classroom_dense128", sc, dict(w=800, h=800, crop=[400, 400, 16, 8], yaw=100.0, pitch=0.0),
+              dirs, pose, rot, ref, 128, "sample_pavillon_16")
+
+    # --- case D: barbershop weights N=4 thr .15
+    sc = O.load_scene(barber)
+    pose_d = np.array(sc.view_cell_center, dtype=np.float32)
+    rot_d = O.camera_rotation(-80.0, 0.0)
+    dirs = subset_dirs(800, 800, sc.fov, 5, 7, 48, 32, 16)
+    tc = build_reference(R, sc, w_barb, 800, 800)
+    ref = run_reference(R, tc, dirs, pose_d, rot_d)
+    save_case("barbershop_n4_thr015", sc, dict(w=800, h=800, crop=[5, 7, 48, 32, 16], yaw=-80.0, pitch=0.0),
+              dirs, pose_d, rot_d, ref, 4, "sample")
+
+    # --- case E: synthetic weights, fixed 8 samples/ray (BASELINE config 1 plumbing): every
+    #     oracle output >= thr, so each ray keeps exactly its top-8.
+    sc = classroom_scene(8, 0.05)
+    w_syn = O.synthetic_weights(0, oracle_bias=3.0, oracle_scale=0.05)
+    dirs = subset_dirs(400, 400, sc.fov, 180, 190, 32, 32)
+    tc = build_reference(R, sc, w_syn, 400, 400)
+    ref = run_reference(R, tc, dirs, pose, rot)
+    save_case("synthetic_fixed8", sc, dict(w=400, h=400, crop=[180, 190, 32, 32], yaw=100.0, pitch=0.0,
+                                           syn=dict(seed=0, oracle_bias=3.0, oracle_scale=0.05)),
+              dirs, pose, rot, ref, 8, "synthetic")
+
+    # --- case F: NDC / linear depth / 2-2 oracle encoding (BASELINE config 5), synthetic weights
+    sc = O.Scene(view_cell_center=(0.0, 0.0, 0.0), view_cell_size=(2.0, 2.0, 1.0), depth_range=(0.9, 12.0),
+                 fov=1.0, max_depth=12.0, num_samples=8, threshold=0.2, use_ndc=True,
+                 depth_transform="linear", pos_enc=((2, 2), (10, 4)), normalization="None")
+    w_ndc = O.synthetic_weights(7, n_in0=30, oracle_bias=-0.55, oracle_scale=0.5)
+    pose_f = np.array([0.1, -0.05, 0.2], dtype=np.float32)
+    rot_f = np.eye(3, dtype=np.float32)   # LLFF-style camera looking down -z
+    full = O.generate_ray_directions(480, 270, sc.fov).reshape(270, 480, 3)
+    dirs = np.ascontiguousarray(full[100:132, 200:248].reshape(-1, 3))
+    tc = build_reference(R, sc, w_ndc, 480, 270)
+    ref = run_reference(R, tc, dirs, pose_f, rot_f)
+    save_case("ndc_synthetic_n8", sc, dict(w=480, h=270, crop=[200, 100, 48, 32], yaw=0.0, pitch=0.0,
+                                           syn=dict(seed=7, n_in0=30, oracle_bias=-0.55, oracle_scale=0.5)),
+              dirs, pose_f, rot_f, ref, 8, "synthetic")
+
+    gen_selection_edge_cases(R)
+
+    if args.timing:
+        timing = {"host": "build container", "threads": torch.get_num_threads(), "dtype": "fp32",
+                  "note": "reference PyTorch path imported from /root/reference/src, chunk 8192, "
+                          "median of repeats, shipped sample_pavillon_16 weights"}
+        runs = []
+        for (nm, n, thr, w, h, rows, reps) in [("config1_400x400_n8", 8, 0.2, 400, 400, 40, 3),
+                                               ("config2_800x800_n8_thr0.2", 8, 0.2, 800, 800, 20, 3),
+                                               ("config3_800x800_dense128", 128, 0.0, 800, 800, 1, 2)]:
+            sc = classroom_scene(n, thr)
+            tc = build_reference(R, sc, w_class, w, h)
+            dirs = O.generate_ray_directions(w, h, sc.fov)[(h // 2) * w:(h // 2 + rows) * w]
+            pose = np.array(sc.view_cell_center, dtype=np.float32)
+            ts = []
+            cnt = None
+            for _ in range(reps):
+                t0 = time.time()
+                r = run_reference(R, tc, dirs, pose, O.camera_rotation(100.0, 0.0))
+                ts.append(time.time() - t0)
+                cnt = float(r["count"].mean())
+            t = float(np.median(ts))
+            runs.append(dict(config=nm, rays=int(dirs.shape[0]), seconds=t, rays_per_s=dirs.shape[0] / t,
+                             mean_samples_per_ray=cnt,
+                             extrapolated_s_per_frame=t * (w * h) / dirs.shape[0]))
+            print(runs[-1])
+        timing["runs"] = runs
+        with open(os.path.join(GOLD, "reference_cpu_timing.json"), "w") as f:
+            json.dump(timing, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

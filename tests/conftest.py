@@ -1,0 +1,49 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_case(name):
+    """Loads a golden fixture written by oracle/gen_golden.py; returns (npz dict, meta, Scene)."""
+    import adanerf_oracle as O
+    z = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    meta = json.loads(bytes(z.pop("meta")).decode())
+    sc = O.Scene(view_cell_center=tuple(meta["view_cell_center"]), view_cell_size=tuple(meta["view_cell_size"]),
+                 depth_range=tuple(meta["depth_range"]), fov=meta["fov"], max_depth=meta["max_depth"],
+                 num_samples=meta["num_samples"], threshold=meta["threshold"], z_near=meta["z_near"],
+                 z_far=meta["z_far"], use_ndc=meta["use_ndc"], depth_transform=meta["depth_transform"],
+                 pos_enc=(tuple(meta["pos_enc"][0]), tuple(meta["pos_enc"][1])),
+                 normalization=meta["normalization"], accumulation_mult=meta["accumulation_mult"])
+    return z, meta, sc
+
+
+def case_weights(meta):
+    """Weights for a golden case: shipped sample dirs are NOT available on the GPU box, so the
+    real-weight cases carry their weights in tests/golden/weights_<tag>.npz (data fixtures
+    extracted from the exported ONNX initializers by oracle/gen_golden.py)."""
+    import adanerf_oracle as O
+    tag = meta["weights"]
+    if tag == "synthetic":
+        s = meta["syn"]
+        return O.synthetic_weights(s["seed"], n_in0=s.get("n_in0", 90), oracle_bias=s["oracle_bias"],
+                                   oracle_scale=s["oracle_scale"])
+    z = np.load(os.path.join(GOLD, "weights_%s.npz" % tag))
+    n0 = {k[3:]: z[k] for k in z.files if k.startswith("n0/")}
+    n1 = {k[3:]: z[k] for k in z.files if k.startswith("n1/")}
+    return O.Weights(n0, n1)
+
+
+CASES = ["classroom_n8_thr02", "classroom_n16_thr015", "classroom_dense128", "barbershop_n4_thr015",
+         "synthetic_fixed8", "ndc_synthetic_n8"]
