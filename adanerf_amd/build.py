@@ -1,0 +1,74 @@
+"""In-tree build of the HIP shared library and the host CLI (hipcc, gfx950 only)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+LIBDIR = os.path.join(HERE, "lib")
+BINDIR = os.path.join(HERE, "bin")
+LIB_SOURCES = ["adanerf_hip.hip", "format.cpp", "pack.cpp"]
+LIB_DEPS = LIB_SOURCES + ["kernels.hip.hpp", "layout.hpp", "format.hpp", "pack.hpp", os.path.join("..", "..", "include", "adanerf_hip.h")]
+ARCH = "gfx950"
+
+
+def library_path():
+    return os.path.join(LIBDIR, "libadanerf_hip.so")
+
+
+def cli_path():
+    return os.path.join(BINDIR, "adanerf")
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the MI355X build needs the ROCm toolchain")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -shared -> adanerf_amd/lib/libadanerf_hip.so (cross-compiles without a GPU)."""
+    out = library_path()
+    deps = [os.path.join(CSRC, d) for d in LIB_DEPS]
+    if not force and not _stale(out, deps):
+        return out
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared"] + \
+          [os.path.join(CSRC, s) for s in LIB_SOURCES] + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return out
+
+
+def build_cli(force=False, verbose=False):
+    """Headless `adanerf` host executable (same CLI as the reference viewer) linked against the library."""
+    lib = build_library(force=force, verbose=verbose)
+    out = cli_path()
+    srcs = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith(".cpp")] if os.path.isdir(HOST) else []
+    if not srcs:
+        return None
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")] + [lib]
+    if not force and not _stale(out, deps):
+        return out
+    os.makedirs(BINDIR, exist_ok=True)
+    cmd = [_hipcc(), "-O2", "-std=c++17"] + srcs + ["-I", os.path.join(HERE, "..", "include"), "-L", LIBDIR,
+                                                     "-ladanerf_hip", "-Wl,-rpath,$ORIGIN/../lib", "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return out
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))
+    print(build_cli(force=True, verbose=True))

@@ -1,0 +1,740 @@
+// C ABI of libadanerf_hip.so (see include/adanerf_hip.h).  Host side: model loading, weight
+// packing/upload, buffer ownership, per-frame launch sequence on the context's own HIP stream.
+#include "../../include/adanerf_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "format.hpp"
+#include "kernels.hip.hpp"
+#include "pack.hpp"
+
+using namespace adanerf;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct PackedDev {
+  DevBuf w, b;
+  NetParams params{};
+};
+
+}  // namespace
+
+struct adanerf_ctx {
+  adanerf_options opt{};
+  adanerf_info info{};
+  Config cfg;
+  std::string err;
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> events;
+
+  RayGenParams rg{};
+  ShadeParams sp{};
+  int mult_mode = 1;   // 0 none, 1 alpha, 2 weights
+  int fp0 = 10, fd0 = 4, fp1 = 10, fd1 = 4;
+
+  PackedDev net0;                 // sampling net, fp32 fragments
+  PackedDev net1[3];              // shading net per precision (packed lazily)
+  TensorMap net1_host;
+  DevBuf ztab;
+
+  // per-batch buffers
+  int cap_rays = 0, cap_nmax = 0;
+  DevBuf rays, oracle, ray_offsets, ray_counts, selbin, selw, block_total, block_offset, total;
+  DevBuf sample_key, sample_w, raw;
+  int shade_grid[3] = {0, 0, 0};
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+      return ADANERF_EDEVICE;                                                               \
+    }                                                                                       \
+  } while (0)
+
+int fail(adanerf_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+int dev_alloc(adanerf_ctx* c, DevBuf* b, size_t bytes) {
+  if (b->bytes >= bytes && b->p) return ADANERF_OK;
+  if (b->p) HIP_TRY(c, hipFree(b->p));
+  b->p = nullptr;
+  b->bytes = 0;
+  if (bytes == 0) return ADANERF_OK;
+  HIP_TRY(c, hipMalloc(&b->p, bytes));
+  b->bytes = bytes;
+  return ADANERF_OK;
+}
+
+void dev_free(DevBuf* b) {
+  if (b->p) (void)hipFree(b->p);
+  b->p = nullptr;
+  b->bytes = 0;
+}
+
+int upload_net(adanerf_ctx* c, const PackedNet& pn, PackedDev* d) {
+  int rc;
+  if ((rc = dev_alloc(c, &d->w, pn.weights.size()))) return rc;
+  if ((rc = dev_alloc(c, &d->b, pn.bias.size() * sizeof(float)))) return rc;
+  HIP_TRY(c, hipMemcpy(d->w.p, pn.weights.data(), pn.weights.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(d->b.p, pn.bias.data(), pn.bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  d->params.w = reinterpret_cast<const u32x4*>(d->w.p);
+  d->params.bias = reinterpret_cast<const float*>(d->b.p);
+  for (size_t i = 0; i < pn.w_off.size() && i < kMaxLayers; ++i) {
+    d->params.w_off[i] = pn.w_off[i];
+    d->params.b_off[i] = pn.b_off[i];
+  }
+  return ADANERF_OK;
+}
+
+
+struct ModelSetup {
+  Config cfg;
+  adanerf_info info{};
+  RayGenParams rg{};
+  ShadeParams sp{};
+  int mult_mode = 1;
+  int fp0 = 10, fd0 = 4, fp1 = 10, fd1 = 4;
+  std::vector<float> ztab;
+};
+
+Elem elem_of(int prec) { return prec == ADANERF_PREC_BF16 ? Elem::BF16 : (prec == ADANERF_PREC_FP16 ? Elem::F16 : Elem::F32); }
+
+// rows of the image owned by `rank` under round-robin strips
+int rows_of_rank(int h, int strip_rows, int world, int rank) {
+  int n_strips = (h + strip_rows - 1) / strip_rows;
+  int rows = 0;
+  for (int s = rank; s < n_strips; s += world) rows += std::min(strip_rows, h - s * strip_rows);
+  return rows;
+}
+
+bool contains(const std::string& s, const char* sub) { return s.find(sub) != std::string::npos; }
+
+// Host-only: parse + validate the model directory and derive every per-context constant.
+int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* ms, std::string* err) {
+  auto bad = [&](int code, const std::string& msg) {
+    *err = msg;
+    return code;
+  };
+  if (opt->width <= 0 || opt->height <= 0) return bad(ADANERF_EINVAL, "width/height must be positive");
+  if (!ms->cfg.load(model_dir, err)) return ADANERF_EIO;
+  const Config& cf = ms->cfg;
+
+  // ---- validate the configuration against the supported (north-star) path ----
+  if (cf.inFeatures.size() != 2 || cf.inFeatures[0] != "SpherePosDir" || cf.inFeatures[1] != "RayMarchFromPoses")
+    return bad(ADANERF_EUNSUPPORTED, "inFeatures must be [SpherePosDir, RayMarchFromPoses]");
+  if (cf.posEnc.size() != 2 || cf.posEnc[0] != "nerf" || cf.posEnc[1] != "nerf" || cf.posEncArgs.size() != 2)
+    return bad(ADANERF_EUNSUPPORTED, "posEnc must be [nerf, nerf] with two posEncArgs entries");
+  if (cf.rayMarchSampler.size() != 2 || !contains(cf.rayMarchSampler[1], "FromClassifiedDepthAdaptive"))
+    return bad(ADANERF_EUNSUPPORTED, "rayMarchSampler[1] must be FromClassifiedDepthAdaptive[NoDepthRange]");
+  for (int v : cf.raySampleInput)
+    if (v != 0) return bad(ADANERF_EUNSUPPORTED, "raySampleInput != 0 is outside the supported path");
+  if (cf.viewcellCenter.size() != 3 || cf.viewcellSize.size() != 3 || cf.depthRange.size() != 2 || cf.fov <= 0.f)
+    return bad(ADANERF_EIO, "dataset_info.txt: view_cell_center/view_cell_size/depth_range/fov missing or malformed");
+  if (cf.numRaymarchSamples.empty()) return bad(ADANERF_EIO, "config.ini: numRaymarchSamples missing");
+  ms->fp0 = static_cast<int>(cf.posEncArgs[0][0]);
+  ms->fd0 = static_cast<int>(cf.posEncArgs[0][1]);
+  ms->fp1 = static_cast<int>(cf.posEncArgs[1][0]);
+  ms->fd1 = static_cast<int>(cf.posEncArgs[1][1]);
+  if (!((ms->fp0 == 10 && ms->fd0 == 4) || (ms->fp0 == 2 && ms->fd0 == 2)))
+    return bad(ADANERF_EUNSUPPORTED, "posEncArgs[0] must be 10-4 or 2-2");
+  if (ms->fp1 != 10 || ms->fd1 != 4) return bad(ADANERF_EUNSUPPORTED, "posEncArgs[1] must be 10-4");
+  const bool ndc = cf.useNDC;
+  const bool no_range = contains(cf.rayMarchSampler[1], "NoDepthRange");
+  if (ndc != no_range) return bad(ADANERF_EUNSUPPORTED, "useNDC requires the NoDepthRange sampler and vice versa");
+  std::string norm = cf.rayMarchNormalization.size() >= 2 ? cf.rayMarchNormalization[1] : std::string("None");
+  if (norm != "InverseSqrtDistCentered" && norm != "None")
+    return bad(ADANERF_EUNSUPPORTED, "rayMarchNormalization[1] must be InverseSqrtDistCentered or None");
+  if (cf.depthTransform != "log" && cf.depthTransform != "linear")
+    return bad(ADANERF_EUNSUPPORTED, "depthTransform must be log or linear");
+  if (cf.accumulationMult == "alpha") ms->mult_mode = 1;
+  else if (cf.accumulationMult == "weights") ms->mult_mode = 2;
+  else ms->mult_mode = 0;
+
+  int n_max = opt->num_samples > 0 ? opt->num_samples : cf.numRaymarchSamples.back();
+  float thr = opt->threshold >= 0.f ? opt->threshold : cf.adaptiveSamplingThreshold;
+  if (thr < 0.f) return bad(ADANERF_EUNSUPPORTED, "adaptiveSamplingThreshold < 0 is unsupported on the adaptive path (as in the reference)");
+  if (thr == 0.f && n_max != kBins) return bad(ADANERF_EUNSUPPORTED, "adaptiveSamplingThreshold == 0 (dense) requires numRaymarchSamples == 128");
+  if (n_max < 1 || n_max > kBins) return bad(ADANERF_EINVAL, "numRaymarchSamples must be in 1..128");
+  if (opt->precision < 0 || opt->precision > 2) return bad(ADANERF_EINVAL, "precision must be ADANERF_PREC_{BF16,FP16,FP32}");
+
+  // ---- info / ray generation constants (A1: src/util/raygeneration.py:10-26, float64) ----
+  const int w = opt->width, h = opt->height;
+  adanerf_info& I = ms->info;
+  I.abi_version = ADANERF_ABI_VERSION;
+  I.width = w;
+  I.height = h;
+  I.compute_units = 0;
+  const int world = opt->shard_world > 0 ? opt->shard_world : 1;
+  const int rank = opt->shard_rank;
+  if (rank < 0 || rank >= world) return bad(ADANERF_EINVAL, "shard_rank out of range");
+  const int strip_rows = opt->strip_rows > 0 ? opt->strip_rows : 8;
+  I.rays_local = rows_of_rank(h, strip_rows, world, rank) * w;
+  I.rays_local_max = rows_of_rank(h, strip_rows, world, 0) * w;
+  const int R = I.rays_local;
+  if (static_cast<int64_t>(w) * h >= (1ll << 25)) return bad(ADANERF_EINVAL, "width*height must be < 2^25");
+  I.batch_rays = (opt->batch_rays <= 0) ? std::max(R, 1) : std::min(opt->batch_rays, std::max(R, 1));
+  I.n_in0 = 6 + 6 * (ms->fp0 + ms->fd0);
+  I.n_in1 = 6 + 6 * (ms->fp1 + ms->fd1);
+  I.num_samples = n_max;
+  I.threshold = thr;
+  I.dense = thr == 0.f;
+  I.use_ndc = ndc;
+  I.precision = opt->precision;
+  I.fov = cf.fov;
+  const double fov = cf.fov;
+  const double focal = 0.5 * w / std::tan(0.5 * fov);   // src/datasets.py:182
+  I.focal = static_cast<float>(focal);
+  const double x_dist = std::tan(fov / 2) * focal;
+  const double y_dist = x_dist * (static_cast<double>(h) / w);
+  const double x_pp = x_dist / (w / 2.0), y_pp = y_dist / (h / 2.0);
+  RayGenParams& g = ms->rg;
+  g.start_x = -(x_dist - x_pp / 2);
+  g.x_pp = x_pp;
+  g.start_y = -(y_dist - y_pp / 2);
+  g.y_pp = y_pp;
+  g.focal = focal;
+  g.w = w;
+  g.h = h;
+  g.strip_rows = strip_rows;
+  g.world = world;
+  g.rank = rank;
+  g.use_ndc = ndc;
+  double r2 = 0;
+  for (int i = 0; i < 3; ++i) {
+    g.center[i] = cf.viewcellCenter[i];
+    I.view_cell_center[i] = cf.viewcellCenter[i];
+    r2 += (static_cast<double>(cf.viewcellSize[i]) / 2.0) * (static_cast<double>(cf.viewcellSize[i]) / 2.0);
+  }
+  // radius = ||view_cell_size / 2||_2 (src/features.py:761); the reference squares the float64 norm
+  const double rad = std::sqrt(r2);
+  g.rad2 = static_cast<float>(rad * rad);
+  I.view_cell_radius = static_cast<float>(rad);
+  g.ndc_sw = static_cast<float>(-1.0 / (w / (2.0 * focal)));
+  g.ndc_sh = static_cast<float>(-1.0 / (h / (2.0 * focal)));
+  const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  std::memcpy(g.rot, ident, sizeof(ident));
+  for (int i = 0; i < 3; ++i) g.pos[i] = g.center[i];
+  I.depth_range[0] = cf.depthRange[0];
+  I.depth_range[1] = cf.depthRange[1];
+  I.max_depth = cf.max_depth;
+
+  ShadeParams& sp = ms->sp;
+  for (int i = 0; i < 3; ++i) sp.center[i] = cf.viewcellCenter[i];
+  sp.sqrt_max_depth = static_cast<float>(std::sqrt(static_cast<double>(cf.max_depth)));   // math.sqrt(max_depth)
+  sp.normalize = norm == "InverseSqrtDistCentered";
+  sp.unit_dir = ndc;
+  sp.ztab = nullptr;
+
+  // ---- depth table: world depth of each of the 128 bins (A4/A5) ----
+  ms->ztab.resize(kBins);
+  const float znear = cf.zNear.empty() ? 0.001f : cf.zNear.back();
+  const float zfar = cf.zFar.empty() ? 1.0f : cf.zFar.back();
+  const float d0 = cf.depthRange[0], d1 = cf.depthRange[1];
+  for (int k = 0; k < kBins; ++k) {
+    float t;
+    if (thr == 0.f) {
+      // src/nerf_raymarch_common.py:708-720: t = linspace(0,1,N+1)[:-1] + .5/N; z = near(1-t) + far t
+      float u = static_cast<float>(k) * (1.0f / kBins) + 0.5f / kBins;
+      t = znear * (1.0f - u) + zfar * u;
+    } else {
+      t = (static_cast<float>(k) + 0.5f) * (1.0f / kBins);   // (k + .5) * cell_size, :737-741
+    }
+    float z;
+    if (ndc) z = t;                                            // ...NoDepthRange: :796-851
+    else if (cf.depthTransform == "log")                       // util/depth_transformations.py:37-48
+      z = powf(static_cast<float>(static_cast<double>(d1) - d0 + 1.0), t) - 1.0f + d0;
+    else z = t * (d1 - d0) + d0;                               // :57-58
+    ms->ztab[k] = z;
+  }
+  return ADANERF_OK;
+}
+
+int ensure_net1(adanerf_ctx* c, int prec) {
+  if (prec < 0 || prec > 2) return fail(c, ADANERF_EINVAL, "precision must be ADANERF_PREC_{BF16,FP16,FP32}");
+  if (c->net1[prec].w.p) return ADANERF_OK;
+  PackedNet pn;
+  std::string err;
+  NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1};
+  if (!pack_shading_net(c->net1_host, sh, elem_of(prec), &pn, &err)) return fail(c, ADANERF_EIO, "model1.onnx: " + err);
+  return upload_net(c, pn, &c->net1[prec]);
+}
+
+
+int ensure_batch_buffers(adanerf_ctx* c, int n_rays, int n_max) {
+  if (n_rays <= c->cap_rays && n_max <= c->cap_nmax) return ADANERF_OK;
+  n_rays = std::max(n_rays, c->cap_rays);
+  n_max = std::max(n_max, c->cap_nmax);
+  const size_t R = static_cast<size_t>(n_rays), S = R * static_cast<size_t>(n_max);
+  const size_t nblk = (R + kSelRaysPerBlock - 1) / kSelRaysPerBlock;
+  int rc;
+  if ((rc = dev_alloc(c, &c->rays, R * 8 * sizeof(float)))) return rc;
+  if ((rc = dev_alloc(c, &c->oracle, R * kBins * sizeof(float)))) return rc;
+  if ((rc = dev_alloc(c, &c->ray_offsets, R * sizeof(int32_t)))) return rc;
+  if ((rc = dev_alloc(c, &c->ray_counts, R * sizeof(int32_t)))) return rc;
+  if ((rc = dev_alloc(c, &c->selbin, S))) return rc;
+  if ((rc = dev_alloc(c, &c->selw, S * sizeof(float)))) return rc;
+  if ((rc = dev_alloc(c, &c->block_total, nblk * sizeof(int32_t)))) return rc;
+  if ((rc = dev_alloc(c, &c->block_offset, nblk * sizeof(int32_t)))) return rc;
+  if ((rc = dev_alloc(c, &c->total, 64))) return rc;
+  if ((rc = dev_alloc(c, &c->sample_key, S * sizeof(uint32_t)))) return rc;
+  if ((rc = dev_alloc(c, &c->sample_w, S * sizeof(float)))) return rc;
+  if ((rc = dev_alloc(c, &c->raw, S * 4 * sizeof(float)))) return rc;
+  c->cap_rays = n_rays;
+  c->cap_nmax = n_max;
+  return ADANERF_OK;
+}
+
+// ---- launches ------------------------------------------------------------------------------
+
+int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle, float* d_rays) {
+  if (n_rays <= 0) return ADANERF_OK;
+  SampleArgs a{};
+  a.g = c->rg;
+  a.net = c->net0.params;
+  a.first_ray = first_ray;
+  a.n_rays = n_rays;
+  a.oracle_out = d_oracle;
+  a.rays_out = d_rays;
+  dim3 grid((n_rays + 127) / 128), block(256);
+  if (c->fp0 == 10 && c->fd0 == 4) hipLaunchKernelGGL((sample_mlp_kernel<10, 4>), grid, block, 0, c->stream, a);
+  else hipLaunchKernelGGL((sample_mlp_kernel<2, 2>), grid, block, 0, c->stream, a);
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max, float thr, int32_t* d_off, int32_t* d_cnt,
+                   uint32_t* d_key, float* d_w, int32_t* d_total) {
+  if (n_rays <= 0) return ADANERF_OK;
+  if (thr == 0.0f) {
+    const size_t n = static_cast<size_t>(n_rays) * kBins;
+    dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL(dense_expand_kernel, grid, block, 0, c->stream, d_oracle, n_rays, d_off, d_cnt, d_key, d_w, d_total);
+    HIP_TRY(c, hipGetLastError());
+    return ADANERF_OK;
+  }
+  const int nblk = (n_rays + kSelRaysPerBlock - 1) / kSelRaysPerBlock;
+  hipLaunchKernelGGL(select_kernel, dim3(nblk), dim3(256), 0, c->stream, d_oracle, n_rays, n_max, thr, d_cnt,
+                     reinterpret_cast<uint8_t*>(c->selbin.p), reinterpret_cast<float*>(c->selw.p),
+                     reinterpret_cast<int32_t*>(c->block_total.p));
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, c->stream, reinterpret_cast<const int32_t*>(c->block_total.p), nblk,
+                     reinterpret_cast<int32_t*>(c->block_offset.p), d_total);
+  hipLaunchKernelGGL(expand_kernel, dim3(nblk), dim3(256), 0, c->stream, reinterpret_cast<const int32_t*>(d_cnt),
+                     reinterpret_cast<const uint8_t*>(c->selbin.p), reinterpret_cast<const float*>(c->selw.p),
+                     reinterpret_cast<const int32_t*>(c->block_offset.p), n_rays, n_max, d_off, d_key, d_w);
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+template <typename K>
+int occupancy_grid(adanerf_ctx* c, K kernel, int threads, int* out) {
+  int per_cu = 0;
+  HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0));
+  if (per_cu < 1) per_cu = 1;
+  *out = per_cu * c->info.compute_units;
+  return ADANERF_OK;
+}
+
+constexpr int kShadeWaves = 8;
+
+int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, const int32_t* d_total, int max_samples, int prec,
+                     float* d_raw) {
+  if (max_samples <= 0) return ADANERF_OK;
+  int rc = ensure_net1(c, prec);
+  if (rc) return rc;
+  ShadeArgs a{};
+  a.sp = c->sp;
+  a.net = c->net1[prec].params;
+  a.rays = d_rays;
+  a.sample_key = d_key;
+  a.total = d_total;
+  a.max_samples = max_samples;
+  a.raw_out = d_raw;
+  if (c->fp1 != 10 || c->fd1 != 4) return fail(c, ADANERF_EUNSUPPORTED, "shading net posEncArgs must be 10-4");
+  if (prec == ADANERF_PREC_FP32) {
+    if (!c->shade_grid[2] && (rc = occupancy_grid(c, shade_mlp32_kernel<10, 4>, 256, &c->shade_grid[2]))) return rc;
+    const int tiles = (max_samples + 127) / 128;
+    hipLaunchKernelGGL((shade_mlp32_kernel<10, 4>), dim3(std::min(tiles, c->shade_grid[2])), dim3(256), 0, c->stream, a);
+  } else {
+    const int tile = kShadeWaves * 32;
+    const int tiles = (max_samples + tile - 1) / tile;
+    if (prec == ADANERF_PREC_BF16) {
+      if (!c->shade_grid[0] && (rc = occupancy_grid(c, shade_mlp16_kernel<Bf16, 10, 4>, kShadeWaves * 64, &c->shade_grid[0]))) return rc;
+      hipLaunchKernelGGL((shade_mlp16_kernel<Bf16, 10, 4>), dim3(std::min(tiles, c->shade_grid[0])), dim3(kShadeWaves * 64), 0,
+                         c->stream, a);
+    } else {
+      if (!c->shade_grid[1] && (rc = occupancy_grid(c, shade_mlp16_kernel<Fp16, 10, 4>, kShadeWaves * 64, &c->shade_grid[1]))) return rc;
+      hipLaunchKernelGGL((shade_mlp16_kernel<Fp16, 10, 4>), dim3(std::min(tiles, c->shade_grid[1])), dim3(kShadeWaves * 64), 0,
+                         c->stream, a);
+    }
+  }
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+int launch_composite(adanerf_ctx* c, const float* d_raw, const float* d_w, const int32_t* d_off, const int32_t* d_cnt, int n_rays,
+                     float* d_rgb, void* d_rgba8) {
+  if (n_rays <= 0) return ADANERF_OK;
+  hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw), d_w,
+                     d_off, d_cnt, n_rays, c->mult_mode, d_rgb, reinterpret_cast<uchar4*>(d_rgba8));
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+
+extern "C" {
+
+const char* adanerf_last_error(const adanerf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ctx** out) {
+  if (!out) return fail(nullptr, ADANERF_EINVAL, "out == NULL");
+  *out = nullptr;
+  if (!model_dir || !opt) return fail(nullptr, ADANERF_EINVAL, "model_dir/opt == NULL");
+  adanerf_ctx* c = new adanerf_ctx();
+  auto bail = [&](int code, const std::string& msg) {
+    g_create_error = msg;
+    adanerf_destroy(c);
+    return code;
+  };
+  std::string err;
+  ModelSetup ms;
+  int rc = setup_model(model_dir, opt, &ms, &err);
+  if (rc) return bail(rc, err);
+  c->opt = *opt;
+  c->cfg = ms.cfg;
+  c->info = ms.info;
+  c->rg = ms.rg;
+  c->sp = ms.sp;
+  c->mult_mode = ms.mult_mode;
+  c->fp0 = ms.fp0;
+  c->fd0 = ms.fd0;
+  c->fp1 = ms.fp1;
+  c->fd1 = ms.fd1;
+
+  // ---- weights: parse + pack on the host before touching the device ----
+  TensorMap n0;
+  if (!read_onnx_initializers(join_path(model_dir, "model0.onnx"), &n0, &err)) return bail(ADANERF_EIO, err);
+  if (!read_onnx_initializers(join_path(model_dir, "model1.onnx"), &c->net1_host, &err)) return bail(ADANERF_EIO, err);
+  NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1};
+  PackedNet p0, p1;
+  if (!pack_sampling_net(n0, sh, Elem::F32, &p0, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
+  if (!pack_shading_net(c->net1_host, sh, elem_of(opt->precision), &p1, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
+
+  // ---- device ----
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return bail(ADANERF_EDEVICE, "no HIP device available: libadanerf_hip has no CPU fallback");
+  if (hipSetDevice(opt->device_id) != hipSuccess) return bail(ADANERF_EDEVICE, "hipSetDevice failed");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, opt->device_id) != hipSuccess) return bail(ADANERF_EDEVICE, "hipGetDeviceProperties failed");
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return bail(ADANERF_EDEVICE, std::string("device is ") + prop.gcnArchName + "; this library is built for gfx950 (MI355X) only");
+  c->info.compute_units = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(ADANERF_EDEVICE, "hipStreamCreate failed");
+
+  rc = dev_alloc(c, &c->ztab, kBins * sizeof(float));
+  if (rc) return bail(rc, c->err);
+  if (hipMemcpy(c->ztab.p, ms.ztab.data(), kBins * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+    return bail(ADANERF_EDEVICE, "ztab upload failed");
+  c->sp.ztab = reinterpret_cast<const float*>(c->ztab.p);
+  if ((rc = upload_net(c, p0, &c->net0))) return bail(rc, c->err);
+  if ((rc = upload_net(c, p1, &c->net1[opt->precision]))) return bail(rc, c->err);
+  if ((rc = ensure_batch_buffers(c, c->info.batch_rays, c->info.num_samples))) return bail(rc, c->err);
+  *out = c;
+  return ADANERF_OK;
+}
+
+int adanerf_host_parse_model(const char* model_dir, const adanerf_options* opt, adanerf_info* info) {
+  if (!model_dir || !opt || !info) return fail(nullptr, ADANERF_EINVAL, "NULL argument");
+  ModelSetup ms;
+  std::string err;
+  int rc = setup_model(model_dir, opt, &ms, &err);
+  if (rc) return fail(nullptr, rc, err);
+  *info = ms.info;
+  return ADANERF_OK;
+}
+
+int adanerf_host_depth_table(const char* model_dir, const adanerf_options* opt, float* ztab128) {
+  if (!model_dir || !opt || !ztab128) return fail(nullptr, ADANERF_EINVAL, "NULL argument");
+  ModelSetup ms;
+  std::string err;
+  int rc = setup_model(model_dir, opt, &ms, &err);
+  if (rc) return fail(nullptr, rc, err);
+  std::memcpy(ztab128, ms.ztab.data(), kBins * sizeof(float));
+  return ADANERF_OK;
+}
+
+int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precision, void* weights_out, size_t* weights_bytes,
+                              float* bias_out, size_t* bias_floats, int32_t* layer_out, int32_t* n_layers) {
+  if (!model_dir || !weights_bytes || !bias_floats || !n_layers) return fail(nullptr, ADANERF_EINVAL, "NULL argument");
+  if (net < 0 || net > 1 || precision < 0 || precision > 2) return fail(nullptr, ADANERF_EINVAL, "net/precision out of range");
+  Config cfg;
+  std::string err;
+  if (!cfg.load(model_dir, &err)) return fail(nullptr, ADANERF_EIO, err);
+  if (cfg.posEncArgs.size() != 2) return fail(nullptr, ADANERF_EIO, "posEncArgs missing");
+  NetShape sh{static_cast<int>(cfg.posEncArgs[0][0]), static_cast<int>(cfg.posEncArgs[0][1]), static_cast<int>(cfg.posEncArgs[1][0]),
+              static_cast<int>(cfg.posEncArgs[1][1])};
+  TensorMap tm;
+  if (!read_onnx_initializers(join_path(model_dir, net == 0 ? "model0.onnx" : "model1.onnx"), &tm, &err)) return fail(nullptr, ADANERF_EIO, err);
+  PackedNet pn;
+  bool ok = net == 0 ? pack_sampling_net(tm, sh, elem_of(precision), &pn, &err) : pack_shading_net(tm, sh, elem_of(precision), &pn, &err);
+  if (!ok) return fail(nullptr, ADANERF_EIO, err);
+  if (weights_out) {
+    if (*weights_bytes < pn.weights.size()) return fail(nullptr, ADANERF_EINVAL, "weights_out too small");
+    std::memcpy(weights_out, pn.weights.data(), pn.weights.size());
+  }
+  if (bias_out) {
+    if (*bias_floats < pn.bias.size()) return fail(nullptr, ADANERF_EINVAL, "bias_out too small");
+    std::memcpy(bias_out, pn.bias.data(), pn.bias.size() * sizeof(float));
+  }
+  if (layer_out) {
+    if (*n_layers < static_cast<int32_t>(pn.w_off.size())) return fail(nullptr, ADANERF_EINVAL, "layer_out too small");
+    for (size_t i = 0; i < pn.w_off.size(); ++i) {
+      layer_out[4 * i + 0] = static_cast<int32_t>(pn.w_off[i]);
+      layer_out[4 * i + 1] = static_cast<int32_t>(pn.b_off[i]);
+      layer_out[4 * i + 2] = pn.slots[i];
+      layer_out[4 * i + 3] = pn.mtiles[i];
+    }
+  }
+  *weights_bytes = pn.weights.size();
+  *bias_floats = pn.bias.size();
+  *n_layers = static_cast<int32_t>(pn.w_off.size());
+  return ADANERF_OK;
+}
+
+int adanerf_destroy(adanerf_ctx* c) {
+  if (!c) return ADANERF_OK;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+  DevBuf* bufs[] = {&c->net0.w, &c->net0.b, &c->net1[0].w, &c->net1[0].b, &c->net1[1].w, &c->net1[1].b, &c->net1[2].w, &c->net1[2].b,
+                    &c->ztab, &c->rays, &c->oracle, &c->ray_offsets, &c->ray_counts, &c->selbin, &c->selw, &c->block_total,
+                    &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw};
+  for (DevBuf* b : bufs) dev_free(b);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return ADANERF_OK;
+}
+
+int adanerf_get_info(const adanerf_ctx* c, adanerf_info* info) {
+  if (!c || !info) return ADANERF_EINVAL;
+  *info = c->info;
+  return ADANERF_OK;
+}
+
+int adanerf_set_camera(adanerf_ctx* c, const float pos[3], const float rot[9]) {
+  if (!c) return ADANERF_EINVAL;
+  if (!pos || !rot) return fail(c, ADANERF_EINVAL, "pos/rot == NULL");
+  std::memcpy(c->rg.pos, pos, 3 * sizeof(float));
+  std::memcpy(c->rg.rot, rot, 9 * sizeof(float));
+  return ADANERF_OK;
+}
+
+int adanerf_sync(adanerf_ctx* c) {
+  if (!c) return ADANERF_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ADANERF_OK;
+}
+
+int adanerf_ray_features(adanerf_ctx* c, int32_t first_ray, int32_t n_rays, float* d_feat, float* d_rays) {
+  if (!c) return ADANERF_EINVAL;
+  if (first_ray < 0 || n_rays < 0 || first_ray + n_rays > c->info.rays_local) return fail(c, ADANERF_EINVAL, "ray range outside this context's rays");
+  if (n_rays == 0) return ADANERF_OK;
+  dim3 grid((n_rays + 255) / 256), block(256);
+  if (c->fp0 == 10) hipLaunchKernelGGL((ray_features_kernel<10, 4>), grid, block, 0, c->stream, c->rg, first_ray, n_rays, d_feat, d_rays);
+  else hipLaunchKernelGGL((ray_features_kernel<2, 2>), grid, block, 0, c->stream, c->rg, first_ray, n_rays, d_feat, d_rays);
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+int adanerf_sample_mlp(adanerf_ctx* c, int32_t first_ray, int32_t n_rays, float* d_oracle, float* d_rays) {
+  if (!c) return ADANERF_EINVAL;
+  if (first_ray < 0 || n_rays < 0 || first_ray + n_rays > c->info.rays_local) return fail(c, ADANERF_EINVAL, "ray range outside this context's rays");
+  return launch_sample_mlp(c, first_ray, n_rays, d_oracle, d_rays);
+}
+
+int adanerf_compact(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, int32_t n_max, float thr, int32_t* d_off, int32_t* d_cnt,
+                    uint32_t* d_key, float* d_w, int32_t* d_total) {
+  if (!c) return ADANERF_EINVAL;
+  if (!d_oracle || !d_off || !d_cnt || !d_key || !d_w || !d_total) return fail(c, ADANERF_EINVAL, "NULL buffer");
+  if (n_rays < 0 || n_max < 1 || n_max > kBins || thr < 0.f) return fail(c, ADANERF_EINVAL, "n_rays/n_max/thr out of range");
+  if (thr == 0.f && n_max != kBins) return fail(c, ADANERF_EINVAL, "dense mode (thr == 0) requires n_max == 128");
+  if (static_cast<int64_t>(n_rays) >= (1ll << 25)) return fail(c, ADANERF_EINVAL, "n_rays must be < 2^25 per batch");
+  int rc = ensure_batch_buffers(c, n_rays, n_max);
+  if (rc) return rc;
+  return launch_compact(c, d_oracle, n_rays, n_max, thr, d_off, d_cnt, d_key, d_w, d_total);
+}
+
+int adanerf_shade_features(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, int32_t n_samples, float* d_feat) {
+  if (!c) return ADANERF_EINVAL;
+  if (!d_rays || !d_key || !d_feat || n_samples < 0) return fail(c, ADANERF_EINVAL, "bad argument");
+  if (n_samples == 0) return ADANERF_OK;
+  ShadeArgs a{};
+  a.sp = c->sp;
+  a.rays = d_rays;
+  a.sample_key = d_key;
+  a.max_samples = n_samples;
+  hipLaunchKernelGGL((shade_features_kernel<10, 4>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, a, d_feat);
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+int adanerf_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, const int32_t* d_total, int32_t max_samples,
+                      int32_t precision, float* d_raw) {
+  if (!c) return ADANERF_EINVAL;
+  if (!d_rays || !d_key || !d_raw || max_samples < 0) return fail(c, ADANERF_EINVAL, "bad argument");
+  return launch_shade_mlp(c, d_rays, d_key, d_total, max_samples, precision < 0 ? c->info.precision : precision, d_raw);
+}
+
+int adanerf_composite(adanerf_ctx* c, const float* d_raw, const float* d_w, const int32_t* d_off, const int32_t* d_cnt, int32_t n_rays,
+                      float* d_rgb, void* d_rgba8) {
+  if (!c) return ADANERF_EINVAL;
+  if (!d_raw || !d_w || !d_off || !d_cnt || n_rays < 0) return fail(c, ADANERF_EINVAL, "bad argument");
+  return launch_composite(c, d_raw, d_w, d_off, d_cnt, n_rays, d_rgb, d_rgba8);
+}
+
+int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* stats) {
+  if (!c) return ADANERF_EINVAL;
+  const int R = c->info.rays_local, B = c->info.batch_rays, N = c->info.num_samples;
+  const float thr = c->info.threshold;
+  const int n_batches = R > 0 ? (R + B - 1) / B : 0;
+  int rc = ensure_batch_buffers(c, std::min(B, std::max(R, 1)), N);
+  if (rc) return rc;
+  const size_t n_ev = static_cast<size_t>(n_batches) * 5;
+  if (stats) {
+    while (c->events.size() < n_ev) {
+      hipEvent_t e;
+      HIP_TRY(c, hipEventCreate(&e));
+      c->events.push_back(e);
+    }
+  }
+  float* rays = reinterpret_cast<float*>(c->rays.p);
+  float* oracle = reinterpret_cast<float*>(c->oracle.p);
+  int32_t* off = reinterpret_cast<int32_t*>(c->ray_offsets.p);
+  int32_t* cnt = reinterpret_cast<int32_t*>(c->ray_counts.p);
+  uint32_t* key = reinterpret_cast<uint32_t*>(c->sample_key.p);
+  float* sw = reinterpret_cast<float*>(c->sample_w.p);
+  float* raw = reinterpret_cast<float*>(c->raw.p);
+  int32_t* total = reinterpret_cast<int32_t*>(c->total.p);
+  std::vector<int32_t> totals(n_batches, 0);
+  for (int b = 0; b < n_batches; ++b) {
+    const int first = b * B, n = std::min(B, R - first);
+    hipEvent_t* ev = stats ? &c->events[static_cast<size_t>(b) * 5] : nullptr;
+    if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+    if ((rc = launch_sample_mlp(c, first, n, oracle, rays))) return rc;
+    if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+    if ((rc = launch_compact(c, oracle, n, N, thr, off, cnt, key, sw, total))) return rc;
+    if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+    const int64_t max_s = static_cast<int64_t>(n) * N;
+    if (max_s > 0x7fffffffll) return fail(c, ADANERF_EINVAL, "batch_rays * num_samples exceeds 2^31; use a smaller batch");
+    if ((rc = launch_shade_mlp(c, rays, key, total, static_cast<int>(max_s), c->info.precision, raw))) return rc;
+    if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
+    if ((rc = launch_composite(c, raw, sw, off, cnt, n, d_rgb ? d_rgb + static_cast<size_t>(first) * 3 : nullptr,
+                               d_rgba8 ? static_cast<char*>(d_rgba8) + static_cast<size_t>(first) * 4 : nullptr)))
+      return rc;
+    if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
+    if (stats) HIP_TRY(c, hipMemcpyAsync(&totals[b], total, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  }
+  if (stats) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memset(stats, 0, sizeof(*stats));
+    stats->rays = R;
+    stats->batches = n_batches;
+    for (int b = 0; b < n_batches; ++b) {
+      hipEvent_t* ev = &c->events[static_cast<size_t>(b) * 5];
+      float t;
+      HIP_TRY(c, hipEventElapsedTime(&t, ev[0], ev[1]));
+      stats->ms_sample_mlp += t;
+      HIP_TRY(c, hipEventElapsedTime(&t, ev[1], ev[2]));
+      stats->ms_compact += t;
+      HIP_TRY(c, hipEventElapsedTime(&t, ev[2], ev[3]));
+      stats->ms_shade_mlp += t;
+      HIP_TRY(c, hipEventElapsedTime(&t, ev[3], ev[4]));
+      stats->ms_composite += t;
+      stats->total_samples += totals[b];
+    }
+    if (n_batches > 0) HIP_TRY(c, hipEventElapsedTime(&stats->ms_total, c->events[0], c->events[static_cast<size_t>(n_batches - 1) * 5 + 4]));
+    stats->shade_launches = n_batches;
+    stats->sample_launches = n_batches;
+  }
+  return ADANERF_OK;
+}
+
+int adanerf_assemble_strips(adanerf_ctx* c, const void* d_gathered, void* d_image) {
+  if (!c) return ADANERF_EINVAL;
+  if (!d_gathered || !d_image) return fail(c, ADANERF_EINVAL, "NULL buffer");
+  const int n = c->info.width * c->info.height;
+  hipLaunchKernelGGL(assemble_strips_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const uchar4*>(d_gathered),
+                     reinterpret_cast<uchar4*>(d_image), c->info.width, c->info.height, c->rg.strip_rows, c->rg.world, c->info.rays_local_max);
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+int adanerf_malloc(adanerf_ctx* c, size_t bytes, void** d_out) {
+  if (!c || !d_out) return ADANERF_EINVAL;
+  HIP_TRY(c, hipMalloc(d_out, bytes ? bytes : 1));
+  return ADANERF_OK;
+}
+int adanerf_free(adanerf_ctx* c, void* d_ptr) {
+  if (!c) return ADANERF_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipFree(d_ptr));
+  return ADANERF_OK;
+}
+int adanerf_memcpy_h2d(adanerf_ctx* c, void* d_dst, const void* src, size_t bytes) {
+  if (!c) return ADANERF_EINVAL;
+  HIP_TRY(c, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ADANERF_OK;
+}
+int adanerf_memcpy_d2h(adanerf_ctx* c, void* dst, const void* d_src, size_t bytes) {
+  if (!c) return ADANERF_EINVAL;
+  HIP_TRY(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ADANERF_OK;
+}
+
+int adanerf_get_buffer(adanerf_ctx* c, int32_t which, void** d_out, size_t* bytes_out) {
+  if (!c || !d_out) return ADANERF_EINVAL;
+  DevBuf* b = nullptr;
+  switch (which) {
+    case ADANERF_BUF_RAYS: b = &c->rays; break;
+    case ADANERF_BUF_ORACLE: b = &c->oracle; break;
+    case ADANERF_BUF_RAY_OFFSETS: b = &c->ray_offsets; break;
+    case ADANERF_BUF_RAY_COUNTS: b = &c->ray_counts; break;
+    case ADANERF_BUF_SAMPLE_KEY: b = &c->sample_key; break;
+    case ADANERF_BUF_SAMPLE_W: b = &c->sample_w; break;
+    case ADANERF_BUF_RAW: b = &c->raw; break;
+    case ADANERF_BUF_TOTAL: b = &c->total; break;
+    default: return fail(c, ADANERF_EINVAL, "unknown buffer id");
+  }
+  *d_out = b->p;
+  if (bytes_out) *bytes_out = b->bytes;
+  return ADANERF_OK;
+}
+
+}  // extern "C"

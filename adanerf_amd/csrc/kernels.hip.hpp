@@ -1,0 +1,854 @@
+// gfx950 (CDNA4, wave64) kernels of the AdaNeRF per-frame hot path.  Device code only; the C ABI
+// in adanerf_hip.hip launches these.  Stage map:
+//   A1+A2+A3  sample_mlp_kernel      ray gen -> sphere exit -> oracle PE -> 8-layer sampling MLP (fp32 MFMA)
+//   A4        select_kernel / scan_blocks_kernel / expand_kernel   top-N + threshold, deterministic compaction
+//   A5+A6     shade_mlp16_kernel / shade_mlp32_kernel   fused PE + 8x256 shading MLP (bf16/f16/f32 MFMA)
+//   A7        composite_kernel       sigmoid + alpha * oracle weight, front-to-back
+// plus explicit-feature debug kernels (ray_features_kernel, shade_features_kernel) that materialise
+// what the reference launchers wrote to memory, for parity tests only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "layout.hpp"
+
+namespace adanerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kMaxLayers = 12;
+
+struct NetParams {
+  const u32x4* w;            // packed A fragments (16 B each)
+  const float* bias;         // packed bias blocks
+  uint32_t w_off[kMaxLayers];
+  uint32_t b_off[kMaxLayers];
+};
+
+// Everything ray generation needs (A1 + A2).  Doubles mirror the float64 numpy ray table of
+// src/util/raygeneration.py:10-26.
+struct RayGenParams {
+  double start_x, x_pp, start_y, y_pp, focal;
+  int32_t w, h;
+  int32_t strip_rows, world, rank;     // round-robin strip sharding of image rows
+  int32_t use_ndc;
+  float rot[9];                        // row-major c2w
+  float pos[3];
+  float center[3];
+  float rad2;                          // ||view_cell_size/2||^2
+  float ndc_sw, ndc_sh;                // -1/(W/(2 focal)), -1/(H/(2 focal))
+};
+
+struct ShadeParams {
+  float center[3];
+  float inv_sqrt_max_depth_unused;
+  float sqrt_max_depth;
+  int32_t normalize;                   // 1: InverseSqrtDistCentered, 0: None
+  int32_t unit_dir;                    // 1: PE(dir/|dir|) (NDC), 0: PE(dir) as received
+  const float* ztab;                   // [128] world depth per bin
+};
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & 63; }
+
+// local ray index -> (col, row) under round-robin row-strip sharding
+__device__ __forceinline__ void ray_pixel(const RayGenParams& g, int i, int* col, int* row) {
+  const int per_strip = g.w * g.strip_rows;
+  const int sl = i / per_strip;
+  const int within = i - sl * per_strip;
+  const int r = within / g.w;
+  *col = within - r * g.w;
+  *row = (sl * g.world + g.rank) * g.strip_rows + r;
+}
+
+// A1: camera-space unit direction (float64 math, cast to float32), then A2: world dir + sphere exit.
+// Follows src/util/raygeneration.py:10-26 and src/features.py:769-791, 845-866.
+__device__ __forceinline__ void gen_ray(const RayGenParams& g, int col, int row, float nds[3], float p[3]) {
+  double vx = __dadd_rn(g.start_x, __dmul_rn(g.x_pp, static_cast<double>(col)));
+  double vy = __dadd_rn(g.start_y, __dmul_rn(g.y_pp, static_cast<double>(row)));
+  double vz = g.focal;
+  double n = sqrt(__dadd_rn(__dadd_rn(__dmul_rn(vx, vx), __dmul_rn(vy, vy)), __dmul_rn(vz, vz)));
+  float dx = static_cast<float>(vx / n);
+  float dy = static_cast<float>(-(vy / n));
+  float dz = static_cast<float>(-(vz / n));
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    nds[i] = __fadd_rn(__fadd_rn(__fmul_rn(g.rot[3 * i], dx), __fmul_rn(g.rot[3 * i + 1], dy)), __fmul_rn(g.rot[3 * i + 2], dz));
+  float q[3] = {g.pos[0] - g.center[0], g.pos[1] - g.center[1], g.pos[2] - g.center[2]};
+  float udot = __fadd_rn(__fadd_rn(__fmul_rn(q[0], nds[0]), __fmul_rn(q[1], nds[1])), __fmul_rn(q[2], nds[2]));
+  float qq = __fadd_rn(__fadd_rn(__fmul_rn(q[0], q[0]), __fmul_rn(q[1], q[1])), __fmul_rn(q[2], q[2]));
+  float delta = __fsub_rn(__fmul_rn(udot, udot), __fsub_rn(qq, g.rad2));
+  float dist = __fadd_rn(-udot, sqrtf(fmaxf(delta, 0.f)));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p[i] = __fadd_rn(g.pos[i], __fmul_rn(nds[i], dist));
+}
+
+__device__ __forceinline__ void unit3(const float v[3], float out[3]) {
+  float n = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(v[0], v[0]), __fmul_rn(v[1], v[1])), __fmul_rn(v[2], v[2])));
+  out[0] = v[0] / n;
+  out[1] = v[1] / n;
+  out[2] = v[2] / n;
+}
+
+// src/nerf_raymarch_common.py:71-88 (near = 1)
+__device__ __forceinline__ void ndc_ray(const RayGenParams& g, const float o[3], const float d[3], float on[3], float dn[3]) {
+  const float near = 1.0f;
+  float t = -(near + o[2]) / d[2];
+  float ox = __fadd_rn(o[0], __fmul_rn(t, d[0])), oy = __fadd_rn(o[1], __fmul_rn(t, d[1])), oz = __fadd_rn(o[2], __fmul_rn(t, d[2]));
+  on[0] = g.ndc_sw * ox / oz;
+  on[1] = g.ndc_sh * oy / oz;
+  on[2] = 1.0f + 2.0f * near / oz;
+  dn[0] = g.ndc_sw * (d[0] / d[2] - ox / oz);
+  dn[1] = g.ndc_sh * (d[1] / d[2] - oy / oz);
+  dn[2] = -2.0f * near / oz;
+}
+
+// PE slots of lane-half h (layout.hpp): slot q < 3F -> h ? cos : sin of 2^(q/3) * x[q%3];
+// then two identity slots.  ACCURATE: libm-grade sincosf (fp32 parity path);
+// !ACCURATE: one v_sin_f32 per slot (cos = sin shifted by a quarter revolution).
+template <int F, bool ACCURATE>
+__device__ __forceinline__ void pe_eval(const float x[3], int h, float* out) {
+#pragma unroll
+  for (int q = 0; q < 3 * F; ++q) {
+    const int b = q / 3, c = q - 3 * b;
+    const float a = x[c] * static_cast<float>(1 << b);
+    if (ACCURATE) {
+      float s, co;
+      sincosf(a, &s, &co);
+      out[q] = h ? co : s;
+    } else {
+      out[q] = __builtin_amdgcn_sinf(__builtin_fmaf(a, 0.15915494309189535f, h ? 0.25f : 0.0f));
+    }
+  }
+  out[3 * F] = h ? x[2] : x[0];
+  out[3 * F + 1] = h ? 0.f : x[1];
+#pragma unroll
+  for (int q = 3 * F + 2; q < pe_slots(F); ++q) out[q] = 0.f;
+}
+
+// A5: sample position + normalisation (src/features.py:458-467, src/nerf_raymarch_common.py:226-230)
+__device__ __forceinline__ void sample_position(const ShadeParams& sp, const float o[3], const float d[3], float z, float x[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) x[i] = __fadd_rn(o[i], __fmul_rn(d[i], z));
+  if (sp.normalize) {
+    float l[3] = {x[0] - sp.center[0], x[1] - sp.center[1], x[2] - sp.center[2]};
+    float n2 = __fadd_rn(__fadd_rn(__fmul_rn(l[0], l[0]), __fmul_rn(l[1], l[1])), __fmul_rn(l[2], l[2]));
+    float local = sqrtf(sqrtf(n2));
+    float den = __fmul_rn(sp.sqrt_max_depth, local);
+    x[0] = l[0] / den;
+    x[1] = l[1] / den;
+    x[2] = l[2] / den;
+  }
+}
+
+// wave64 max of a float (every lane gets the result): 4 in-row DPP butterflies, then 4 readlanes
+__device__ __forceinline__ float wave_max_f32(float v) {
+  int x = __builtin_bit_cast(int, v);
+#define ADN_DPP_MAX(ctrl)                                                                         \
+  {                                                                                                \
+    int y = __builtin_amdgcn_update_dpp(x, x, ctrl, 0xF, 0xF, false);                               \
+    x = __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y))); \
+  }
+  ADN_DPP_MAX(0xB1)    // quad_perm [1,0,3,2]
+  ADN_DPP_MAX(0x4E)    // quad_perm [2,3,0,1]
+  ADN_DPP_MAX(0x141)   // row_half_mirror
+  ADN_DPP_MAX(0x140)   // row_mirror
+#undef ADN_DPP_MAX
+  float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0));
+  float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+  float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32));
+  float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+__device__ __forceinline__ int mbcnt64(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0));
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 MFMA MLP engine: v_mfma_f32_32x32x2_f32, activations fp32 in registers
+// ------------------------------------------------------------------------------------------
+
+// One layer for one 32-sample column block.  QS input slots (per lane-half), MT output tiles.
+template <int QS, int MT, bool RELU>
+__device__ __forceinline__ void layer_f32(const u32x4* __restrict__ w, const float* __restrict__ bias, int lane,
+                                          const float* in, float* out) {
+  static_assert(QS % 4 == 0, "fp32 engine groups 4 k-steps per 16-byte fragment");
+  const int h = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    f32x16 acc;
+    const float4* bp = reinterpret_cast<const float4*>(bias + (m * 2 + h) * 16);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 b = bp[g];
+      acc[4 * g + 0] = b.x;
+      acc[4 * g + 1] = b.y;
+      acc[4 * g + 2] = b.z;
+      acc[4 * g + 3] = b.w;
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < QS / 4; ++s4) {
+      u32x4 a = w[(m * (QS / 4) + s4) * 64 + lane];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[0]), in[4 * s4 + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[1]), in[4 * s4 + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[2]), in[4 * s4 + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[3]), in[4 * s4 + 3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[16 * m + r] = RELU ? fmaxf(acc[r], 0.f) : acc[r];
+  }
+}
+
+struct SampleArgs {
+  RayGenParams g;
+  NetParams net;
+  int32_t first_ray, n_rays;
+  float* oracle_out;     // [n_rays,128] or null
+  float* rays_out;       // [n_rays,8] or null
+};
+
+// A1+A2+A3.  One wave = one block of 32 rays; 4 waves per workgroup (one per SIMD, up to 512 VGPRs).
+template <int FP, int FD>
+__global__ __launch_bounds__(256) void sample_mlp_kernel(SampleArgs a) {
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int blk = blockIdx.x * 4 + wave;
+  if (blk * 32 >= a.n_rays) return;
+  const int local = blk * 32 + j;
+  const bool valid = local < a.n_rays;
+  const int ray = a.first_ray + (valid ? local : a.n_rays - 1);
+
+  int col, row;
+  ray_pixel(a.g, ray, &col, &row);
+  float nds[3], p[3], u[3];
+  gen_ray(a.g, col, row, nds, p);
+  unit3(nds, u);
+
+  constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP;
+  float bufA[128], bufB[128];
+  pe_eval<FD, true>(u, h, bufA);          // [dir PE | pos PE]  (src/features.py:868-874)
+  pe_eval<FP, true>(p, h, bufA + QD);
+
+  const u32x4* w = a.net.w;
+  const float* b = a.net.bias;
+  layer_f32<Q0, 8, true>(w + a.net.w_off[0], b + a.net.b_off[0], lane, bufA, bufB);
+#pragma unroll 1
+  for (int l = 1; l <= 5; l += 2) {
+    layer_f32<128, 8, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, bufB, bufA);
+    layer_f32<128, 8, true>(w + a.net.w_off[l + 1], b + a.net.b_off[l + 1], lane, bufA, bufB);
+  }
+  layer_f32<128, 4, false>(w + a.net.w_off[7], b + a.net.b_off[7], lane, bufB, bufA);
+
+  if (valid) {
+    if (a.oracle_out) {
+      float* o = a.oracle_out + static_cast<size_t>(local) * kBins;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v = make_float4(bufA[16 * m + 4 * g], bufA[16 * m + 4 * g + 1], bufA[16 * m + 4 * g + 2], bufA[16 * m + 4 * g + 3]);
+          *reinterpret_cast<float4*>(o + 32 * m + 8 * g + 4 * h) = v;
+        }
+    }
+    if (a.rays_out) {
+      float ro[3] = {p[0], p[1], p[2]}, rd[3] = {nds[0], nds[1], nds[2]};
+      if (a.g.use_ndc) ndc_ray(a.g, p, nds, ro, rd);
+      float4* r = reinterpret_cast<float4*>(a.rays_out + static_cast<size_t>(local) * 8);
+      if (h == 0) r[0] = make_float4(ro[0], ro[1], ro[2], 0.f);
+      else r[1] = make_float4(rd[0], rd[1], rd[2], 0.f);
+    }
+  }
+}
+
+// Debug/parity: explicit oracle-net input features in the reference's column order.
+template <int FP, int FD>
+__global__ __launch_bounds__(256) void ray_features_kernel(RayGenParams g, int first_ray, int n_rays, float* feat, float* rays_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rays) return;
+  int col, row;
+  ray_pixel(g, first_ray + i, &col, &row);
+  float nds[3], p[3], u[3];
+  gen_ray(g, col, row, nds, p);
+  unit3(nds, u);
+  if (feat) {
+    constexpr int ND = 3 + 6 * FD, NP = 3 + 6 * FP;
+    float* f = feat + static_cast<size_t>(i) * (ND + NP);
+    for (int c = 0; c < 3; ++c) {
+      f[c] = u[c];
+      f[ND + c] = p[c];
+    }
+    for (int b = 0; b < FD; ++b)
+      for (int c = 0; c < 3; ++c) {
+        float s, co;
+        sincosf(u[c] * static_cast<float>(1 << b), &s, &co);
+        f[3 + 6 * b + c] = s;
+        f[3 + 6 * b + 3 + c] = co;
+      }
+    for (int b = 0; b < FP; ++b)
+      for (int c = 0; c < 3; ++c) {
+        float s, co;
+        sincosf(p[c] * static_cast<float>(1 << b), &s, &co);
+        f[ND + 3 + 6 * b + c] = s;
+        f[ND + 3 + 6 * b + 3 + c] = co;
+      }
+  }
+  if (rays_out) {
+    float ro[3] = {p[0], p[1], p[2]}, rd[3] = {nds[0], nds[1], nds[2]};
+    if (g.use_ndc) ndc_ray(g, p, nds, ro, rd);
+    float4* r = reinterpret_cast<float4*>(rays_out + static_cast<size_t>(i) * 8);
+    r[0] = make_float4(ro[0], ro[1], ro[2], 0.f);
+    r[1] = make_float4(rd[0], rd[1], rd[2], 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// A4: adaptive selection + deterministic compaction
+// ------------------------------------------------------------------------------------------
+
+constexpr int kSelRaysPerBlock = 256;   // 4 waves x 64 rays
+
+// Selection rule (src/nerf_raymarch_common.py:699-757 as a set rule):
+// keep the n_max largest values (ties: lower bin first) that are >= thr; if none is >= thr keep the
+// arg-max alone.  One wave per ray: lane holds bins (lane, lane + 64); the kept set lives in two
+// 64-bit ballot masks, so ascending-bin output order is a popcount.
+__device__ __forceinline__ void select_ray(float v0, float v1, int lane, int n_max, float thr, uint64_t* s0, uint64_t* s1) {
+  const uint64_t b0 = __ballot(v0 >= thr), b1 = __ballot(v1 >= thr);
+  const int c = __popcll(b0) + __popcll(b1);
+  uint64_t sel0, sel1;
+  if (c == 0) {
+    const float m = wave_max_f32(fmaxf(v0, v1));
+    const uint64_t e0 = __ballot(v0 == m), e1 = __ballot(v1 == m);
+    sel0 = e0 & (~e0 + 1);
+    sel1 = e0 ? 0 : (e1 & (~e1 + 1));
+    if ((sel0 | sel1) == 0) sel0 = 1;   // all-NaN row: keep bin 0 (undefined in the reference)
+  } else if (c <= n_max) {
+    sel0 = b0;
+    sel1 = b1;
+  } else {
+    sel0 = 0;
+    sel1 = 0;
+    uint64_t c0 = b0, c1 = b1;
+    const float ninf = -__builtin_inff();
+    for (int k = 0; k < n_max; ++k) {
+      const float x0 = ((c0 >> lane) & 1) ? v0 : ninf;
+      const float x1 = ((c1 >> lane) & 1) ? v1 : ninf;
+      const float m = wave_max_f32(fmaxf(x0, x1));
+      const uint64_t e0 = __ballot(x0 == m) & c0, e1 = __ballot(x1 == m) & c1;
+      if (e0) {
+        const uint64_t bit = e0 & (~e0 + 1);
+        sel0 |= bit;
+        c0 &= ~bit;
+      } else {
+        const uint64_t bit = e1 & (~e1 + 1);
+        sel1 |= bit;
+        c1 &= ~bit;
+      }
+    }
+  }
+  *s0 = sel0;
+  *s1 = sel1;
+}
+
+__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ oracle, int n_rays, int n_max, float thr,
+                                                     int32_t* __restrict__ counts, uint8_t* __restrict__ selbin,
+                                                     float* __restrict__ selw, int32_t* __restrict__ block_total) {
+  __shared__ int wave_tot[4];
+  const int lane = lane_id();
+  const int wave = static_cast<int>(threadIdx.x) >> 6;
+  const int base = blockIdx.x * kSelRaysPerBlock + wave * 64;
+  int total = 0;
+  for (int i = 0; i < 64; i += 4) {
+    float v0[4], v1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = base + i + u;
+      const bool ok = r < n_rays;
+      const float* row = oracle + static_cast<size_t>(ok ? r : 0) * kBins;
+      v0[u] = row[lane];
+      v1[u] = row[64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = base + i + u;
+      if (r >= n_rays) break;     // wave-uniform
+      uint64_t s0, s1;
+      select_ray(v0[u], v1[u], lane, n_max, thr, &s0, &s1);
+      const int c0 = __popcll(s0);
+      const int cnt = c0 + __popcll(s1);
+      const size_t o = static_cast<size_t>(r) * n_max;
+      if ((s0 >> lane) & 1) {
+        const int rank = mbcnt64(s0);
+        selbin[o + rank] = static_cast<uint8_t>(lane);
+        selw[o + rank] = v0[u];
+      }
+      if ((s1 >> lane) & 1) {
+        const int rank = c0 + mbcnt64(s1);
+        selbin[o + rank] = static_cast<uint8_t>(64 + lane);
+        selw[o + rank] = v1[u];
+      }
+      if (lane == 0) counts[r] = cnt;
+      total += cnt;
+    }
+  }
+  if (lane == 0) wave_tot[wave] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) block_total[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+// exclusive scan of the per-block totals by one workgroup; writes S to *total
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(const int32_t* __restrict__ block_total, int n_blocks,
+                                                           int32_t* __restrict__ block_offset, int32_t* __restrict__ total) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (n_blocks + 1023) / 1024;
+  const int lo = t * per;
+  int s = 0;
+  for (int i = 0; i < per; ++i) {
+    const int k = lo + i;
+    if (k < n_blocks) s += block_total[k];
+  }
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;   // exclusive prefix of this thread's chunk
+  for (int i = 0; i < per; ++i) {
+    const int k = lo + i;
+    if (k < n_blocks) {
+      block_offset[k] = run;
+      run += block_total[k];
+    }
+  }
+  if (t == 1023) *total = part[1023];
+}
+
+// ray offsets + compacted (key, weight) arrays, ray-major / bins ascending
+__global__ __launch_bounds__(256) void expand_kernel(const int32_t* __restrict__ counts, const uint8_t* __restrict__ selbin,
+                                                     const float* __restrict__ selw, const int32_t* __restrict__ block_offset,
+                                                     int n_rays, int n_max, int32_t* __restrict__ ray_offsets,
+                                                     uint32_t* __restrict__ sample_key, float* __restrict__ sample_w) {
+  __shared__ int sc[256];
+  const int t = threadIdx.x;
+  const int r = blockIdx.x * kSelRaysPerBlock + t;
+  const int c = (r < n_rays) ? counts[r] : 0;
+  sc[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    int v = (t >= off) ? sc[t - off] : 0;
+    __syncthreads();
+    sc[t] += v;
+    __syncthreads();
+  }
+  if (r >= n_rays) return;
+  const int o = block_offset[blockIdx.x] + sc[t] - c;
+  ray_offsets[r] = o;
+  const size_t src = static_cast<size_t>(r) * n_max;
+  for (int k = 0; k < c; ++k) {
+    sample_key[o + k] = (static_cast<uint32_t>(r) << 7) | selbin[src + k];
+    sample_w[o + k] = selw[src + k];
+  }
+}
+
+// thr == 0: every bin of every ray (src/nerf_raymarch_common.py:708-720); keys are implicit
+__global__ __launch_bounds__(256) void dense_expand_kernel(const float* __restrict__ oracle, int n_rays, int32_t* __restrict__ ray_offsets,
+                                                           int32_t* __restrict__ counts, uint32_t* __restrict__ sample_key,
+                                                           float* __restrict__ sample_w, int32_t* __restrict__ total) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t n = static_cast<size_t>(n_rays) * kBins;
+  if (i == 0) *total = static_cast<int32_t>(n);
+  if (i >= n) return;
+  sample_key[i] = static_cast<uint32_t>(i);
+  sample_w[i] = oracle[i];
+  if ((i & (kBins - 1)) == 0) {
+    const int r = static_cast<int>(i >> 7);
+    ray_offsets[r] = static_cast<int32_t>(i);
+    counts[r] = kBins;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// A5 + A6: fused PE + shading MLP
+// ------------------------------------------------------------------------------------------
+
+struct ShadeArgs {
+  ShadeParams sp;
+  NetParams net;
+  const float* rays;          // [*,8]
+  const uint32_t* sample_key; // [S]
+  const int32_t* total;       // device S (may be null -> max_samples)
+  int32_t max_samples;
+  float* raw_out;             // [S,4]
+};
+
+struct Bf16 {
+  typedef bf16x8 vec8;
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  }
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+struct Fp16 {
+  typedef f16x8 vec8;
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+  }
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// ---- weight streaming through LDS -------------------------------------------------------------
+// The packed 16-bit shading net is one linear stream of 1 KiB A fragments in consumption order
+// (layer, tile m, k-step s).  All waves of a workgroup consume it in lockstep, so it is staged ONCE
+// per workgroup: 8 KiB chunks (8 fragments; each of the 8 waves DMA-copies one fragment with
+// global_load_lds_dwordx4, LDS image lane-linear = fragment order, so ds_read_b128 is conflict
+// free) into a 4-slot ring.  One s_barrier per chunk; counted vmcnt keeps 2-3 chunks in flight
+// across the barrier (never vmcnt(0) in the loop).  Each wave keeps the current chunk's 8
+// fragments in registers and re-fills fragment i from the NEXT chunk right after the MFMA that
+// consumed it, so LDS latency hides behind the other 7 MFMAs.
+constexpr int kChunkFrags = 8;
+constexpr int kChunkBytes = kChunkFrags * 1024;
+constexpr int kRingSlots = 4;
+constexpr int kRingBytes = kRingSlots * kChunkBytes;
+constexpr int kShadeFrags16 = 32 + 4 * 128 + 160 + 2 * 128 + 144 + 72 + 8;   // 1184 per pass (FP=10, FD=4)
+constexpr int kShadeBiasFloats = 8 * 256 + 288 + 128 + 32;                     // 2496
+static_assert(kShadeFrags16 % (kChunkFrags * kRingSlots) == 0, "ring slot pattern must repeat per pass");
+
+struct WStream {
+  const char* gbase;     // stream start (global)
+  uint32_t gbytes;       // stream length in bytes (multiple of kChunkBytes)
+  uint32_t goff;         // byte offset of the next chunk to issue
+  uint32_t lane_off;     // wave * 1024 + lane * 16
+  char* lds;             // ring base (LDS)
+  int wave;
+  u32x4 R[kChunkFrags];  // current chunk's fragments
+};
+
+__device__ __forceinline__ void ws_issue(WStream& st, int slot) {
+  const char* src = st.gbase + st.goff + st.lane_off;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)(st.lds + slot * kChunkBytes + st.wave * 1024), 16, 0, 0);
+  st.goff += kChunkBytes;
+  if (st.goff >= st.gbytes) st.goff = 0;
+}
+
+__device__ __forceinline__ u32x4 ws_read(const WStream& st, int slot, int frag) {
+  return *reinterpret_cast<const u32x4*>(st.lds + slot * kChunkBytes + frag * 1024 + (st.lane_off & 1023));
+}
+
+// chunk boundary k: own piece of chunk k+1 has landed (<= 1 younger DMA outstanding); barrier =>
+// chunk k+1 complete in LDS for every wave and every wave has consumed chunk k-1 (its MFMAs were
+// issued before the barrier, so its ds_reads returned) => refill the slot of chunk k-1 with chunk k+3.
+__device__ __forceinline__ void ws_boundary(WStream& st, int slot_prev) {
+  asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+  ws_issue(st, slot_prev);
+}
+
+__device__ __forceinline__ void ws_prologue(WStream& st) {
+#pragma unroll
+  for (int k = 0; k < kRingSlots - 1; ++k) ws_issue(st, k);
+  asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < kChunkFrags; ++i) st.R[i] = ws_read(st, 0, i);
+}
+
+// ReLU on the raw bits: max(int(x), 0) is +0.0 for every negative float and the identity for positive
+// ones -- one v_max_i32, no canonicalising v_max_f32 pair.
+__device__ __forceinline__ float relu_bits(float x) {
+  int i = __builtin_bit_cast(int, x);
+  i = i > 0 ? i : 0;
+  return __builtin_bit_cast(float, i);
+}
+
+template <class ET, int F>
+__device__ __forceinline__ void pe_pack(const float x[3], int h, uint32_t* out) {
+  float t[pe_slots(F)];
+  pe_eval<F, false>(x, h, t);
+#pragma unroll
+  for (int q = 0; q < pe_slots(F) / 2; ++q) out[q] = ET::pack(t[2 * q], t[2 * q + 1]);
+}
+
+// One 16-bit layer for one 32-sample column block.  Input = two register segments (S1 then S2
+// k-steps of 8 slots = 4 packed dwords each); output tile m lands in out[8m .. 8m+7] (packed pairs).
+// FPOS = position of the layer's first fragment in the stream modulo 32 (4 chunks).
+// KEEP_F32_TILE >= 0: that tile's raw accumulator is returned in *keep instead (alpha / rgb rows).
+template <class ET, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
+__device__ __forceinline__ void layer_16(WStream& st, const float* __restrict__ bias, int lane, const uint32_t* in1, const uint32_t* in2,
+                                         uint32_t* out, f32x16* keep = nullptr) {
+  constexpr int KS = S1 + S2;
+  const bool hi = lane >= 32;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    // bias block [m][h][16]: wave-uniform addresses -> scalar loads (lgkmcnt, never vmcnt: an
+    // ordinary vector load here would make hipcc drain the LDS-DMA queue with vmcnt(0))
+    // The constant address space lets the backend pick s_load for these wave-uniform reads.
+    f32x16 acc;
+    const __attribute__((address_space(4))) float* cb = (const __attribute__((address_space(4))) float*)(bias + m * 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float b0 = cb[r], b1 = cb[16 + r];
+      acc[r] = hi ? b1 : b0;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int p = FPOS + m * KS + s;            // compile-time after unrolling
+      const int chunk = p / kChunkFrags, f = p % kChunkFrags;
+      if (f == 0) ws_boundary(st, (chunk + kRingSlots - 1) % kRingSlots);
+      const uint32_t* src = (s < S1) ? (in1 + 4 * s) : (in2 + 4 * (s - S1));
+      u32x4 b = {src[0], src[1], src[2], src[3]};
+      acc = ET::mfma(st.R[f], b, acc);
+      st.R[f] = ws_read(st, (chunk + 1) % kRingSlots, f);
+    }
+    if (KEEP_F32_TILE == m) {
+      *keep = acc;
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v0 = acc[4 * g + 0], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
+        if (RELU) {
+          v0 = relu_bits(v0);
+          v1 = relu_bits(v1);
+          v2 = relu_bits(v2);
+          v3 = relu_bits(v3);
+        }
+        out[8 * m + 2 * g + 0] = ET::pack(v0, v1);
+        out[8 * m + 2 * g + 1] = ET::pack(v2, v3);
+      }
+    }
+  }
+}
+
+// Loads the sample's ray record and evaluates position (+ optional unit direction).
+__device__ __forceinline__ void load_sample(const ShadeArgs& a, int s, int total, float x[3], float dpe[3]) {
+  const uint32_t key = (s < total) ? a.sample_key[s] : a.sample_key[total > 0 ? total - 1 : 0];
+  const uint32_t ray = key >> 7;
+  const int bin = static_cast<int>(key & 127u);
+  const float4* rr = reinterpret_cast<const float4*>(a.rays + static_cast<size_t>(ray) * 8);
+  const float4 o4 = rr[0], d4 = rr[1];
+  const float o[3] = {o4.x, o4.y, o4.z}, d[3] = {d4.x, d4.y, d4.z};
+  sample_position(a.sp, o, d, a.sp.ztab[bin], x);
+  if (a.sp.unit_dir) unit3(d, dpe);
+  else {
+    dpe[0] = d[0];
+    dpe[1] = d[1];
+    dpe[2] = d[2];
+  }
+}
+
+// A5+A6, 16-bit MFMA path.  Workgroup = 8 waves (2 per SIMD) = 256 samples per tile; persistent
+// over tiles; the weight stream is cyclic so DMA prefetch runs across tile boundaries.
+template <class ET, int FP, int FD>
+__global__ __launch_bounds__(512) void shade_mlp16_kernel(ShadeArgs a) {
+  static_assert(FP == 10 && FD == 4, "fragment positions below assume the 10-4 shading encoding");
+  constexpr int QP = pe_slots(FP), QD = pe_slots(FD);
+  constexpr int WAVES = 8, TILE = WAVES * 32;
+  __shared__ __attribute__((aligned(16))) char lds[kRingBytes];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  int total = a.total ? *a.total : a.max_samples;
+  if (total > a.max_samples) total = a.max_samples;
+  const int ntiles = (total + TILE - 1) / TILE;
+  if (static_cast<int>(blockIdx.x) >= ntiles) return;    // workgroup-uniform
+
+  WStream st;
+  st.gbase = reinterpret_cast<const char*>(a.net.w);
+  st.gbytes = kShadeFrags16 * 1024;
+  st.goff = 0;
+  st.lane_off = wave * 1024 + lane * 16;
+  st.lds = lds;
+  st.wave = wave;
+  ws_prologue(st);
+
+  const float* __restrict__ bias = a.net.bias;
+  const uint32_t* bo = a.net.b_off;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int s = tile * TILE + wave * 32 + j;
+    float x[3], dpe[3];
+    load_sample(a, s, total, x, dpe);
+    uint32_t hA[64], hB[64];
+    {
+      uint32_t pts[QP / 2];
+      pe_pack<ET, FP>(x, h, pts);
+      layer_16<ET, QP / 8, 0, 8, true, 0>(st, bias + bo[0], lane, pts, pts, hA);
+    }
+#pragma unroll 1
+    for (int l = 1; l <= 3; l += 2) {
+      layer_16<ET, 16, 0, 8, true, 0>(st, bias + bo[l], lane, hA, hA, hB);
+      layer_16<ET, 16, 0, 8, true, 0>(st, bias + bo[l + 1], lane, hB, hB, hA);
+    }
+    {
+      // the skip connection re-evaluates the 32 position slots instead of holding 16 VGPRs across
+      // layers 1-4 (30 v_sin per lane vs ~600 MFMA issue slots)
+      uint32_t pts[QP / 2];
+      pe_pack<ET, FP>(x, h, pts);
+      layer_16<ET, QP / 8, 16, 8, true, 0>(st, bias + bo[5], lane, pts, hA, hB);   // cat([pts, h])
+    }
+    layer_16<ET, 16, 0, 8, true, 0>(st, bias + bo[6], lane, hB, hB, hA);
+    layer_16<ET, 16, 0, 8, true, 0>(st, bias + bo[7], lane, hA, hA, hB);
+    f32x16 alpha_tile;
+    layer_16<ET, 16, 0, 9, false, 0, 8>(st, bias + bo[8], lane, hB, hB, hA, &alpha_tile);      // feature (+alpha row)
+    const float alpha = alpha_tile[0];
+    {
+      uint32_t dirs[QD / 2];
+      pe_pack<ET, FD>(dpe, h, dirs);
+      layer_16<ET, 16, QD / 8, 4, true, 16>(st, bias + bo[9], lane, hA, dirs, hB);             // cat([feature, dir])
+    }
+    f32x16 rgb_tile;
+    layer_16<ET, 8, 0, 1, false, 24, 0>(st, bias + bo[10], lane, hB, hB, hA, &rgb_tile);
+    if (h == 0 && s < total)
+      *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(rgb_tile[0], rgb_tile[1], rgb_tile[2], alpha);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+// fp32 parity mode of the shading net: same structure on the fp32 MFMA engine, accurate sincos.
+template <int FP, int FD>
+__global__ __launch_bounds__(256) void shade_mlp32_kernel(ShadeArgs a) {
+  constexpr int QP = pe_slots(FP), QD = pe_slots(FD);
+  constexpr int TILE = 4 * 32;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  int total = a.total ? *a.total : a.max_samples;
+  if (total > a.max_samples) total = a.max_samples;
+  const u32x4* w = a.net.w;
+  const float* b = a.net.bias;
+
+  for (int tile = blockIdx.x; tile * TILE < total; tile += gridDim.x) {
+    const int s = tile * TILE + wave * 32 + j;
+    if (tile * TILE + wave * 32 >= total) continue;
+    float x[3], dpe[3];
+    load_sample(a, s, total, x, dpe);
+    // bufA/bufB: [pts slots QP | 128 activation slots]; layer 5 reads the concatenation in place
+    float bufA[QP + 128], bufB[QP + 128 + QD];
+    pe_eval<FP, true>(x, h, bufA);
+#pragma unroll
+    for (int q = 0; q < QP; ++q) bufB[q] = bufA[q];
+    float* hA = bufA + QP;
+    float* hB = bufB + QP;
+    layer_f32<QP, 8, true>(w + a.net.w_off[0], b + a.net.b_off[0], lane, bufA, hB);
+#pragma unroll 1
+    for (int l = 1; l <= 3; l += 2) {
+      layer_f32<128, 8, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, hB, hA);
+      layer_f32<128, 8, true>(w + a.net.w_off[l + 1], b + a.net.b_off[l + 1], lane, hA, hB);
+    }
+    // hB holds h4; bufB = [pts | h4]
+    layer_f32<QP + 128, 8, true>(w + a.net.w_off[5], b + a.net.b_off[5], lane, bufB, hA);
+    layer_f32<128, 8, true>(w + a.net.w_off[6], b + a.net.b_off[6], lane, hA, hB);
+    layer_f32<128, 8, true>(w + a.net.w_off[7], b + a.net.b_off[7], lane, hB, hA);
+    float feat[144 + QD];                 // 9 tiles (tile 8 = alpha row) then dir slots
+    layer_f32<128, 9, false>(w + a.net.w_off[8], b + a.net.b_off[8], lane, hA, feat);
+    const float alpha = feat[128];
+    pe_eval<FD, true>(dpe, h, feat + 128);   // overwrite tile 8 with the dir slots: [feature | dir]
+    float v[64];
+    layer_f32<128 + QD, 4, true>(w + a.net.w_off[9], b + a.net.b_off[9], lane, feat, v);
+    float rgb[16];
+    layer_f32<64, 1, false>(w + a.net.w_off[10], b + a.net.b_off[10], lane, v, rgb);
+    if (h == 0 && s < total)
+      *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(rgb[0], rgb[1], rgb[2], alpha);
+  }
+}
+
+// Debug/parity: explicit shading-net input features in the reference's column order.
+template <int FP, int FD>
+__global__ __launch_bounds__(256) void shade_features_kernel(ShadeArgs a, float* feat) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.max_samples) return;
+  float x[3], dpe[3];
+  load_sample(a, s, a.max_samples, x, dpe);
+  constexpr int NP = 3 + 6 * FP, ND = 3 + 6 * FD;
+  float* f = feat + static_cast<size_t>(s) * (NP + ND);
+  for (int c = 0; c < 3; ++c) {
+    f[c] = x[c];
+    f[NP + c] = dpe[c];
+  }
+  for (int b = 0; b < FP; ++b)
+    for (int c = 0; c < 3; ++c) {
+      float sn, co;
+      sincosf(x[c] * static_cast<float>(1 << b), &sn, &co);
+      f[3 + 6 * b + c] = sn;
+      f[3 + 6 * b + 3 + c] = co;
+    }
+  for (int b = 0; b < FD; ++b)
+    for (int c = 0; c < 3; ++c) {
+      float sn, co;
+      sincosf(dpe[c] * static_cast<float>(1 << b), &sn, &co);
+      f[NP + 3 + 6 * b + c] = sn;
+      f[NP + 3 + 6 * b + 3 + c] = co;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// A7: compositing (src/nerf_raymarch_common.py:91-144)
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict__ raw, const float* __restrict__ sample_w,
+                                                        const int32_t* __restrict__ ray_offsets, const int32_t* __restrict__ counts,
+                                                        int n_rays, int mult_mode, float* __restrict__ rgb_out, uchar4* __restrict__ rgba8_out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  const int o = ray_offsets[r], c = counts[r];
+  float cr = 0.f, cg = 0.f, cb = 0.f, T = 1.f;
+  for (int k = 0; k < c; ++k) {
+    const float4 v = raw[o + k];
+    const float wv = sample_w[o + k];
+    float al = sigmoidf(v.w);
+    if (mult_mode == 1) al = __fmul_rn(al, wv);
+    float wt = __fmul_rn(al, T);
+    if (mult_mode == 2) wt = __fmul_rn(wt, wv);
+    cr = __fadd_rn(cr, __fmul_rn(wt, sigmoidf(v.x)));
+    cg = __fadd_rn(cg, __fmul_rn(wt, sigmoidf(v.y)));
+    cb = __fadd_rn(cb, __fmul_rn(wt, sigmoidf(v.z)));
+    T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, al), 1e-10f));
+  }
+  if (rgb_out) {
+    rgb_out[3 * static_cast<size_t>(r) + 0] = cr;
+    rgb_out[3 * static_cast<size_t>(r) + 1] = cg;
+    rgb_out[3 * static_cast<size_t>(r) + 2] = cb;
+  }
+  if (rgba8_out) {
+    // viewer output contract: (uchar)(clamp(v,0,1)*255), A = 255 (adaptive_cuda_kernels.cu:846-851)
+    uchar4 px;
+    px.x = static_cast<unsigned char>(fminf(fmaxf(cr, 0.f), 1.f) * 255.0f);
+    px.y = static_cast<unsigned char>(fminf(fmaxf(cg, 0.f), 1.f) * 255.0f);
+    px.z = static_cast<unsigned char>(fminf(fmaxf(cb, 0.f), 1.f) * 255.0f);
+    px.w = 255;
+    rgba8_out[r] = px;
+  }
+}
+
+// multi-GPU: gathered [world][rays_local_max] uchar4 (rank-major) -> row-major image
+__global__ __launch_bounds__(256) void assemble_strips_kernel(const uchar4* __restrict__ gathered, uchar4* __restrict__ image, int w, int h,
+                                                              int strip_rows, int world, int rays_local_max) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const int row = i / w, col = i - row * w;
+  const int strip = row / strip_rows;
+  const int rank = strip % world, sl = strip / world;
+  const int local = (sl * strip_rows + (row - strip * strip_rows)) * w + col;
+  image[i] = gathered[static_cast<size_t>(rank) * rays_local_max + local];
+}
+
+}  // namespace adanerf

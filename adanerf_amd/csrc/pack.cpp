@@ -1,0 +1,242 @@
+#include "pack.hpp"
+
+#include <cmath>
+#include <cstring>
+
+#include "layout.hpp"
+
+namespace adanerf {
+
+uint16_t f32_to_bf16(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return static_cast<uint16_t>((u >> 16) | 0x40);  // NaN
+  u += 0x7FFFu + ((u >> 16) & 1u);   // round to nearest even
+  return static_cast<uint16_t>(u >> 16);
+}
+
+uint16_t f32_to_f16(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u;
+  uint32_t mant = x & 0x007FFFFFu;
+  int32_t exp = static_cast<int32_t>((x >> 23) & 0xFF);
+  if (exp == 0xFF) return static_cast<uint16_t>(sign | 0x7C00u | (mant ? 0x200u : 0));
+  int32_t e = exp - 127 + 15;
+  if (e >= 31) return static_cast<uint16_t>(sign | 0x7C00u);   // overflow -> inf
+  if (e <= 0) {
+    if (e < -10) return static_cast<uint16_t>(sign);
+    mant |= 0x00800000u;
+    uint32_t shift = static_cast<uint32_t>(14 - e);
+    uint32_t half = mant >> shift;
+    uint32_t rem = mant & ((1u << shift) - 1u);
+    uint32_t mid = 1u << (shift - 1);
+    if (rem > mid || (rem == mid && (half & 1u))) half++;
+    return static_cast<uint16_t>(sign | half);
+  }
+  uint32_t half = static_cast<uint32_t>(e << 10) | (mant >> 13);
+  uint32_t rem = mant & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) half++;   // may carry into the exponent: correct
+  return static_cast<uint16_t>(sign | half);
+}
+
+namespace {
+
+// dense "virtual" layer: rows padded to 32, arbitrary source columns
+struct VLayer {
+  int rows = 0, cols = 0;          // cols = number of source columns
+  std::vector<float> w;            // [rows][cols]
+  std::vector<float> b;            // [rows]
+  std::vector<int> col_h0, col_h1; // per slot: source column for lane-half 0 / 1 (-1 = zero)
+};
+
+const Tensor* find(const TensorMap& m, const std::string& k, std::string* err) {
+  auto it = m.find(k);
+  if (it == m.end()) {
+    if (err) *err = "missing initializer " + k;
+    return nullptr;
+  }
+  return &it->second;
+}
+
+bool set_rows(VLayer* L, int row0, const Tensor* W, const Tensor* B, int expect_cols, std::string* err,
+              const std::string& name) {
+  if (W->dims.size() != 2 || W->cols() != expect_cols || static_cast<int>(B->data.size()) != W->rows()) {
+    if (err) *err = "unexpected shape for " + name + " (expected [*, " + std::to_string(expect_cols) + "])";
+    return false;
+  }
+  for (int r = 0; r < W->rows(); ++r) {
+    std::memcpy(&L->w[static_cast<size_t>(row0 + r) * L->cols], &W->data[static_cast<size_t>(r) * expect_cols],
+                sizeof(float) * expect_cols);
+    L->b[row0 + r] = B->data[r];
+  }
+  return true;
+}
+
+void init_layer(VLayer* L, int rows_padded, int cols) {
+  L->rows = rows_padded;
+  L->cols = cols;
+  L->w.assign(static_cast<size_t>(rows_padded) * cols, 0.f);
+  L->b.assign(rows_padded, 0.f);
+}
+
+void add_pe_slots(VLayer* L, int F, int col_base) {
+  int n = pe_slots(F);
+  for (int q = 0; q < n; ++q) {
+    int c0 = pe_col(F, q, 0), c1 = pe_col(F, q, 1);
+    L->col_h0.push_back(c0 < 0 ? -1 : col_base + c0);
+    L->col_h1.push_back(c1 < 0 ? -1 : col_base + c1);
+  }
+}
+
+void add_act_slots(VLayer* L, int n_features, int col_base) {
+  int n = n_features / 2;   // slots per lane-half
+  for (int q = 0; q < n; ++q) {
+    L->col_h0.push_back(col_base + act_feature(q, 0));
+    L->col_h1.push_back(col_base + act_feature(q, 1));
+  }
+}
+
+void emit(const VLayer& L, Elem elem, PackedNet* out) {
+  const int G = (elem == Elem::F32) ? 4 : 8;          // slots per 16-byte fragment element group
+  const int QS = static_cast<int>(L.col_h0.size());
+  const int steps = QS / G;
+  const int MT = L.rows / 32;
+  out->w_off.push_back(static_cast<uint32_t>(out->weights.size() / 16));
+  out->b_off.push_back(static_cast<uint32_t>(out->bias.size()));
+  out->slots.push_back(QS);
+  out->mtiles.push_back(MT);
+  size_t base = out->weights.size();
+  out->weights.resize(base + static_cast<size_t>(MT) * steps * 64 * 16);
+  uint8_t* dst = out->weights.data() + base;
+  for (int m = 0; m < MT; ++m)
+    for (int s = 0; s < steps; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        int i = lane & 31, h = lane >> 5;
+        int row = 32 * m + i;
+        for (int e = 0; e < G; ++e) {
+          int q = G * s + e;
+          int col = h ? L.col_h1[q] : L.col_h0[q];
+          float v = (col >= 0) ? L.w[static_cast<size_t>(row) * L.cols + col] : 0.f;
+          size_t frag = (static_cast<size_t>(m) * steps + s) * 64 + lane;
+          if (elem == Elem::F32) {
+            std::memcpy(dst + frag * 16 + 4 * e, &v, 4);
+          } else {
+            uint16_t hv = (elem == Elem::BF16) ? f32_to_bf16(v) : f32_to_f16(v);
+            std::memcpy(dst + frag * 16 + 2 * e, &hv, 2);
+          }
+        }
+      }
+  for (int m = 0; m < MT; ++m)
+    for (int h = 0; h < 2; ++h)
+      for (int r = 0; r < 16; ++r) out->bias.push_back(L.b[32 * m + 8 * (r >> 2) + 4 * h + (r & 3)]);
+}
+
+}  // namespace
+
+bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, PackedNet* out, std::string* err) {
+  *out = PackedNet();
+  out->elem = elem;
+  const int n_dir = 3 + 6 * sh.fd0, n_pos = 3 + 6 * sh.fp0;
+  const int n_in = n_dir + n_pos;
+  for (int i = 0; i < 8; ++i) {
+    const Tensor* W = find(net0, "layers." + std::to_string(i) + ".weight", err);
+    const Tensor* B = find(net0, "layers." + std::to_string(i) + ".bias", err);
+    if (!W || !B) return false;
+    const int n_out = (i == 7) ? kBins : 256;
+    const int k = (i == 0) ? n_in : 256;
+    if (W->rows() != n_out) {
+      if (err) *err = "layers." + std::to_string(i) + ".weight: expected " + std::to_string(n_out) + " rows";
+      return false;
+    }
+    VLayer L;
+    init_layer(&L, n_out, k);
+    if (!set_rows(&L, 0, W, B, k, err, "layers." + std::to_string(i))) return false;
+    if (i == 0) {
+      add_pe_slots(&L, sh.fd0, 0);        // [dir PE | pos PE]  (src/features.py:868-874)
+      add_pe_slots(&L, sh.fp0, n_dir);
+    } else {
+      add_act_slots(&L, 256, 0);
+    }
+    emit(L, elem, out);
+  }
+  return true;
+}
+
+bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, PackedNet* out, std::string* err) {
+  *out = PackedNet();
+  out->elem = elem;
+  const int n_pos = 3 + 6 * sh.fp1, n_dir = 3 + 6 * sh.fd1;
+  for (int i = 0; i < 8; ++i) {
+    const std::string nm = "pts_linears." + std::to_string(i);
+    const Tensor* W = find(net1, nm + ".weight", err);
+    const Tensor* B = find(net1, nm + ".bias", err);
+    if (!W || !B) return false;
+    const int k = (i == 0) ? n_pos : (i == 5 ? n_pos + 256 : 256);
+    if (W->rows() != 256) {
+      if (err) *err = nm + ".weight: expected 256 rows";
+      return false;
+    }
+    VLayer L;
+    init_layer(&L, 256, k);
+    if (!set_rows(&L, 0, W, B, k, err, nm)) return false;
+    if (i == 0) {
+      add_pe_slots(&L, sh.fp1, 0);
+    } else if (i == 5) {                   // cat([input_pts, h])  (src/models.py:260-261)
+      add_pe_slots(&L, sh.fp1, 0);
+      add_act_slots(&L, 256, n_pos);
+    } else {
+      add_act_slots(&L, 256, 0);
+    }
+    emit(L, elem, out);
+  }
+  {   // feature_linear rows 0..255, alpha_linear as row 256 (tile 8, row 0)
+    const Tensor* WF = find(net1, "feature_linear.weight", err);
+    const Tensor* BF = find(net1, "feature_linear.bias", err);
+    const Tensor* WA = find(net1, "alpha_linear.weight", err);
+    const Tensor* BA = find(net1, "alpha_linear.bias", err);
+    if (!WF || !BF || !WA || !BA) return false;
+    VLayer L;
+    init_layer(&L, 288, 256);
+    if (!set_rows(&L, 0, WF, BF, 256, err, "feature_linear")) return false;
+    if (WF->rows() != 256 || WA->rows() != 1) {
+      if (err) *err = "feature_linear/alpha_linear: unexpected row count";
+      return false;
+    }
+    if (!set_rows(&L, 256, WA, BA, 256, err, "alpha_linear")) return false;
+    add_act_slots(&L, 256, 0);
+    emit(L, elem, out);
+  }
+  {   // views_linears.0 on cat([feature, input_views])  (src/models.py:266-270)
+    const Tensor* W = find(net1, "views_linears.0.weight", err);
+    const Tensor* B = find(net1, "views_linears.0.bias", err);
+    if (!W || !B) return false;
+    if (W->rows() != 128) {
+      if (err) *err = "views_linears.0.weight: expected 128 rows";
+      return false;
+    }
+    VLayer L;
+    init_layer(&L, 128, 256 + n_dir);
+    if (!set_rows(&L, 0, W, B, 256 + n_dir, err, "views_linears.0")) return false;
+    add_act_slots(&L, 256, 0);
+    add_pe_slots(&L, sh.fd1, 256);
+    emit(L, elem, out);
+  }
+  {   // rgb_linear 128 -> 3 (tile 0 rows 0..2)
+    const Tensor* W = find(net1, "rgb_linear.weight", err);
+    const Tensor* B = find(net1, "rgb_linear.bias", err);
+    if (!W || !B) return false;
+    if (W->rows() != 3) {
+      if (err) *err = "rgb_linear.weight: expected 3 rows";
+      return false;
+    }
+    VLayer L;
+    init_layer(&L, 32, 128);
+    if (!set_rows(&L, 0, W, B, 128, err, "rgb_linear")) return false;
+    add_act_slots(&L, 128, 0);
+    emit(L, elem, out);
+  }
+  return true;
+}
+
+}  // namespace adanerf

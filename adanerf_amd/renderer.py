@@ -1,0 +1,291 @@
+"""ctypes host mirror of the reference viewer's object model over the C ABI (include/adanerf_hip.h).
+
+Names follow adanerf_real_time_viewer: ``Settings`` (include/settings.h:12-34, CLI semantics of
+src/settings.cpp:15-47) and ``NeuralRenderer`` with ``init()`` / ``render()``
+(include/neuralrenderer.h:53-55).  Stage-level methods mirror the reference launchers
+(include/cuda/adanerf_cuda_kernels.cuh:20-74) and exist for the parity tests.
+
+The product path is the HIP library.  Nothing here falls back to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from .build import library_path
+
+PREC_BF16, PREC_FP16, PREC_FP32 = 0, 1, 2
+_PREC = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "fp32": PREC_FP32, "f32": PREC_FP32}
+
+BUF_RAYS, BUF_ORACLE, BUF_RAY_OFFSETS, BUF_RAY_COUNTS, BUF_SAMPLE_KEY, BUF_SAMPLE_W, BUF_RAW, BUF_TOTAL = range(8)
+
+
+class AdaNeRFError(RuntimeError):
+    pass
+
+
+class _Options(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("batch_rays", C.c_int32), ("device_id", C.c_int32),
+                ("precision", C.c_int32), ("num_samples", C.c_int32), ("threshold", C.c_float),
+                ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("strip_rows", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
+
+
+class Info(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("rays_local", C.c_int32),
+                ("rays_local_max", C.c_int32), ("batch_rays", C.c_int32), ("n_in0", C.c_int32), ("n_in1", C.c_int32),
+                ("num_samples", C.c_int32), ("threshold", C.c_float), ("dense", C.c_int32), ("use_ndc", C.c_int32),
+                ("precision", C.c_int32), ("compute_units", C.c_int32), ("fov", C.c_float), ("focal", C.c_float),
+                ("view_cell_center", C.c_float * 3), ("view_cell_radius", C.c_float), ("depth_range", C.c_float * 2),
+                ("max_depth", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("total_samples", C.c_int64), ("rays", C.c_int32), ("batches", C.c_int32), ("ms_total", C.c_float),
+                ("ms_sample_mlp", C.c_float), ("ms_compact", C.c_float), ("ms_shade_mlp", C.c_float),
+                ("ms_composite", C.c_float), ("shade_launches", C.c_int32), ("sample_launches", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
+
+
+EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_last_error", "adanerf_set_camera",
+           "adanerf_render", "adanerf_assemble_strips", "adanerf_sync", "adanerf_ray_features", "adanerf_sample_mlp",
+           "adanerf_compact", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_composite", "adanerf_malloc",
+           "adanerf_free", "adanerf_memcpy_h2d", "adanerf_memcpy_d2h", "adanerf_get_buffer"]
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libadanerf_hip.so (built in-tree by adanerf_amd.build).  Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or library_path()
+    if not os.path.exists(p):
+        raise AdaNeRFError("HIP library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % p)
+    lib = C.CDLL(p)
+    vp, i32, f32p = C.c_void_p, C.c_int32, C.c_void_p
+    lib.adanerf_create.argtypes = [C.c_char_p, C.POINTER(_Options), C.POINTER(vp)]
+    lib.adanerf_destroy.argtypes = [vp]
+    lib.adanerf_get_info.argtypes = [vp, C.POINTER(Info)]
+    lib.adanerf_last_error.argtypes = [vp]
+    lib.adanerf_last_error.restype = C.c_char_p
+    lib.adanerf_set_camera.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.adanerf_render.argtypes = [vp, vp, vp, C.POINTER(Stats)]
+    lib.adanerf_assemble_strips.argtypes = [vp, vp, vp]
+    lib.adanerf_sync.argtypes = [vp]
+    lib.adanerf_ray_features.argtypes = [vp, i32, i32, f32p, f32p]
+    lib.adanerf_sample_mlp.argtypes = [vp, i32, i32, f32p, f32p]
+    lib.adanerf_compact.argtypes = [vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, vp]
+    lib.adanerf_shade_features.argtypes = [vp, vp, vp, i32, vp]
+    lib.adanerf_shade_mlp.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    lib.adanerf_composite.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
+    lib.adanerf_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.adanerf_free.argtypes = [vp, vp]
+    lib.adanerf_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.adanerf_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.adanerf_get_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    for name in EXPORTS:
+        if name != "adanerf_last_error":
+            getattr(lib, name).restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+@dataclass
+class Settings:
+    """Viewer CLI settings (adanerf_real_time_viewer/src/settings.cpp:15-47)."""
+    model_path: str
+    width: int = 800
+    height: int = 800
+    batch_size: int = -1          # -bs: <= 0 -> width*height, else min(bs, w*h)
+    number_of_batches: int = 1    # -nb (overridden by batch_size)
+    write_images: bool = False
+    is_debug: bool = True         # headless always
+
+    @property
+    def total_size(self) -> int:
+        return self.width * self.height
+
+    def resolved_batch(self) -> int:
+        if self.batch_size and self.batch_size > 0:
+            return min(self.batch_size, self.total_size)
+        if self.number_of_batches > 1:
+            return -(-self.total_size // self.number_of_batches)
+        return self.total_size
+
+
+class DeviceArray:
+    """A device allocation owned by the library's allocator, with numpy round trips."""
+
+    def __init__(self, r: "NeuralRenderer", shape, dtype):
+        self.r = r
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        r._check(r.lib.adanerf_malloc(r.handle, max(self.nbytes, 1), C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray) -> "DeviceArray":
+        a = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert a.nbytes == self.nbytes, (a.shape, self.shape)
+        if self.nbytes:
+            self.r._check(self.r.lib.adanerf_memcpy_h2d(self.r.handle, self.ptr, a.ctypes.data, self.nbytes))
+        return self
+
+    def numpy(self, count: Optional[int] = None) -> np.ndarray:
+        shape = self.shape if count is None else (count,) + self.shape[1:]
+        out = np.empty(shape, dtype=self.dtype)
+        if out.nbytes:
+            self.r._check(self.r.lib.adanerf_memcpy_d2h(self.r.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr and self.r.handle:
+            self.r.lib.adanerf_free(self.r.handle, self.ptr)
+        self.ptr = None
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, DeviceArray):
+        return x.ptr
+    if hasattr(x, "data_ptr"):      # torch tensor on the context's device
+        return x.data_ptr()
+    return int(x)
+
+
+class NeuralRenderer:
+    """Headless counterpart of the viewer's NeuralRenderer: ``init()`` loads the model directory and
+    builds the device state, ``render()`` produces one frame."""
+
+    def __init__(self, settings: Settings, precision="bf16", device_id: int = 0, num_samples: int = 0,
+                 threshold: float = -1.0, shard_rank: int = 0, shard_world: int = 1, strip_rows: int = 8,
+                 lib_path: Optional[str] = None):
+        self.settings = settings
+        self.lib = load_library(lib_path)
+        self.handle = None
+        self._opt = _Options(width=settings.width, height=settings.height, batch_rays=settings.resolved_batch(),
+                             device_id=device_id, precision=_PREC[precision] if isinstance(precision, str) else int(precision),
+                             num_samples=num_samples, threshold=threshold, shard_rank=shard_rank,
+                             shard_world=shard_world, strip_rows=strip_rows)
+        self.info = Info()
+        self.last_stats = Stats()
+        self._own = []
+
+    # -- lifecycle -------------------------------------------------------------------------------
+    def init(self) -> bool:
+        h = C.c_void_p()
+        rc = self.lib.adanerf_create(self.settings.model_path.encode(), C.byref(self._opt), C.byref(h))
+        if rc != 0:
+            raise AdaNeRFError("adanerf_create(%s) failed (%d): %s" %
+                               (self.settings.model_path, rc, self.lib.adanerf_last_error(None).decode()))
+        self.handle = h.value
+        self._check(self.lib.adanerf_get_info(self.handle, C.byref(self.info)))
+        return True
+
+    def close(self):
+        if self.handle:
+            for a in self._own:
+                a.free()
+            self._own = []
+            self.lib.adanerf_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        if not self.handle:
+            self.init()
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self.lib.adanerf_last_error(self.handle).decode() if self.handle else "?"
+            raise AdaNeRFError("libadanerf_hip error %d: %s" % (rc, msg))
+
+    def empty(self, shape, dtype) -> DeviceArray:
+        a = DeviceArray(self, shape, dtype)
+        self._own.append(a)
+        return a
+
+    def to_device(self, arr: np.ndarray) -> DeviceArray:
+        return self.empty(arr.shape, arr.dtype).upload(arr)
+
+    # -- per frame ---------------------------------------------------------------------------------
+    def set_camera(self, pos, rot_c2w):
+        p = np.ascontiguousarray(pos, dtype=np.float32).reshape(3)
+        r = np.ascontiguousarray(rot_c2w, dtype=np.float32).reshape(9)
+        self._check(self.lib.adanerf_set_camera(self.handle, p.ctypes.data_as(C.POINTER(C.c_float)),
+                                                r.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def render(self, rgba8_out=None, rgb_out=None, stats: bool = False) -> Optional[Stats]:
+        """One frame into caller-owned device buffers ([rays_local] uchar4 / [rays_local,3] fp32).
+        ``stats=True`` synchronises and returns the per-stage timing record."""
+        st = Stats() if stats else None
+        self._check(self.lib.adanerf_render(self.handle, _ptr(rgba8_out), _ptr(rgb_out), C.byref(st) if stats else None))
+        if stats:
+            self.last_stats = st
+        return st
+
+    def render_numpy(self):
+        """Convenience for tests/tools: renders and returns (rgb fp32 [R,3], rgba8 [R,4], Stats)."""
+        n = self.info.rays_local
+        if not hasattr(self, "_o_rgb") or self._o_rgb.shape[0] != n:
+            self._o_rgb = self.empty((n, 3), np.float32)
+            self._o_rgba = self.empty((n, 4), np.uint8)
+        st = self.render(self._o_rgba, self._o_rgb, stats=True)
+        return self._o_rgb.numpy(), self._o_rgba.numpy(), st
+
+    def sync(self):
+        self._check(self.lib.adanerf_sync(self.handle))
+
+    def assemble_strips(self, gathered, image_out):
+        self._check(self.lib.adanerf_assemble_strips(self.handle, _ptr(gathered), _ptr(image_out)))
+
+    def buffer(self, which: int, dtype, shape) -> np.ndarray:
+        """Copies an internal buffer of the last rendered batch to the host."""
+        p = C.c_void_p()
+        nb = C.c_size_t()
+        self._check(self.lib.adanerf_get_buffer(self.handle, which, C.byref(p), C.byref(nb)))
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= nb.value, (out.nbytes, nb.value)
+        if out.nbytes:
+            self._check(self.lib.adanerf_memcpy_d2h(self.handle, out.ctypes.data, p.value, out.nbytes))
+        return out
+
+    # -- stage-level entry points --------------------------------------------------------------------
+    def ray_features(self, first_ray: int, n_rays: int, features_out=None, rays_out=None):
+        self._check(self.lib.adanerf_ray_features(self.handle, first_ray, n_rays, _ptr(features_out), _ptr(rays_out)))
+
+    def sample_mlp(self, first_ray: int, n_rays: int, oracle_out=None, rays_out=None):
+        self._check(self.lib.adanerf_sample_mlp(self.handle, first_ray, n_rays, _ptr(oracle_out), _ptr(rays_out)))
+
+    def compact(self, oracle, n_rays: int, n_max: int, thr: float, ray_offsets, ray_counts, sample_key, sample_w, total):
+        self._check(self.lib.adanerf_compact(self.handle, _ptr(oracle), n_rays, n_max, thr, _ptr(ray_offsets),
+                                             _ptr(ray_counts), _ptr(sample_key), _ptr(sample_w), _ptr(total)))
+
+    def shade_features(self, rays, sample_key, n_samples: int, features_out):
+        self._check(self.lib.adanerf_shade_features(self.handle, _ptr(rays), _ptr(sample_key), n_samples, _ptr(features_out)))
+
+    def shade_mlp(self, rays, sample_key, total, max_samples: int, raw_out, precision: int = -1):
+        self._check(self.lib.adanerf_shade_mlp(self.handle, _ptr(rays), _ptr(sample_key), _ptr(total), max_samples,
+                                               precision, _ptr(raw_out)))
+
+    def composite(self, raw, sample_w, ray_offsets, ray_counts, n_rays: int, rgb_out=None, rgba8_out=None):
+        self._check(self.lib.adanerf_composite(self.handle, _ptr(raw), _ptr(sample_w), _ptr(ray_offsets), _ptr(ray_counts),
+                                               n_rays, _ptr(rgb_out), _ptr(rgba8_out)))

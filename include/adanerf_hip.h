@@ -1,0 +1,230 @@
+/*
+ * adanerf_hip.h -- C ABI of libadanerf_hip.so, the MI355X (gfx950) AdaNeRF inference renderer.
+ *
+ * Drop-in boundary: these entry points are what the reference viewer's host pipeline binds in
+ * place of its CUDA launchers + TensorRT contexts.  Reference interface replaced (paths relative
+ * to /root/reference/adanerf_real_time_viewer):
+ *
+ *   adanerf_create / adanerf_destroy     NeuralRenderer::init (src/neuralrenderer.cpp:59-139):
+ *                                        Config::load (src/config.cpp:270-344), Encoding::load,
+ *                                        RayMarchFromPoses::create (src/featureset.cpp:67-140),
+ *                                        ImageGenerator::load/initEngine (src/imagegenerator.cpp:84-226)
+ *   adanerf_set_camera                   Camera::UpdateFeatureRot/getPosition (src/camera.cpp:143-201)
+ *   adanerf_render                       ImageGenerator::inference, 2-context adaptive branch
+ *                                        (src/imagegenerator.cpp:282-394) as called from
+ *                                        NeuralRenderer::render (src/neuralrenderer.cpp:146-182)
+ *   adanerf_ray_features                 updateSpherePosDirBatchedUnrolledEnc
+ *                                        (include/cuda/adanerf_cuda_kernels.cuh:41-45)
+ *   adanerf_sample_mlp                   contexts[0]->executeV2 (src/imagegenerator.cpp:308-312)
+ *   adanerf_compact                      updateRayMarchFromPosesAdaptive, selection half
+ *                                        (include/cuda/adanerf_cuda_kernels.cuh:52-58; kernels
+ *                                        src/cuda/adaptive_cuda_kernels.cu:229-607)
+ *   adanerf_shade_features               updateRayMarchFromPosesAdaptive, feature half
+ *                                        (rayMarchFromPosesAdaptive[NDC], adaptive_cuda_kernels.cu:609-739)
+ *   adanerf_shade_mlp                    contexts[1]->executeV2 (src/imagegenerator.cpp:336-344)
+ *   adanerf_composite                    copyResultRaymarchAdaptiveMultDepth
+ *                                        (include/cuda/adanerf_cuda_kernels.cuh:30-32)
+ *
+ * Numerics follow the reference's PyTorch path (src/evaluate.py over nerf_raymarch_common.py /
+ * features.py / models.py) wherever it disagrees with the viewer.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ADANERF_E* code on failure; the message is
+ *     available from adanerf_last_error().  Nothing throws or aborts across this boundary.
+ *   - one context = one device = one non-default HIP stream.  A context is not thread-safe;
+ *     distinct contexts are independent.
+ *   - pointers named d_* are DEVICE pointers on the context's device; all others are host.
+ *   - the library owns every buffer behind the context; the caller owns output buffers it passes.
+ *   - calls enqueue on the context's stream; adanerf_sync() (or stats != NULL) waits.
+ */
+#ifndef ADANERF_HIP_H
+#define ADANERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADANERF_ABI_VERSION 1
+
+enum {
+  ADANERF_OK = 0,
+  ADANERF_EINVAL = -1,    /* bad argument */
+  ADANERF_EIO = -2,       /* model directory / file format problem */
+  ADANERF_EDEVICE = -3,   /* HIP runtime error */
+  ADANERF_EUNSUPPORTED = -4 /* config outside the supported north-star path */
+};
+
+/* arithmetic of the shading MLP's MFMA path (the sampling MLP is always exact fp32 MFMA) */
+enum {
+  ADANERF_PREC_BF16 = 0,  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+  ADANERF_PREC_FP16 = 1,  /* v_mfma_f32_32x32x16_f16,  fp32 accumulate */
+  ADANERF_PREC_FP32 = 2   /* v_mfma_f32_32x32x2_f32 (exact fp32; parity mode) */
+};
+
+typedef struct adanerf_ctx adanerf_ctx;
+
+typedef struct adanerf_options {
+  int32_t width;            /* image width  (Settings::width,  -s w h) */
+  int32_t height;           /* image height (Settings::height)         */
+  int32_t batch_rays;       /* <=0: whole frame; else min(batch_rays, rays) like Settings::batch_size (-bs) */
+  int32_t device_id;        /* HIP device ordinal */
+  int32_t precision;        /* ADANERF_PREC_* for the shading MLP */
+  int32_t num_samples;      /* >0 overrides numRaymarchSamples from config.ini */
+  float   threshold;        /* >=0 overrides adaptiveSamplingThreshold; <0 keeps config value */
+  int32_t shard_rank;       /* image-strip shard of this context (multi-GPU); 0 */
+  int32_t shard_world;      /* number of shards; 1 */
+  int32_t strip_rows;       /* rows per strip for round-robin strip sharding; <=0 -> 8 */
+  int32_t reserved[6];
+} adanerf_options;
+
+typedef struct adanerf_info {
+  int32_t abi_version;
+  int32_t width, height;
+  int32_t rays_local;       /* rays rendered by this context (all of w*h when shard_world==1) */
+  int32_t rays_local_max;   /* max over shards (gather payload size in rays) */
+  int32_t batch_rays;
+  int32_t n_in0, n_in1;     /* sampling / shading net input widths (90/90, or 30/90 for 2-2 NDC oracle) */
+  int32_t num_samples;      /* N */
+  float   threshold;
+  int32_t dense;            /* threshold == 0: all 128 bins, no selection */
+  int32_t use_ndc;
+  int32_t precision;
+  int32_t compute_units;
+  float   fov, focal;
+  float   view_cell_center[3];
+  float   view_cell_radius;
+  float   depth_range[2];
+  float   max_depth;
+} adanerf_info;
+
+/* per-frame statistics: the fields the reference logs every 100 frames
+ * (src/imagegenerator.cpp:379-393): Inference 1/2, fc1, fc2, rm, avg samples ppx */
+typedef struct adanerf_stats {
+  int64_t total_samples;      /* S summed over batches */
+  int32_t rays;               /* rays rendered */
+  int32_t batches;
+  float   ms_total;           /* first launch -> last kernel end, HIP events on the context's stream */
+  float   ms_sample_mlp;      /* ray gen + oracle PE + sampling MLP  ("fc1" + "Inference 1") */
+  float   ms_compact;         /* selection + scan + expand           ("fc2", selection half) */
+  float   ms_shade_mlp;       /* fused PE + shading MLP              ("fc2" feature half + "Inference 2") */
+  float   ms_composite;       /* compositing                          ("rm") */
+  int32_t shade_launches;     /* kernel launches behind ms_shade_mlp  */
+  int32_t sample_launches;    /* kernel launches behind ms_sample_mlp */
+  int32_t reserved[6];
+} adanerf_stats;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+
+/* model_dir holds config.ini, dataset_info.txt, model0.onnx, model1.onnx (the format written by the
+ * reference's src/export.py).  A trailing path separator is optional. */
+int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ctx** out);
+int adanerf_destroy(adanerf_ctx* ctx);
+int adanerf_get_info(const adanerf_ctx* ctx, adanerf_info* info);
+/* message of the last failing call on ctx; ctx == NULL reads the thread's last create() failure */
+const char* adanerf_last_error(const adanerf_ctx* ctx);
+
+/* ---- per frame ---------------------------------------------------------------------------- */
+
+/* pos: camera position (world).  rot_c2w: row-major 3x3 camera-to-world rotation; camera looks
+ * along -z, +y up (the convention of src/util/raygeneration.py:24-25). */
+int adanerf_set_camera(adanerf_ctx* ctx, const float pos[3], const float rot_c2w[9]);
+
+/* Renders this context's rays.  d_rgba8_out: [rays_local] uchar4 (A=255), row-major over the shard's
+ * rows -- for shard_world==1 that is the whole image, pixel (x,y) at y*w+x.  d_rgb_f32_out: optional
+ * [rays_local,3] fp32 unclamped colour (parity output).  Either may be NULL.  stats != NULL makes
+ * the call synchronous and fills the per-stage timings. */
+int adanerf_render(adanerf_ctx* ctx, void* d_rgba8_out, float* d_rgb_f32_out, adanerf_stats* stats);
+
+/* De-interleaves the gathered shard payloads ([shard_world][rays_local_max] uchar4, rank-major)
+ * into the full row-major image [h*w] uchar4. */
+int adanerf_assemble_strips(adanerf_ctx* ctx, const void* d_gathered, void* d_image_out);
+
+int adanerf_sync(adanerf_ctx* ctx);
+
+/* ---- stage-level entry points (mirror the reference launchers; used by the parity tests) ---- */
+
+/* Oracle-net input features [n_rays, n_in0] fp32 = [PE(dir/|dir|) | PE(p)] and the per-ray record
+ * d_rays_out [n_rays, 8] fp32 = (origin.xyz, 0, dir.xyz, 0) handed to the shading stage (sphere-exit
+ * point and un-normalised world direction; NDC-space origin/direction when useNDC).  first_ray
+ * indexes this context's local ray list.  Either output may be NULL. */
+int adanerf_ray_features(adanerf_ctx* ctx, int32_t first_ray, int32_t n_rays,
+                         float* d_features_out, float* d_rays_out);
+
+/* Fused ray generation + PE + sampling MLP -> raw oracle values [n_rays,128] fp32 (+ ray records). */
+int adanerf_sample_mlp(adanerf_ctx* ctx, int32_t first_ray, int32_t n_rays,
+                       float* d_oracle_out, float* d_rays_out);
+
+/* Adaptive selection + deterministic compaction of arbitrary oracle values.
+ *   d_oracle       [n_rays,128] fp32
+ *   n_max, thr     N and threshold (thr > 0)
+ *   d_ray_offsets  [n_rays] int32  exclusive prefix sum of counts (ray-major)
+ *   d_ray_counts   [n_rays] int32  1..n_max
+ *   d_sample_key   [>= n_rays*n_max] uint32  (local_ray << 7) | bin, ray-major, bins ascending
+ *   d_sample_w     [>= n_rays*n_max] fp32    oracle value of the kept bin
+ *   d_total        [1] int32       S
+ * thr == 0 selects the dense mode (all 128 bins; n_max must be 128). */
+int adanerf_compact(adanerf_ctx* ctx, const float* d_oracle, int32_t n_rays, int32_t n_max, float thr,
+                    int32_t* d_ray_offsets, int32_t* d_ray_counts, uint32_t* d_sample_key,
+                    float* d_sample_w, int32_t* d_total);
+
+/* Explicit shading-net input features [n_samples, n_in1] fp32 = [PE(x^) | PE(dir)] (parity/debug;
+ * the render path never materialises them). */
+int adanerf_shade_features(adanerf_ctx* ctx, const float* d_rays, const uint32_t* d_sample_key,
+                           int32_t n_samples, float* d_features_out);
+
+/* Fused PE + shading MLP over compacted samples -> raw [rgb, alpha] fp32 [n_samples,4].
+ * d_total (device int32) bounds the work without a host sync; max_samples bounds the launch.
+ * precision: ADANERF_PREC_*, or -1 for the context's. */
+int adanerf_shade_mlp(adanerf_ctx* ctx, const float* d_rays, const uint32_t* d_sample_key,
+                      const int32_t* d_total, int32_t max_samples, int32_t precision, float* d_raw_out);
+
+/* Per-ray front-to-back compositing: c = sigmoid(raw.rgb), a = sigmoid(raw.a) * w. */
+int adanerf_composite(adanerf_ctx* ctx, const float* d_raw, const float* d_sample_w,
+                      const int32_t* d_ray_offsets, const int32_t* d_ray_counts, int32_t n_rays,
+                      float* d_rgb_out, void* d_rgba8_out);
+
+/* ---- device memory plumbing for callers without a HIP runtime of their own ---- */
+int adanerf_malloc(adanerf_ctx* ctx, size_t bytes, void** d_out);
+int adanerf_free(adanerf_ctx* ctx, void* d_ptr);
+int adanerf_memcpy_h2d(adanerf_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int adanerf_memcpy_d2h(adanerf_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+/* Internal buffers of the last adanerf_render batch (device pointers, valid until the next call). */
+enum {
+  ADANERF_BUF_RAYS = 0,        /* [batch,8] fp32 */
+  ADANERF_BUF_ORACLE = 1,      /* [batch,128] fp32 */
+  ADANERF_BUF_RAY_OFFSETS = 2, /* [batch] int32 */
+  ADANERF_BUF_RAY_COUNTS = 3,  /* [batch] int32 */
+  ADANERF_BUF_SAMPLE_KEY = 4,  /* [S] uint32 */
+  ADANERF_BUF_SAMPLE_W = 5,    /* [S] fp32 */
+  ADANERF_BUF_RAW = 6,         /* [S,4] fp32 */
+  ADANERF_BUF_TOTAL = 7        /* [1] int32 */
+};
+int adanerf_get_buffer(adanerf_ctx* ctx, int32_t which, void** d_out, size_t* bytes_out);
+
+/* ---- host-only inspection (no device needed; used by the CPU test-suite) ---- */
+
+/* Parses and validates config.ini / dataset_info.txt exactly as adanerf_create does and fills
+ * `info` (compute_units = 0).  Fails with the same codes/messages as adanerf_create. */
+int adanerf_host_parse_model(const char* model_dir, const adanerf_options* opt, adanerf_info* info);
+
+/* Packs net 0 (sampling) or net 1 (shading) of model_dir into MFMA A-fragment order for
+ * `precision` (ADANERF_PREC_*).  Two-call pattern: pass NULL outputs to query sizes.
+ *   weights_out  packed 16-byte fragments        (*weights_bytes)
+ *   bias_out     packed bias blocks, fp32        (*bias_floats)
+ *   layer_out    per layer {w_off (16-B units), b_off (floats), slots per lane-half, 32-row tiles}
+ *                as int32[4] each                (*n_layers) */
+int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precision, void* weights_out,
+                              size_t* weights_bytes, float* bias_out, size_t* bias_floats, int32_t* layer_out,
+                              int32_t* n_layers);
+
+/* 128-entry world-depth table the shading stage indexes by bin (and dense t-values) for model_dir. */
+int adanerf_host_depth_table(const char* model_dir, const adanerf_options* opt, float* ztab128);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADANERF_HIP_H */

@@ -1,0 +1,205 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol,
+model-directory parsing/validation, the weight packer + MFMA slot layout (emulated in numpy against
+the oracle), and that the product path refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import adanerf_oracle as O
+from conftest import ROOT, case_weights, load_case
+from mfma_emulation import PackedNet, pack_weights, run_sampling_net, run_shading_net
+
+import adanerf_amd
+from adanerf_amd import renderer as R
+
+
+@pytest.fixture(scope="module")
+def lib():
+    adanerf_amd.build_library()
+    return R.load_library()
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "adanerf_hip.h")).read()
+    return sorted(set(re.findall(r"\b(adanerf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = _header_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libadanerf_hip.so does not export %s" % n
+    assert set(R.EXPORTS) <= set(names)
+
+
+def _opts(**kw):
+    o = R._Options(width=64, height=48, batch_rays=0, device_id=0, precision=0, num_samples=0, threshold=-1.0,
+                   shard_rank=0, shard_world=1, strip_rows=8)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _model_dir(tmp_path, scene=None, weights=None, name="m"):
+    scene = scene or O.Scene((0.5, -1.0, 1.25), (0.7, 0.7, 0.2), (0.15, 8.25), 1.125, 8.75, 8, 0.2)
+    weights = weights or O.synthetic_weights(3)
+    d = str(tmp_path / name)
+    O.write_model_dir(d, scene, weights)
+    return d, scene, weights
+
+
+def test_parse_model_and_info(lib, tmp_path):
+    d, sc, _ = _model_dir(tmp_path)
+    info = R.Info()
+    lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+    o = _opts()
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == 0
+    assert (info.width, info.height, info.rays_local, info.batch_rays) == (64, 48, 64 * 48, 64 * 48)
+    assert (info.n_in0, info.n_in1, info.num_samples, info.dense, info.use_ndc) == (90, 90, 8, 0, 0)
+    assert abs(info.threshold - 0.2) < 1e-7
+    assert abs(info.focal - O.focal_from_fov(64, sc.fov)) < 1e-3
+    assert abs(info.view_cell_radius - sc.radius) < 1e-6
+    # batch semantics of Settings::init (src/settings.cpp:38-46)
+    o = _opts(batch_rays=1000)
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == 0 and info.batch_rays == 1000
+    o = _opts(batch_rays=10 ** 8)
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == 0 and info.batch_rays == 64 * 48
+    # overrides
+    o = _opts(num_samples=4, threshold=0.3)
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == 0
+    assert info.num_samples == 4 and abs(info.threshold - 0.3) < 1e-7
+
+
+def test_strip_sharding_partitions_rows(lib, tmp_path):
+    d, _, _ = _model_dir(tmp_path)
+    lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+    for (w, h, world, strip) in [(800, 800, 8, 8), (1920, 1080, 8, 8), (100, 37, 3, 4), (64, 5, 4, 8)]:
+        tot = 0
+        mx = 0
+        for rank in range(world):
+            info = R.Info()
+            o = _opts(width=w, height=h, shard_rank=rank, shard_world=world, strip_rows=strip)
+            assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == 0
+            tot += info.rays_local
+            mx = max(mx, info.rays_local)
+            assert info.rays_local_max >= info.rays_local
+            rmax = info.rays_local_max
+        assert tot == w * h
+        assert rmax == mx
+
+
+def test_error_codes_and_messages(lib, tmp_path):
+    lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+    info = R.Info()
+    o = _opts()
+    assert lib.adanerf_host_parse_model(str(tmp_path / "nope").encode(), C.byref(o), C.byref(info)) == -2
+    assert b"couldn't open" in lib.adanerf_last_error(None)
+    d, _, _ = _model_dir(tmp_path)
+    # threshold < 0 unsupported, dense needs N == 128
+    cfg = open(os.path.join(d, "config.ini")).read()
+    open(os.path.join(d, "config.ini"), "w").write(cfg.replace("adaptiveSamplingThreshold = 0.2", "adaptiveSamplingThreshold = -1.0"))
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == -4
+    o2 = _opts(threshold=0.0)
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o2), C.byref(info)) == -4
+    o3 = _opts(threshold=0.0, num_samples=128)
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o3), C.byref(info)) == 0 and info.dense == 1
+    open(os.path.join(d, "config.ini"), "w").write(cfg.replace("raySampleInput = [0, 0]", "raySampleInput = [128, 0]"))
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == -4
+    open(os.path.join(d, "config.ini"), "w").write(cfg.replace("posEncArgs = [10-4, 10-4]", "posEncArgs = [6-3, 10-4]"))
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == -4
+    assert lib.adanerf_host_parse_model(None, C.byref(o), C.byref(info)) == -1
+
+
+def test_reference_sample_config_forms_parse(lib, tmp_path):
+    """Both shipped config.ini forms (the 71-line training config with section headers and the trimmed
+    19-key one) parse to the same Config; here a training-style file is synthesised."""
+    d, sc, _ = _model_dir(tmp_path)
+    cfg = open(os.path.join(d, "config.ini")).read()
+    extra = "[Features]\nlayers = [8, 8]\nlayerWidth = [256, 256]\nskips = [, auto]\ndevice = 0\nlosses = [NeRFWeightMultiplicationLoss, MSE]\n"
+    open(os.path.join(d, "config.ini"), "w").write("config = /some/path//fine_training.ini\n" + extra +
+                                                   cfg.replace("outFeatures = [Raw, RGBARayMarch]", "outFeatures = [RawSigmoid, RGBARayMarch]"))
+    lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+    info = R.Info()
+    o = _opts()
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == 0
+    assert info.num_samples == sc.num_samples
+
+
+def test_depth_table_matches_oracle(lib, tmp_path):
+    lib.adanerf_host_depth_table.argtypes = [C.c_char_p, C.POINTER(R._Options), C.c_void_p]
+    for sc in [O.Scene((0, 0, 0), (1, 1, 1), (0.1542, 8.3582), 1.1, 8.8, 8, 0.2),
+               O.Scene((0, 0, 0), (1, 1, 1), (-0.4277, 7.0724), 1.5, 8.7, 128, 0.0),
+               O.Scene((0, 0, 0), (1, 1, 1), (0.9, 12.0), 1.0, 12.0, 8, 0.2, use_ndc=True, depth_transform="linear",
+                       pos_enc=((2, 2), (10, 4)), normalization="None")]:
+        w = O.synthetic_weights(1, n_in0=sc.n_in0)
+        d, _, _ = _model_dir(tmp_path, sc, w, name="z%d%d" % (sc.num_samples, int(sc.use_ndc)))
+        z = np.zeros(128, dtype=np.float32)
+        o = _opts()
+        assert lib.adanerf_host_depth_table(d.encode(), C.byref(o), z.ctypes.data) == 0, lib.adanerf_last_error(None)
+        t = O.dense_t(sc) if sc.threshold == 0.0 else O.bin_t(np.arange(128))
+        np.testing.assert_allclose(z, O.to_world_depth(t, sc), rtol=3e-7, atol=1e-6)
+
+
+@pytest.mark.parametrize("precision,tol", [(2, 2e-4), (1, 3e-2), (0, 2e-1)])
+def test_packed_shading_net_reproduces_oracle(lib, tmp_path, precision, tol):
+    z, meta, sc = load_case("classroom_n8_thr02")
+    wts = case_weights(meta)
+    d, _, _ = _model_dir(tmp_path, sc, wts)
+    w, b, lay = pack_weights(lib, d, 1, precision)
+    assert lay.shape[0] == 11
+    assert [int(v) for v in lay[:, 3]] == [8] * 8 + [9, 4, 1]
+    G = 4 if precision == 2 else 8
+    assert sum(int(l[2]) // G * int(l[3]) for l in lay) * 1024 == w.size
+    if precision != 2:
+        assert w.size == 1184 * 1024          # kShadeFrags16 in kernels.hip.hpp
+        assert b.size == 2496                 # kShadeBiasFloats
+    # a few real samples: positions/dirs from the golden case
+    count = z["sel_count"].astype(np.int32)
+    off, sray, sbin, sw = O.compact(count, z["sel_bins"], z["sel_weight"])
+    n = 48
+    zw = O.to_world_depth(O.bin_t(sbin[:n].astype(np.int64)), sc)
+    feat = O.shading_inputs(z["p"], z["nds"], sray[:n], zw, sc)
+    ref = O.shading_mlp(feat, wts.net1)
+    x = feat[:, 0:3]
+    dpe = feat[:, 63:66]
+    out = run_shading_net(PackedNet(w, b, lay, precision), x, dpe)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=tol)
+
+
+def test_packed_sampling_net_reproduces_oracle(lib, tmp_path):
+    for name in ["classroom_n8_thr02", "ndc_synthetic_n8"]:
+        z, meta, sc = load_case(name)
+        wts = case_weights(meta)
+        d, _, _ = _model_dir(tmp_path, sc, wts, name=name)
+        w, b, lay = pack_weights(lib, d, 0, 2)
+        fp, fd = sc.pos_enc[0]
+        n = 64
+        nds = z["nds"][:n]
+        u = (nds / np.sqrt(np.sum(nds * nds, -1, keepdims=True))).astype(np.float32)
+        orc = run_sampling_net(PackedNet(w, b, lay, 2), u, z["p"][:n], fp, fd)
+        np.testing.assert_allclose(orc, z["oracle_out"][:n], rtol=0, atol=5e-5)
+
+
+def test_product_path_fails_loudly_without_gpu(lib, tmp_path):
+    """No CPU fallback: on a box without a HIP device create() must fail with EDEVICE (on the GPU box
+    this test is a no-op)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    d, _, _ = _model_dir(tmp_path)
+    r = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, 64, 48))
+    with pytest.raises(adanerf_amd.AdaNeRFError) as ei:
+        r.init()
+    assert "no HIP device" in str(ei.value) or "hip" in str(ei.value).lower()
+
+
+def test_settings_batch_semantics():
+    S = adanerf_amd.Settings
+    assert S("x", 800, 800).resolved_batch() == 640000
+    assert S("x", 800, 800, batch_size=80000).resolved_batch() == 80000
+    assert S("x", 800, 800, batch_size=10 ** 9).resolved_batch() == 640000
+    assert S("x", 800, 800, number_of_batches=8).resolved_batch() == 80000
+    assert S("x", 10, 10, number_of_batches=3).resolved_batch() == 34
