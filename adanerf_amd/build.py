@@ -42,7 +42,7 @@ def build_library(force=False, verbose=False):
     if not force and not _stale(out, deps):
         return out
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared"] + \
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"] + \
           [os.path.join(CSRC, s) for s in LIB_SOURCES] + ["-o", out]
     if verbose:
         print(" ".join(cmd))

@@ -38,8 +38,13 @@ struct adanerf_ctx {
   adanerf_info info{};
   Config cfg;
   std::string err;
-  hipStream_t stream = nullptr;
-  std::vector<hipEvent_t> events;
+  hipStream_t stream = nullptr;       // stream in use
+  hipStream_t own_stream = nullptr;   // the context's own stream
+  std::vector<hipEvent_t> events;     // pool; 5 per batch
+  size_t events_used = 0;
+  bool profiling = false;
+  int prof_frames = 0;
+  std::vector<int32_t*> pinned_totals;   // one pinned int32 per recorded batch
 
   RayGenParams rg{};
   ShadeParams sp{};
@@ -455,7 +460,8 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     return bail(ADANERF_EDEVICE, std::string("device is ") + prop.gcnArchName + "; this library is built for gfx950 (MI355X) only");
   c->info.compute_units = prop.multiProcessorCount;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(ADANERF_EDEVICE, "hipStreamCreate failed");
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(ADANERF_EDEVICE, "hipStreamCreate failed");
+  c->stream = c->own_stream;
 
   rc = dev_alloc(c, &c->ztab, kBins * sizeof(float));
   if (rc) return bail(rc, c->err);
@@ -531,11 +537,12 @@ int adanerf_destroy(adanerf_ctx* c) {
   if (!c) return ADANERF_OK;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+  for (int32_t* p : c->pinned_totals) (void)hipHostFree(p);
   DevBuf* bufs[] = {&c->net0.w, &c->net0.b, &c->net1[0].w, &c->net1[0].b, &c->net1[1].w, &c->net1[1].b, &c->net1[2].w, &c->net1[2].b,
                     &c->ztab, &c->rays, &c->oracle, &c->ray_offsets, &c->ray_counts, &c->selbin, &c->selw, &c->block_total,
                     &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw};
   for (DevBuf* b : bufs) dev_free(b);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return ADANERF_OK;
 }
@@ -617,6 +624,36 @@ int adanerf_composite(adanerf_ctx* c, const float* d_raw, const float* d_w, cons
   return launch_composite(c, d_raw, d_w, d_off, d_cnt, n_rays, d_rgb, d_rgba8);
 }
 
+namespace {
+
+constexpr size_t kMaxProfiledBatches = 1 << 16;
+
+int sum_stats(adanerf_ctx* c, adanerf_stats* stats) {
+  std::memset(stats, 0, sizeof(*stats));
+  const size_t nb = c->events_used / 5;
+  for (size_t b = 0; b < nb; ++b) {
+    hipEvent_t* ev = &c->events[b * 5];
+    float t;
+    HIP_TRY(c, hipEventElapsedTime(&t, ev[0], ev[1]));
+    stats->ms_sample_mlp += t;
+    HIP_TRY(c, hipEventElapsedTime(&t, ev[1], ev[2]));
+    stats->ms_compact += t;
+    HIP_TRY(c, hipEventElapsedTime(&t, ev[2], ev[3]));
+    stats->ms_shade_mlp += t;
+    HIP_TRY(c, hipEventElapsedTime(&t, ev[3], ev[4]));
+    stats->ms_composite += t;
+    HIP_TRY(c, hipEventElapsedTime(&t, ev[0], ev[4]));
+    stats->ms_total += t;
+    stats->total_samples += *c->pinned_totals[b];
+  }
+  stats->batches = static_cast<int32_t>(nb);
+  stats->shade_launches = static_cast<int32_t>(nb);
+  stats->sample_launches = static_cast<int32_t>(nb);
+  return ADANERF_OK;
+}
+
+}  // namespace
+
 int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* stats) {
   if (!c) return ADANERF_EINVAL;
   const int R = c->info.rays_local, B = c->info.batch_rays, N = c->info.num_samples;
@@ -624,12 +661,25 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
   const int n_batches = R > 0 ? (R + B - 1) / B : 0;
   int rc = ensure_batch_buffers(c, std::min(B, std::max(R, 1)), N);
   if (rc) return rc;
-  const size_t n_ev = static_cast<size_t>(n_batches) * 5;
-  if (stats) {
-    while (c->events.size() < n_ev) {
+  if (stats && c->profiling && c->events_used) {   // a synchronous call starts a fresh record
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->events_used = 0;
+    c->prof_frames = 0;
+  }
+  bool record = stats || c->profiling;
+  if (record && c->events_used / 5 + n_batches > kMaxProfiledBatches) record = stats != nullptr;
+  if (record) {
+    const size_t need = c->events_used + static_cast<size_t>(n_batches) * 5;
+    while (c->events.size() < need) {
       hipEvent_t e;
       HIP_TRY(c, hipEventCreate(&e));
       c->events.push_back(e);
+    }
+    while (c->pinned_totals.size() < need / 5) {
+      int32_t* p = nullptr;
+      HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(int32_t), hipHostMallocDefault));
+      *p = 0;
+      c->pinned_totals.push_back(p);
     }
   }
   float* rays = reinterpret_cast<float*>(c->rays.p);
@@ -640,10 +690,9 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
   float* sw = reinterpret_cast<float*>(c->sample_w.p);
   float* raw = reinterpret_cast<float*>(c->raw.p);
   int32_t* total = reinterpret_cast<int32_t*>(c->total.p);
-  std::vector<int32_t> totals(n_batches, 0);
   for (int b = 0; b < n_batches; ++b) {
     const int first = b * B, n = std::min(B, R - first);
-    hipEvent_t* ev = stats ? &c->events[static_cast<size_t>(b) * 5] : nullptr;
+    hipEvent_t* ev = record ? &c->events[c->events_used] : nullptr;
     if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     if ((rc = launch_sample_mlp(c, first, n, oracle, rays))) return rc;
     if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
@@ -656,31 +705,52 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     if ((rc = launch_composite(c, raw, sw, off, cnt, n, d_rgb ? d_rgb + static_cast<size_t>(first) * 3 : nullptr,
                                d_rgba8 ? static_cast<char*>(d_rgba8) + static_cast<size_t>(first) * 4 : nullptr)))
       return rc;
-    if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
-    if (stats) HIP_TRY(c, hipMemcpyAsync(&totals[b], total, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (ev) {
+      HIP_TRY(c, hipEventRecord(ev[4], c->stream));
+      HIP_TRY(c, hipMemcpyAsync(c->pinned_totals[c->events_used / 5], total, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      c->events_used += 5;
+    }
   }
+  if (record) c->prof_frames++;
   if (stats) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    std::memset(stats, 0, sizeof(*stats));
+    if ((rc = sum_stats(c, stats))) return rc;
     stats->rays = R;
-    stats->batches = n_batches;
-    for (int b = 0; b < n_batches; ++b) {
-      hipEvent_t* ev = &c->events[static_cast<size_t>(b) * 5];
-      float t;
-      HIP_TRY(c, hipEventElapsedTime(&t, ev[0], ev[1]));
-      stats->ms_sample_mlp += t;
-      HIP_TRY(c, hipEventElapsedTime(&t, ev[1], ev[2]));
-      stats->ms_compact += t;
-      HIP_TRY(c, hipEventElapsedTime(&t, ev[2], ev[3]));
-      stats->ms_shade_mlp += t;
-      HIP_TRY(c, hipEventElapsedTime(&t, ev[3], ev[4]));
-      stats->ms_composite += t;
-      stats->total_samples += totals[b];
+    if (n_batches > 0) {   // wall span of this frame, first launch -> last kernel end
+      const size_t e0 = c->events_used - static_cast<size_t>(n_batches) * 5;
+      HIP_TRY(c, hipEventElapsedTime(&stats->ms_total, c->events[e0], c->events[c->events_used - 1]));
     }
-    if (n_batches > 0) HIP_TRY(c, hipEventElapsedTime(&stats->ms_total, c->events[0], c->events[static_cast<size_t>(n_batches - 1) * 5 + 4]));
-    stats->shade_launches = n_batches;
-    stats->sample_launches = n_batches;
+    c->events_used = 0;
+    c->prof_frames = 0;
   }
+  return ADANERF_OK;
+}
+
+int adanerf_set_stream(adanerf_ctx* c, void* hip_stream) {
+  if (!c) return ADANERF_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return ADANERF_OK;
+}
+
+int adanerf_set_profiling(adanerf_ctx* c, int32_t enabled) {
+  if (!c) return ADANERF_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->profiling = enabled != 0;
+  c->events_used = 0;
+  c->prof_frames = 0;
+  return ADANERF_OK;
+}
+
+int adanerf_collect_stats(adanerf_ctx* c, adanerf_stats* stats, int32_t* frames) {
+  if (!c || !stats) return ADANERF_EINVAL;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = sum_stats(c, stats);
+  if (rc) return rc;
+  stats->rays = c->info.rays_local;
+  if (frames) *frames = c->prof_frames;
+  c->events_used = 0;
+  c->prof_frames = 0;
   return ADANERF_OK;
 }
 

@@ -16,6 +16,7 @@ namespace adanerf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -198,11 +199,13 @@ __device__ __forceinline__ void layer_f32(const u32x4* __restrict__ w, const flo
     }
 #pragma unroll
     for (int s4 = 0; s4 < QS / 4; ++s4) {
-      u32x4 a = w[(m * (QS / 4) + s4) * 64 + lane];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[0]), in[4 * s4 + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[1]), in[4 * s4 + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[2]), in[4 * s4 + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[3]), in[4 * s4 + 3], acc, 0, 0, 0);
+      // NB: load as a float vector.  __builtin_bit_cast(float, u32x4_value[i]) miscompiles on
+      // ROCm 7.2 hipcc (every element reads lane register 0).
+      const f32x4 a = reinterpret_cast<const f32x4*>(w)[(m * (QS / 4) + s4) * 64 + lane];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], in[4 * s4 + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], in[4 * s4 + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], in[4 * s4 + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], in[4 * s4 + 3], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[16 * m + r] = RELU ? fmaxf(acc[r], 0.f) : acc[r];

@@ -52,7 +52,8 @@ class Stats(C.Structure):
 
 
 EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_last_error", "adanerf_set_camera",
-           "adanerf_render", "adanerf_assemble_strips", "adanerf_sync", "adanerf_ray_features", "adanerf_sample_mlp",
+           "adanerf_render", "adanerf_assemble_strips", "adanerf_sync", "adanerf_set_stream", "adanerf_set_profiling",
+           "adanerf_collect_stats", "adanerf_ray_features", "adanerf_sample_mlp",
            "adanerf_compact", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_composite", "adanerf_malloc",
            "adanerf_free", "adanerf_memcpy_h2d", "adanerf_memcpy_d2h", "adanerf_get_buffer"]
 
@@ -78,6 +79,9 @@ def load_library(path: Optional[str] = None):
     lib.adanerf_render.argtypes = [vp, vp, vp, C.POINTER(Stats)]
     lib.adanerf_assemble_strips.argtypes = [vp, vp, vp]
     lib.adanerf_sync.argtypes = [vp]
+    lib.adanerf_set_stream.argtypes = [vp, vp]
+    lib.adanerf_set_profiling.argtypes = [vp, i32]
+    lib.adanerf_collect_stats.argtypes = [vp, C.POINTER(Stats), C.POINTER(i32)]
     lib.adanerf_ray_features.argtypes = [vp, i32, i32, f32p, f32p]
     lib.adanerf_sample_mlp.argtypes = [vp, i32, i32, f32p, f32p]
     lib.adanerf_compact.argtypes = [vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, vp]
@@ -253,6 +257,20 @@ class NeuralRenderer:
 
     def sync(self):
         self._check(self.lib.adanerf_sync(self.handle))
+
+    def set_stream(self, hip_stream: Optional[int]):
+        """Enqueue on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._check(self.lib.adanerf_set_stream(self.handle, hip_stream))
+
+    def set_profiling(self, enabled: bool):
+        self._check(self.lib.adanerf_set_profiling(self.handle, 1 if enabled else 0))
+
+    def collect_stats(self):
+        """(Stats summed over the frames rendered since the last collect, number of frames)."""
+        st = Stats()
+        n = C.c_int32(0)
+        self._check(self.lib.adanerf_collect_stats(self.handle, C.byref(st), C.byref(n)))
+        return st, n.value
 
     def assemble_strips(self, gathered, image_out):
         self._check(self.lib.adanerf_assemble_strips(self.handle, _ptr(gathered), _ptr(image_out)))

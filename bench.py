@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- AdaNeRF frame throughput on MI355X (BASELINE.json metric: FPS at 800x800).
+
+One "step" = one full frame of the hot path (ray generation -> sampling MLP -> adaptive compaction ->
+fused PE + shading MLP -> compositing [-> RCCL gather of the RGBA8 strips on N > 1]) for a fixed camera
+on synthetic 800x800 ray batches.  Workload at every N: BASELINE.json configs[1]
+(800x800, N = 8, threshold 0.2, bf16 shading MLP; weights = the reference's exported
+`sample_pavillon_16` model, carried as a data fixture, random-init fallback if absent).
+
+  python bench.py --gpus 1 --steps 30 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the field meanings).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+SHADE_FLOP_PER_SAMPLE = 1186816      # 2 x 593408 MAC
+SAMPLE_FLOP_PER_RAY = 898048         # 2 x 449024 MAC
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (width, height, N, threshold, weights tag)
+    "config2": (800, 800, 8, 0.2, "sample_pavillon_16"),
+    "config3_dense": (800, 800, 128, 0.0, "sample_pavillon_16"),
+    "config4": (800, 800, 8, 0.1, "sample_pavillon_16"),
+}
+
+
+def build_model_dir(td, tag, n, thr):
+    import adanerf_oracle as O
+    gold = os.path.join(ROOT, "tests", "golden")
+    wpath = os.path.join(gold, "weights_%s.npz" % tag)
+    spath = os.path.join(gold, "scene_%s.json" % tag)
+    if os.path.exists(wpath) and os.path.exists(spath):
+        z = np.load(wpath)
+        wts = O.Weights({k[3:]: z[k] for k in z.files if k.startswith("n0/")},
+                        {k[3:]: z[k] for k in z.files if k.startswith("n1/")})
+        s = json.load(open(spath))
+        data = "synthetic rays; weights = reference's exported %s model (fixture)" % tag
+    else:
+        wts = O.synthetic_weights(0, oracle_bias=0.1, oracle_scale=0.3)
+        s = dict(view_cell_center=(0.783, -3.19, 1.39), view_cell_size=(0.7, 0.7, 0.2),
+                 depth_range=(0.1542200982570648, 8.358194804191589), fov=1.1386263370513916, max_depth=8.79825210571289)
+        data = "synthetic rays; random-init weights (seed 0)"
+    sc = O.Scene(tuple(s["view_cell_center"]), tuple(s["view_cell_size"]), tuple(s["depth_range"]), s["fov"],
+                 s["max_depth"], n, thr)
+    O.write_model_dir(td, sc, wts)
+    return sc, wts, data
+
+
+def cpu_baseline(sc, wts, w, h, pose, rot, budget_s=15.0):
+    """The oracle (numpy port of the reference's PyTorch path, validated against the golden vectors)
+    timed on this box's host cores over a bounded band of image rows of the same frame."""
+    import adanerf_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    r0 = h // 2
+    t0 = time.time()
+    O.render_frame(sc, wts, w, h, pose, rot, rows=(r0, r0 + 2))
+    probe = max(time.time() - t0, 1e-3)
+    rows = int(max(2, min(h // 4, (budget_s / probe) * 2)))
+    t0 = time.time()
+    res = O.render_frame(sc, wts, w, h, pose, rot, rows=(r0 - rows // 2, r0 - rows // 2 + rows))
+    dt = time.time() - t0
+    fps = 1.0 / (dt * h / rows)
+    return {"value": fps, "unit": "frames/s", "cores": int(cores), "kind": "port",
+            "sample": "%d of %d image rows (%d rays, %.2f samples/ray) of the same frame, numpy fp32, %.1f s" %
+                      (rows, h, rows * w, float(res["count"].mean()), dt)}, res, (r0 - rows // 2, rows)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--batch-rays", type=int, default=-1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import adanerf_oracle as O
+    import adanerf_amd
+    from adanerf_amd import build as B
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        B.build_library()
+    if dist:
+        dist.barrier()
+
+    w, h, n_max, thr, tag = WORKLOADS[args.workload]
+    td = tempfile.mkdtemp(prefix="adanerf_bench_%d_" % rank)
+    sc, wts, data = build_model_dir(td, tag, n_max, thr)
+    pose = np.array(sc.view_cell_center, dtype=np.float32)
+    rot = O.camera_rotation(100.0, 0.0)
+
+    r = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision,
+                                   device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=8)
+    r.init()
+    r.set_camera(pose, rot)
+    dev = torch.device("cuda", local_rank)
+    # one non-default stream for the renderer AND torch.distributed, so the gather is stream-ordered
+    # behind the compositing kernel without a host sync
+    tstream = torch.cuda.Stream(device=dev)
+    r.set_stream(tstream.cuda_stream)
+    out = torch.zeros((r.info.rays_local_max, 4), dtype=torch.uint8, device=dev)
+    rgb = torch.zeros((max(r.info.rays_local, 1), 3), dtype=torch.float32, device=dev)
+    gathered = image = None
+    if world > 1:
+        if rank == 0:
+            gathered = torch.zeros((world, r.info.rays_local_max, 4), dtype=torch.uint8, device=dev)
+            image = torch.zeros((h * w, 4), dtype=torch.uint8, device=dev)
+
+    def step():
+        with torch.cuda.stream(tstream):
+            _step()
+
+    def _step():
+        r.render(out, rgb)
+        if world > 1:
+            # the one exchange step: RGBA8 strip payloads -> rank 0 over RCCL (xGMI), then de-interleave
+            dist.gather(out, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                r.assemble_strips(gathered, image)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    r.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    st, frames = r.collect_stats()
+    r.set_profiling(False)
+    if dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([float(st.total_samples), float(st.ms_shade_mlp), float(st.ms_sample_mlp)], dtype=torch.float64, device=dev)
+        tot_all = tot.clone()
+        dist.all_reduce(tot_all, op=dist.ReduceOp.SUM)
+        samples_all = float(tot_all[0].item())
+    else:
+        samples_all = float(st.total_samples)
+
+    ms_per_step = dt / args.steps * 1e3
+    fps = args.steps / dt
+    frames = max(frames, 1)
+    samples_per_frame_local = st.total_samples / frames
+    samples_per_frame = samples_all / frames
+    mean_spp = samples_per_frame / (w * h)
+
+    if rank == 0:
+        # roofline of the dominant kernel (fused PE + shading MLP), this rank's launches
+        launches = max(st.shade_launches, 1)
+        shade_ms = st.ms_shade_mlp / launches
+        flop_per_launch = SHADE_FLOP_PER_SAMPLE * (st.total_samples / launches)
+        achieved = flop_per_launch / (shade_ms * 1e-3) / 1e12 if shade_ms > 0 else 0.0
+        peak = PEAK_TFLOPS[args.precision]
+        roofline = {"bound": "mfma", "kernel": "shade_mlp%s_kernel" % ("32" if args.precision == "fp32" else "16"),
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "traffic": None, "avg_launch_ms": shade_ms, "samples_per_launch": st.total_samples / launches,
+                    "flop_per_sample": SHADE_FLOP_PER_SAMPLE}
+        stage_ms = {"sample_mlp": st.ms_sample_mlp / frames, "compact": st.ms_compact / frames,
+                    "shade_mlp": st.ms_shade_mlp / frames, "composite": st.ms_composite / frames}
+        smp_launch = max(st.sample_launches, 1)
+        smp_tflops = SAMPLE_FLOP_PER_RAY * (r.info.rays_local * frames / smp_launch) / (st.ms_sample_mlp / smp_launch * 1e-3) / 1e12 \
+            if st.ms_sample_mlp > 0 else 0.0
+        # HBM-side view of the two bandwidth-bound stages (algorithmic bytes)
+        R = r.info.rays_local
+        comp_bytes = R * 512 + R * 8 + samples_per_frame_local * 10 if thr > 0 else R * 512 + samples_per_frame_local * 8
+        cmp_bytes = samples_per_frame_local * 20 + R * 8 + R * 16
+        hbm = {"compact_GBps": comp_bytes / (stage_ms["compact"] * 1e-3) / 1e9 if stage_ms["compact"] > 0 else None,
+               "composite_GBps": cmp_bytes / (stage_ms["composite"] * 1e-3) / 1e9 if stage_ms["composite"] > 0 else None,
+               "peak_GBps": 8000.0}
+
+        cpu = None
+        quality = {}
+        if not args.no_cpu_baseline and world == 1:
+            cpu, ref, (row0, rows) = cpu_baseline(sc, wts, w, h, pose, rot, args.cpu_budget)
+            mine = rgb.cpu().numpy()[row0 * w:(row0 + rows) * w]
+            cnt = r.buffer(3, np.int32, (r.info.rays_local,))[row0 * w:(row0 + rows) * w] if r.info.batch_rays >= r.info.rays_local else None
+            if cnt is not None:
+                same = cnt == ref["count"]
+                quality = {"psnr_vs_oracle_db": O.psnr(mine[same], ref["rgb"][same]),
+                           "max_abs_err_vs_oracle": float(np.abs(mine[same] - ref["rgb"][same]).max()),
+                           "rays_with_identical_sample_count": float(same.mean()), "rays_checked": int(same.size)}
+        rec = {"metric": "FPS at 800x800", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": args.precision, "data": data,
+               "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, 8x256 shading MLP %s, sampling MLP fp32" %
+                                      (args.workload, w, h, n_max, thr, args.precision),
+                          "parallelism": "image-strip shard x%d (8-row strips, round-robin) + RCCL gather" % world if world > 1 else "single GPU",
+                          "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame},
+               "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,
+               "sampling_mlp_tflops_fp32": smp_tflops, "hbm_stages": hbm, "quality": quality}
+        print(json.dumps(rec))
+    r.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,6 +144,17 @@ int adanerf_assemble_strips(adanerf_ctx* ctx, const void* d_gathered, void* d_im
 
 int adanerf_sync(adanerf_ctx* ctx);
 
+/* Makes the context enqueue on a caller-owned HIP stream (hipStream_t, e.g. PyTorch's current stream)
+ * instead of its own; NULL restores the context's stream.  The caller keeps the stream alive. */
+int adanerf_set_stream(adanerf_ctx* ctx, void* hip_stream);
+
+/* Asynchronous per-stage timing: with profiling on, every adanerf_render() records HIP events on the
+ * context's stream without synchronising; adanerf_collect_stats() synchronises once and returns the
+ * SUM over all frames rendered since the previous collect (stats->batches counts batches,
+ * shade_launches / sample_launches the kernel launches behind the summed durations). */
+int adanerf_set_profiling(adanerf_ctx* ctx, int32_t enabled);
+int adanerf_collect_stats(adanerf_ctx* ctx, adanerf_stats* stats, int32_t* frames);
+
 /* ---- stage-level entry points (mirror the reference launchers; used by the parity tests) ---- */
 
 /* Oracle-net input features [n_rays, n_in0] fp32 = [PE(dir/|dir|) | PE(p)] and the per-ray record
