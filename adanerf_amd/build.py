@@ -61,8 +61,8 @@ def build_cli(force=False, verbose=False):
     if not force and not _stale(out, deps):
         return out
     os.makedirs(BINDIR, exist_ok=True)
-    cmd = [_hipcc(), "-O2", "-std=c++17"] + srcs + ["-I", os.path.join(HERE, "..", "include"), "-L", LIBDIR,
-                                                     "-ladanerf_hip", "-Wl,-rpath,$ORIGIN/../lib", "-o", out]
+    cxx = shutil.which("g++") or shutil.which("c++") or _hipcc()     # pure host C++ over the C ABI
+    cmd = [cxx, "-O2", "-std=c++17"] + srcs + ["-L", LIBDIR, "-ladanerf_hip", "-Wl,-rpath,$ORIGIN/../lib", "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -1,0 +1,120 @@
+#include "neuralrenderer.h"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+NeuralRenderer::~NeuralRenderer() {
+  if (ctx) {
+    if (d_frame) adanerf_free(ctx, d_frame);
+    adanerf_destroy(ctx);
+  }
+}
+
+bool NeuralRenderer::init() {
+  std::cout << "Model Path: " << settings.model_path << std::endl;
+  adanerf_options opt;
+  std::memset(&opt, 0, sizeof(opt));
+  opt.width = static_cast<int32_t>(settings.width);
+  opt.height = static_cast<int32_t>(settings.height);
+  opt.batch_rays = static_cast<int32_t>(settings.batch_size);
+  opt.device_id = 0;
+  opt.precision = settings.precision == "fp32" ? ADANERF_PREC_FP32 : (settings.precision == "fp16" ? ADANERF_PREC_FP16 : ADANERF_PREC_BF16);
+  opt.num_samples = settings.num_samples;
+  opt.threshold = settings.threshold;
+  opt.shard_rank = 0;
+  opt.shard_world = 1;
+  opt.strip_rows = 8;
+  if (adanerf_create(settings.model_path.c_str(), &opt, &ctx) != ADANERF_OK) {
+    err = adanerf_last_error(nullptr);
+    return false;
+  }
+  adanerf_get_info(ctx, &info_);
+  if (adanerf_malloc(ctx, static_cast<size_t>(info_.rays_local) * 4, &d_frame) != ADANERF_OK) {
+    err = adanerf_last_error(ctx);
+    return false;
+  }
+  camera.setPosition(info_.view_cell_center);   // Camera::init: pos = view-cell centre (camera.cpp:49)
+  return true;
+}
+
+bool NeuralRenderer::render() {
+  float rot[9];
+  camera.getRotMatrix(rot);
+  if (adanerf_set_camera(ctx, camera.getPosition(), rot) != ADANERF_OK) {
+    err = adanerf_last_error(ctx);
+    return false;
+  }
+  adanerf_stats st;
+  if (adanerf_render(ctx, d_frame, nullptr, &st) != ADANERF_OK) {
+    err = adanerf_last_error(ctx);
+    return false;
+  }
+  s_inference1 += st.ms_sample_mlp;
+  s_inference2 += st.ms_shade_mlp;
+  s_fc2 += st.ms_compact;
+  s_rm += st.ms_composite;
+  s_total += st.ms_total;
+  s_num_total_samples += st.total_samples;
+  sample_count++;
+  if (sample_count % logging_interval == 0) {
+    // same fields as the reference's log line; fc1 (ray/oracle features) is fused into "Inference 1"
+    std::cout << "Inference 1:" << s_inference1 / logging_interval << ", 2:" << s_inference2 / logging_interval << " | fc1: 0"
+              << ", fc2: " << s_fc2 / logging_interval << ", rm: " << s_rm / logging_interval
+              << ", avg samples ppx: " << s_num_total_samples / static_cast<double>(logging_interval) / settings.total_size
+              << " (total: " << s_num_total_samples / logging_interval << ")"
+              << ", frames: " << sample_count << ", frame ms: " << s_total / logging_interval << std::endl;
+    s_inference1 = s_inference2 = s_fc2 = s_rm = s_total = 0;
+    s_num_total_samples = 0;
+  }
+  if (settings.write_images) return writeImageToFile();
+  return true;
+}
+
+bool NeuralRenderer::writeImageToFile() {
+  const int w = static_cast<int>(settings.width), h = static_cast<int>(settings.height);
+  std::vector<unsigned char> image(static_cast<size_t>(w) * h * 4);
+  if (adanerf_memcpy_d2h(ctx, image.data(), d_frame, image.size()) != ADANERF_OK) {
+    err = adanerf_last_error(ctx);
+    return false;
+  }
+  std::string path = settings.model_path;
+  if (!path.empty() && path.back() != '/') path += '/';
+  path += "out.bmp";
+  std::ofstream fout(path, std::ios::binary);
+  if (!fout) {
+    err = "cannot write " + path;
+    return false;
+  }
+  // 24-bit BMP, bottom-up rows, BGR, rows padded to 4 bytes
+  const int row_bytes = (w * 3 + 3) & ~3;
+  const uint32_t data_size = static_cast<uint32_t>(row_bytes) * h, off = 54, file_size = off + data_size;
+  unsigned char hdr[54] = {'B', 'M'};
+  auto put32 = [&](int at, uint32_t v) {
+    hdr[at] = v & 255;
+    hdr[at + 1] = (v >> 8) & 255;
+    hdr[at + 2] = (v >> 16) & 255;
+    hdr[at + 3] = (v >> 24) & 255;
+  };
+  put32(2, file_size);
+  put32(10, off);
+  put32(14, 40);
+  put32(18, static_cast<uint32_t>(w));
+  put32(22, static_cast<uint32_t>(h));
+  hdr[26] = 1;
+  hdr[28] = 24;
+  put32(34, data_size);
+  fout.write(reinterpret_cast<char*>(hdr), 54);
+  std::vector<unsigned char> row(row_bytes, 0);
+  for (int y = h - 1; y >= 0; --y) {
+    for (int x = 0; x < w; ++x) {
+      const unsigned char* px = &image[(static_cast<size_t>(y) * w + x) * 4];
+      row[3 * x + 0] = px[2];
+      row[3 * x + 1] = px[1];
+      row[3 * x + 2] = px[0];
+    }
+    fout.write(reinterpret_cast<char*>(row.data()), row_bytes);
+  }
+  return true;
+}

@@ -1,0 +1,34 @@
+// Headless NeuralRenderer: the viewer's init()/render() pair (include/neuralrenderer.h:53-55) over the
+// C ABI of libadanerf_hip.so.  Owns the device framebuffer the viewer's BufferManager would own.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/adanerf_hip.h"
+#include "camera.h"
+#include "settings.h"
+
+class NeuralRenderer {
+ public:
+  NeuralRenderer(Settings& settings, Camera& camera) : settings(settings), camera(camera) {}
+  ~NeuralRenderer();
+
+  bool init();
+  bool render();                     // one frame; logs every 100 frames like imagegenerator.cpp:379-393
+  bool writeImageToFile();           // out.bmp in the model directory (neuralrenderer.cpp:184-222)
+  const adanerf_info& info() const { return info_; }
+  const std::string& error() const { return err; }
+
+ private:
+  Settings& settings;
+  Camera& camera;
+  adanerf_ctx* ctx = nullptr;
+  adanerf_info info_{};
+  void* d_frame = nullptr;           // uchar4 [h*w]
+  std::string err;
+  // 100-frame running sums
+  int logging_interval = 100, sample_count = 0;
+  double s_inference1 = 0, s_inference2 = 0, s_fc2 = 0, s_rm = 0, s_total = 0;
+  long long s_num_total_samples = 0;
+};

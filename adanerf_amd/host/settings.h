@@ -1,0 +1,24 @@
+// Command-line settings of the headless `adanerf` host.  Same arguments and batch-size semantics as the
+// reference viewer (adanerf_real_time_viewer/src/main.cpp:19-50, src/settings.cpp:15-47).
+#pragma once
+#include <string>
+
+class Settings {
+ public:
+  std::string model_path = "sample/";
+  unsigned int width = 800, height = 800, total_size = 640000;
+  unsigned int window_width = 800, window_height = 800;   // accepted, unused (headless)
+  unsigned int batch_size = 640000;
+  bool write_images = false;
+  bool is_debug = false;        // -d: accepted, headless is always "debug" (no GL interop)
+  // headless extras (not in the reference)
+  int frames = 100;             // --frames: frames to render before exiting
+  std::string precision = "bf16";
+  float yaw = -80.f, pitch = 0.f;   // Camera::init defaults (camera.cpp:90-91)
+  int num_samples = 0;
+  float threshold = -1.f;
+
+  // returns false and fills err on a malformed command line
+  bool init(int argc, char** argv, std::string* err);
+  static const char* usage();
+};
