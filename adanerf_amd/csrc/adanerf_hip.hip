@@ -51,7 +51,11 @@ struct adanerf_ctx {
   int mult_mode = 1;   // 0 none, 1 alpha, 2 weights
   int fp0 = 10, fd0 = 4, fp1 = 10, fd1 = 4;
 
-  PackedDev net0;                 // sampling net, fp32 fragments
+  PackedDev net0;                 // sampling net, fp32 fragments (exact engine)
+  PackedDev net0_split;           // sampling net, fp16 hi/lo' fragment pairs (split-precision engine)
+  int sampling_mode = 0;          // 0: split-precision fp16x3 (default), 1: exact fp32 MFMA
+  DevBuf overflow;                // int32 counter: rays whose oracle values came out non-finite
+  int sample_grid = 0;
   PackedDev net1[3];              // shading net per precision (packed lazily)
   TensorMap net1_host;
   DevBuf ztab;
@@ -123,7 +127,9 @@ struct ModelSetup {
   std::vector<float> ztab;
 };
 
-Elem elem_of(int prec) { return prec == ADANERF_PREC_BF16 ? Elem::BF16 : (prec == ADANERF_PREC_FP16 ? Elem::F16 : Elem::F32); }
+Elem elem_of(int prec) {
+  return prec == ADANERF_PREC_BF16 ? Elem::BF16 : (prec == ADANERF_PREC_FP16 ? Elem::F16 : (prec == 3 ? Elem::F16_SPLIT : Elem::F32));
+}
 
 // rows of the image owned by `rank` under round-robin strips
 int rows_of_rank(int h, int strip_rows, int world, int rank) {
@@ -182,6 +188,7 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   if (thr == 0.f && n_max != kBins) return bad(ADANERF_EUNSUPPORTED, "adaptiveSamplingThreshold == 0 (dense) requires numRaymarchSamples == 128");
   if (n_max < 1 || n_max > kBins) return bad(ADANERF_EINVAL, "numRaymarchSamples must be in 1..128");
   if (opt->precision < 0 || opt->precision > 2) return bad(ADANERF_EINVAL, "precision must be ADANERF_PREC_{BF16,FP16,FP32}");
+  if (opt->sampling_mode < 0 || opt->sampling_mode > 1) return bad(ADANERF_EINVAL, "sampling_mode must be ADANERF_SAMPLING_{SPLIT_FP16,FP32}");
 
   // ---- info / ray generation constants (A1: src/util/raygeneration.py:10-26, float64) ----
   const int w = opt->width, h = opt->height;
@@ -312,18 +319,41 @@ int ensure_batch_buffers(adanerf_ctx* c, int n_rays, int n_max) {
 
 // ---- launches ------------------------------------------------------------------------------
 
+template <typename K>
+int occupancy_grid(adanerf_ctx* c, K kernel, int threads, int* out) {
+  int per_cu = 0;
+  HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0));
+  if (per_cu < 1) per_cu = 1;
+  *out = per_cu * c->info.compute_units;
+  return ADANERF_OK;
+}
+
 int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle, float* d_rays) {
   if (n_rays <= 0) return ADANERF_OK;
   SampleArgs a{};
   a.g = c->rg;
   a.net = c->net0.params;
+  a.net16 = c->net0_split.params;
+  a.overflow_flag = reinterpret_cast<int32_t*>(c->overflow.p);
   a.first_ray = first_ray;
   a.n_rays = n_rays;
   a.oracle_out = d_oracle;
   a.rays_out = d_rays;
   dim3 grid((n_rays + 127) / 128), block(256);
-  if (c->fp0 == 10 && c->fd0 == 4) hipLaunchKernelGGL((sample_mlp_kernel<10, 4>), grid, block, 0, c->stream, a);
-  else hipLaunchKernelGGL((sample_mlp_kernel<2, 2>), grid, block, 0, c->stream, a);
+  const bool full = c->fp0 == 10 && c->fd0 == 4;
+  if (c->sampling_mode == 1) {
+    if (full) hipLaunchKernelGGL((sample_mlp_kernel<10, 4>), grid, block, 0, c->stream, a);
+    else hipLaunchKernelGGL((sample_mlp_kernel<2, 2>), grid, block, 0, c->stream, a);
+  } else {
+    if (!c->sample_grid) {
+      int rc = full ? occupancy_grid(c, sample_mlp16x3_kernel<10, 4>, 256, &c->sample_grid)
+                    : occupancy_grid(c, sample_mlp16x3_kernel<2, 2>, 256, &c->sample_grid);
+      if (rc) return rc;
+    }
+    grid.x = std::min<unsigned>(grid.x, static_cast<unsigned>(c->sample_grid));
+    if (full) hipLaunchKernelGGL((sample_mlp16x3_kernel<10, 4>), grid, block, 0, c->stream, a);
+    else hipLaunchKernelGGL((sample_mlp16x3_kernel<2, 2>), grid, block, 0, c->stream, a);
+  }
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;
 }
@@ -348,15 +378,6 @@ int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max,
                      reinterpret_cast<const uint8_t*>(c->selbin.p), reinterpret_cast<const float*>(c->selw.p),
                      reinterpret_cast<const int32_t*>(c->block_offset.p), n_rays, n_max, d_off, d_key, d_w);
   HIP_TRY(c, hipGetLastError());
-  return ADANERF_OK;
-}
-
-template <typename K>
-int occupancy_grid(adanerf_ctx* c, K kernel, int threads, int* out) {
-  int per_cu = 0;
-  HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0));
-  if (per_cu < 1) per_cu = 1;
-  *out = per_cu * c->info.compute_units;
   return ADANERF_OK;
 }
 
@@ -448,6 +469,9 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1};
   PackedNet p0, p1;
   if (!pack_sampling_net(n0, sh, Elem::F32, &p0, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
+  PackedNet p0s;
+  if (!pack_sampling_net(n0, sh, Elem::F16_SPLIT, &p0s, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
+  c->sampling_mode = opt->sampling_mode;
   if (!pack_shading_net(c->net1_host, sh, elem_of(opt->precision), &p1, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
 
   // ---- device ----
@@ -469,6 +493,9 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     return bail(ADANERF_EDEVICE, "ztab upload failed");
   c->sp.ztab = reinterpret_cast<const float*>(c->ztab.p);
   if ((rc = upload_net(c, p0, &c->net0))) return bail(rc, c->err);
+  if ((rc = upload_net(c, p0s, &c->net0_split))) return bail(rc, c->err);
+  if ((rc = dev_alloc(c, &c->overflow, 64))) return bail(rc, c->err);
+  if (hipMemset(c->overflow.p, 0, 64) != hipSuccess) return bail(ADANERF_EDEVICE, "hipMemset failed");
   if ((rc = upload_net(c, p1, &c->net1[opt->precision]))) return bail(rc, c->err);
   if ((rc = ensure_batch_buffers(c, c->info.batch_rays, c->info.num_samples))) return bail(rc, c->err);
   *out = c;
@@ -498,7 +525,8 @@ int adanerf_host_depth_table(const char* model_dir, const adanerf_options* opt, 
 int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precision, void* weights_out, size_t* weights_bytes,
                               float* bias_out, size_t* bias_floats, int32_t* layer_out, int32_t* n_layers) {
   if (!model_dir || !weights_bytes || !bias_floats || !n_layers) return fail(nullptr, ADANERF_EINVAL, "NULL argument");
-  if (net < 0 || net > 1 || precision < 0 || precision > 2) return fail(nullptr, ADANERF_EINVAL, "net/precision out of range");
+  if (net < 0 || net > 1 || precision < 0 || precision > 3 || (precision == 3 && net != 0))
+    return fail(nullptr, ADANERF_EINVAL, "net/precision out of range");
   Config cfg;
   std::string err;
   if (!cfg.load(model_dir, &err)) return fail(nullptr, ADANERF_EIO, err);
@@ -538,7 +566,7 @@ int adanerf_destroy(adanerf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
   for (int32_t* p : c->pinned_totals) (void)hipHostFree(p);
-  DevBuf* bufs[] = {&c->net0.w, &c->net0.b, &c->net1[0].w, &c->net1[0].b, &c->net1[1].w, &c->net1[1].b, &c->net1[2].w, &c->net1[2].b,
+  DevBuf* bufs[] = {&c->net0_split.w, &c->net0_split.b, &c->overflow, &c->net0.w, &c->net0.b, &c->net1[0].w, &c->net1[0].b, &c->net1[1].w, &c->net1[1].b, &c->net1[2].w, &c->net1[2].b,
                     &c->ztab, &c->rays, &c->oracle, &c->ray_offsets, &c->ray_counts, &c->selbin, &c->selw, &c->block_total,
                     &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw};
   for (DevBuf* b : bufs) dev_free(b);
@@ -646,6 +674,9 @@ int sum_stats(adanerf_ctx* c, adanerf_stats* stats) {
     stats->ms_total += t;
     stats->total_samples += *c->pinned_totals[b];
   }
+  int32_t ovf = 0;
+  HIP_TRY(c, hipMemcpy(&ovf, c->overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+  stats->sampling_overflow = ovf;
   stats->batches = static_cast<int32_t>(nb);
   stats->shade_launches = static_cast<int32_t>(nb);
   stats->sample_launches = static_cast<int32_t>(nb);

@@ -40,6 +40,27 @@ uint16_t f32_to_f16(float f) {
   return static_cast<uint16_t>(sign | half);
 }
 
+float f16_to_f32(uint16_t h) {
+  uint32_t sign = static_cast<uint32_t>(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1Fu, mant = h & 0x3FFu;
+  uint32_t u;
+  if (exp == 0) {
+    if (mant == 0) u = sign;
+    else {   // subnormal: normalise
+      int e = -1;
+      do {
+        mant <<= 1;
+        e++;
+      } while (!(mant & 0x400u));
+      u = sign | static_cast<uint32_t>(127 - 15 - e) << 23 | ((mant & 0x3FFu) << 13);
+    }
+  } else if (exp == 31) u = sign | 0x7F800000u | (mant << 13);
+  else u = sign | (exp + 127 - 15) << 23 | (mant << 13);
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
 namespace {
 
 // dense "virtual" layer: rows padded to 32, arbitrary source columns
@@ -102,12 +123,13 @@ void emit(const VLayer& L, Elem elem, PackedNet* out) {
   const int QS = static_cast<int>(L.col_h0.size());
   const int steps = QS / G;
   const int MT = L.rows / 32;
+  const int parts = (elem == Elem::F16_SPLIT) ? 2 : 1;
   out->w_off.push_back(static_cast<uint32_t>(out->weights.size() / 16));
   out->b_off.push_back(static_cast<uint32_t>(out->bias.size()));
   out->slots.push_back(QS);
   out->mtiles.push_back(MT);
   size_t base = out->weights.size();
-  out->weights.resize(base + static_cast<size_t>(MT) * steps * 64 * 16);
+  out->weights.resize(base + static_cast<size_t>(MT) * steps * parts * 64 * 16);
   uint8_t* dst = out->weights.data() + base;
   for (int m = 0; m < MT; ++m)
     for (int s = 0; s < steps; ++s)
@@ -118,9 +140,15 @@ void emit(const VLayer& L, Elem elem, PackedNet* out) {
           int q = G * s + e;
           int col = h ? L.col_h1[q] : L.col_h0[q];
           float v = (col >= 0) ? L.w[static_cast<size_t>(row) * L.cols + col] : 0.f;
-          size_t frag = (static_cast<size_t>(m) * steps + s) * 64 + lane;
+          size_t frag = (static_cast<size_t>(m) * steps + s) * parts * 64 + lane;
           if (elem == Elem::F32) {
             std::memcpy(dst + frag * 16 + 4 * e, &v, 4);
+          } else if (elem == Elem::F16_SPLIT) {
+            uint16_t hi = f32_to_f16(v);
+            float lo = (v - f16_to_f32(hi)) * kSplitScale;
+            uint16_t lv = f32_to_f16(lo);
+            std::memcpy(dst + frag * 16 + 2 * e, &hi, 2);
+            std::memcpy(dst + (frag + 64) * 16 + 2 * e, &lv, 2);
           } else {
             uint16_t hv = (elem == Elem::BF16) ? f32_to_bf16(v) : f32_to_f16(v);
             std::memcpy(dst + frag * 16 + 2 * e, &hv, 2);

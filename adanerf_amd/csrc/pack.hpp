@@ -8,11 +8,15 @@
 
 namespace adanerf {
 
-enum class Elem { F32, BF16, F16 };
+// F16_SPLIT: every fragment is emitted twice, back to back: hi = fp16(w) and lo' = fp16((w - hi) * 2^11)
+// (the split-precision path of the sampling net: w ~= hi + lo' * 2^-11 to 22 bits)
+enum class Elem { F32, BF16, F16, F16_SPLIT };
+constexpr float kSplitScale = 2048.0f;
 
 // One packed network: every layer's A fragments back to back plus the per-tile bias blocks.
 //   fp32 engine   : float  w[layer][m][s4][lane][4]   (slot q = 4 s4 + e)
 //   16-bit engine : uint16 w[layer][m][s ][lane][8]   (slot q = 8 s  + e)
+//   split engine  : uint16 w[layer][m][s ][part][lane][8], part 0 = hi, 1 = lo' 
 //   bias          : float  b[layer][m][h][16]         (feature 32m + 8(r>>2) + 4h + (r&3))
 struct PackedNet {
   Elem elem = Elem::F32;
@@ -38,5 +42,6 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& shape, Elem elem, P
 
 uint16_t f32_to_bf16(float f);
 uint16_t f32_to_f16(float f);
+float f16_to_f32(uint16_t h);
 
 }  // namespace adanerf

@@ -32,7 +32,7 @@ class _Options(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("batch_rays", C.c_int32), ("device_id", C.c_int32),
                 ("precision", C.c_int32), ("num_samples", C.c_int32), ("threshold", C.c_float),
                 ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("strip_rows", C.c_int32),
-                ("reserved", C.c_int32 * 6)]
+                ("sampling_mode", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class Info(C.Structure):
@@ -48,7 +48,7 @@ class Stats(C.Structure):
     _fields_ = [("total_samples", C.c_int64), ("rays", C.c_int32), ("batches", C.c_int32), ("ms_total", C.c_float),
                 ("ms_sample_mlp", C.c_float), ("ms_compact", C.c_float), ("ms_shade_mlp", C.c_float),
                 ("ms_composite", C.c_float), ("shade_launches", C.c_int32), ("sample_launches", C.c_int32),
-                ("reserved", C.c_int32 * 6)]
+                ("sampling_overflow", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_last_error", "adanerf_set_camera",
@@ -172,14 +172,15 @@ class NeuralRenderer:
 
     def __init__(self, settings: Settings, precision="bf16", device_id: int = 0, num_samples: int = 0,
                  threshold: float = -1.0, shard_rank: int = 0, shard_world: int = 1, strip_rows: int = 8,
-                 lib_path: Optional[str] = None):
+                 sampling: str = "split", lib_path: Optional[str] = None):
         self.settings = settings
         self.lib = load_library(lib_path)
         self.handle = None
         self._opt = _Options(width=settings.width, height=settings.height, batch_rays=settings.resolved_batch(),
                              device_id=device_id, precision=_PREC[precision] if isinstance(precision, str) else int(precision),
                              num_samples=num_samples, threshold=threshold, shard_rank=shard_rank,
-                             shard_world=shard_world, strip_rows=strip_rows)
+                             shard_world=shard_world, strip_rows=strip_rows,
+                             sampling_mode={"split": 0, "fp16x3": 0, "fp32": 1}[sampling])
         self.info = Info()
         self.last_stats = Stats()
         self._own = []

@@ -57,7 +57,14 @@ enum {
   ADANERF_EUNSUPPORTED = -4 /* config outside the supported north-star path */
 };
 
-/* arithmetic of the shading MLP's MFMA path (the sampling MLP is always exact fp32 MFMA) */
+/* arithmetic of the sampling MLP (its outputs drive the bit-exact sample selection) */
+enum {
+  ADANERF_SAMPLING_SPLIT_FP16 = 0, /* default: x = hi + 2^-11 lo' (two fp16), 3 x v_mfma_f32_32x32x16_f16 per term,
+                                      fp32 accumulate; 22-bit operands, measured error <= fp32 sgemm's */
+  ADANERF_SAMPLING_FP32 = 1        /* v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain */
+};
+
+/* arithmetic of the shading MLP's MFMA path */
 enum {
   ADANERF_PREC_BF16 = 0,  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate */
   ADANERF_PREC_FP16 = 1,  /* v_mfma_f32_32x32x16_f16,  fp32 accumulate */
@@ -77,7 +84,8 @@ typedef struct adanerf_options {
   int32_t shard_rank;       /* image-strip shard of this context (multi-GPU); 0 */
   int32_t shard_world;      /* number of shards; 1 */
   int32_t strip_rows;       /* rows per strip for round-robin strip sharding; <=0 -> 8 */
-  int32_t reserved[6];
+  int32_t sampling_mode;    /* ADANERF_SAMPLING_* */
+  int32_t reserved[5];
 } adanerf_options;
 
 typedef struct adanerf_info {
@@ -113,7 +121,9 @@ typedef struct adanerf_stats {
   float   ms_composite;       /* compositing                          ("rm") */
   int32_t shade_launches;     /* kernel launches behind ms_shade_mlp  */
   int32_t sample_launches;    /* kernel launches behind ms_sample_mlp */
-  int32_t reserved[6];
+  int32_t sampling_overflow;  /* rays (since create) whose oracle values were non-finite: an activation left the
+                                 fp16 range of the split-precision engine -> use ADANERF_SAMPLING_FP32 */
+  int32_t reserved[5];
 } adanerf_stats;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
@@ -223,7 +233,7 @@ int adanerf_get_buffer(adanerf_ctx* ctx, int32_t which, void** d_out, size_t* by
 int adanerf_host_parse_model(const char* model_dir, const adanerf_options* opt, adanerf_info* info);
 
 /* Packs net 0 (sampling) or net 1 (shading) of model_dir into MFMA A-fragment order for
- * `precision` (ADANERF_PREC_*).  Two-call pattern: pass NULL outputs to query sizes.
+ * `precision` (ADANERF_PREC_*, or 3 = the sampling net's fp16 hi/lo' split pairs).  Two-call pattern: pass NULL outputs to query sizes.
  *   weights_out  packed 16-byte fragments        (*weights_bytes)
  *   bias_out     packed bias blocks, fp32        (*bias_floats)
  *   layer_out    per layer {w_off (16-B units), b_off (floats), slots per lane-half, 32-row tiles}

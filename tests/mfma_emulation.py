@@ -63,13 +63,45 @@ def pe_eval(x, F):
     return out
 
 
+def f16(x):
+    return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
 class PackedNet:
     def __init__(self, w, b, lay, precision):
         self.w, self.b, self.lay, self.precision = w, b, lay, precision
         self.G = 4 if precision == 2 else 8
 
+    def layer_split(self, l, act, relu):
+        """precision 3: (hi, lo') fragment pairs; W.x = Whi.xhi + (Whi.xlo' + Wlo'.xhi) / 2048"""
+        w_off, b_off, QS, MT = [int(v) for v in self.lay[l]]
+        steps = QS // 8
+        frag = self.w[w_off * 16:(w_off + MT * steps * 2 * 64) * 16].view(np.float16).astype(np.float32)
+        frag = frag.reshape(MT, steps, 2, 64, 8)
+        a_hi = f16(act)
+        a_lo = f16((act - a_hi) * np.float32(2048.0))
+        n = act.shape[2]
+        out = np.zeros((2, 16 * MT, n), dtype=np.float32)
+        bias = self.b[b_off:b_off + MT * 32].reshape(MT, 2, 16)
+        for m in range(MT):
+            main = np.zeros((32, n), dtype=np.float32)
+            cross = np.zeros((32, n), dtype=np.float32)
+            for h in range(2):
+                Whi = frag[m, :, 0, h * 32:(h + 1) * 32, :].transpose(1, 0, 2).reshape(32, QS)
+                Wlo = frag[m, :, 1, h * 32:(h + 1) * 32, :].transpose(1, 0, 2).reshape(32, QS)
+                main += Whi @ a_hi[h]
+                cross += Whi @ a_lo[h] + Wlo @ a_hi[h]
+            D = main + cross / np.float32(2048.0)
+            for hh in range(2):
+                for r in range(16):
+                    row = (r & 3) + 8 * (r >> 2) + 4 * hh
+                    out[hh, 16 * m + r] = D[row] + bias[m, hh, r]
+        return np.maximum(out, 0) if relu else out
+
     def layer(self, l, act, relu):
         """act [2, QS, n] -> next slots [2, 16*MT, n]"""
+        if self.precision == 3:
+            return self.layer_split(l, act, relu)
         w_off, b_off, QS, MT = [int(v) for v in self.lay[l]]
         G = self.G
         steps = QS // G

@@ -174,13 +174,15 @@ def test_packed_sampling_net_reproduces_oracle(lib, tmp_path):
         z, meta, sc = load_case(name)
         wts = case_weights(meta)
         d, _, _ = _model_dir(tmp_path, sc, wts, name=name)
-        w, b, lay = pack_weights(lib, d, 0, 2)
         fp, fd = sc.pos_enc[0]
         n = 64
         nds = z["nds"][:n]
         u = (nds / np.sqrt(np.sum(nds * nds, -1, keepdims=True))).astype(np.float32)
-        orc = run_sampling_net(PackedNet(w, b, lay, 2), u, z["p"][:n], fp, fd)
-        np.testing.assert_allclose(orc, z["oracle_out"][:n], rtol=0, atol=5e-5)
+        for precision in (2, 3):     # exact fp32 fragments, and the fp16 hi/lo' split pairs
+            w, b, lay = pack_weights(lib, d, 0, precision)
+            assert w.size == sum(int(l[2]) // (4 if precision == 2 else 8) * int(l[3]) for l in lay) * 1024 * (2 if precision == 3 else 1)
+            orc = run_sampling_net(PackedNet(w, b, lay, precision), u, z["p"][:n], fp, fd)
+            np.testing.assert_allclose(orc, z["oracle_out"][:n], rtol=0, atol=5e-5)
 
 
 def test_product_path_fails_loudly_without_gpu(lib, tmp_path):
