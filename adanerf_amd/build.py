@@ -39,6 +39,8 @@ def build_library(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -shared -> adanerf_amd/lib/libadanerf_hip.so (cross-compiles without a GPU)."""
     out = library_path()
     deps = [os.path.join(CSRC, d) for d in LIB_DEPS]
+    if os.environ.get("ADANERF_LIB"):
+        return os.environ["ADANERF_LIB"]      # pre-built variant selected by the caller
     if not force and not _stale(out, deps):
         return out
     os.makedirs(LIBDIR, exist_ok=True)

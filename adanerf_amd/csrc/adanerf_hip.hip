@@ -381,7 +381,10 @@ int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max,
   return ADANERF_OK;
 }
 
-constexpr int kShadeWaves = 8;
+#ifndef ADN_SHADE_WAVES
+#define ADN_SHADE_WAVES 8   // 8: one 8-wave workgroup per CU (measured best); 4: two independent 4-wave workgroups
+#endif
+constexpr int kShadeWaves = ADN_SHADE_WAVES;
 
 int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, const int32_t* d_total, int max_samples, int prec,
                      float* d_raw) {
@@ -405,12 +408,12 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
     const int tile = kShadeWaves * 32;
     const int tiles = (max_samples + tile - 1) / tile;
     if (prec == ADANERF_PREC_BF16) {
-      if (!c->shade_grid[0] && (rc = occupancy_grid(c, shade_mlp16_kernel<Bf16, 10, 4>, kShadeWaves * 64, &c->shade_grid[0]))) return rc;
-      hipLaunchKernelGGL((shade_mlp16_kernel<Bf16, 10, 4>), dim3(std::min(tiles, c->shade_grid[0])), dim3(kShadeWaves * 64), 0,
+      if (!c->shade_grid[0] && (rc = occupancy_grid(c, shade_mlp16_kernel<Bf16, 10, 4, kShadeWaves>, kShadeWaves * 64, &c->shade_grid[0]))) return rc;
+      hipLaunchKernelGGL((shade_mlp16_kernel<Bf16, 10, 4, kShadeWaves>), dim3(std::min(tiles, c->shade_grid[0])), dim3(kShadeWaves * 64), 0,
                          c->stream, a);
     } else {
-      if (!c->shade_grid[1] && (rc = occupancy_grid(c, shade_mlp16_kernel<Fp16, 10, 4>, kShadeWaves * 64, &c->shade_grid[1]))) return rc;
-      hipLaunchKernelGGL((shade_mlp16_kernel<Fp16, 10, 4>), dim3(std::min(tiles, c->shade_grid[1])), dim3(kShadeWaves * 64), 0,
+      if (!c->shade_grid[1] && (rc = occupancy_grid(c, shade_mlp16_kernel<Fp16, 10, 4, kShadeWaves>, kShadeWaves * 64, &c->shade_grid[1]))) return rc;
+      hipLaunchKernelGGL((shade_mlp16_kernel<Fp16, 10, 4, kShadeWaves>), dim3(std::min(tiles, c->shade_grid[1])), dim3(kShadeWaves * 64), 0,
                          c->stream, a);
     }
   }

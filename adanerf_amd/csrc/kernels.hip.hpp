@@ -23,6 +23,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kMaxLayers = 12;
 
@@ -531,69 +532,114 @@ struct Fp16 {
 // across the barrier (never vmcnt(0) in the loop).  Each wave keeps the current chunk's 8
 // fragments in registers and re-fills fragment i from the NEXT chunk right after the MFMA that
 // consumed it, so LDS latency hides behind the other 7 MFMAs.
-constexpr int kChunkFrags = 8;
-constexpr int kChunkBytes = kChunkFrags * 1024;
-constexpr int kRingSlots = 4;
-constexpr int kRingBytes = kRingSlots * kChunkBytes;
+// Timing-ablation switches for tools/ablate.sh (results become WRONG; never defined in the shipped build):
+//   1: no chunk boundary (no wait, no barrier, no DMA)   2: no LDS re-fill of the fragment registers
+//   4: no bias read (acc starts at 0)                    8: no ReLU/convert epilogue
+//  16: boundary without the DMA issue                   32: boundary without wait + barrier
+// ADN_ABLATE applies to shade_mlp16_kernel, ADN_ABLATE_S to sample_mlp16x3_kernel.
+#ifndef ADN_ABLATE
+#define ADN_ABLATE 0
+#endif
+#ifndef ADN_ABLATE_S
+#define ADN_ABLATE_S 0
+#endif
+// Ring geometry.  CF = fragments (KiB) per chunk = MFMAs per wave between barriers; RS = ring slots.
+// At boundary k a wave waits for its own pieces of chunk k+1, so RS-3 further chunks stay in flight.
+#ifndef ADN_CF
+#define ADN_CF 16
+#endif
+#ifndef ADN_RS
+#define ADN_RS 4
+#endif
+#ifndef ADN_CF_S
+#define ADN_CF_S 16
+#endif
+#ifndef ADN_RS_S
+#define ADN_RS_S 6
+#endif
+constexpr int kRegFrags = 4;     // fragments held in registers per wave (re-fill distance in MFMAs)
 constexpr int kShadeFrags16 = 32 + 4 * 128 + 160 + 2 * 128 + 144 + 72 + 8;   // 1184 per pass (FP=10, FD=4)
 constexpr int kShadeBiasFloats = 8 * 256 + 288 + 128 + 32;                     // 2496
-static_assert(kShadeFrags16 % (kChunkFrags * kRingSlots) == 0, "ring slot pattern must repeat per pass");
 
+// CF / RS / LPW (fragments each wave DMA-copies per chunk = CF / waves) are compile-time; the slot a
+// chunk lives in is a run-time counter, so any tile length that is a multiple of CF works.
+template <int CF, int RS, int LPW>
 struct WStream {
+  static constexpr int kChunkBytes = CF * 1024;
   const char* gbase;     // stream start (global)
   uint32_t gbytes;       // stream length in bytes (multiple of kChunkBytes)
   uint32_t goff;         // byte offset of the next chunk to issue
   uint32_t lane_off;     // lane * 16
   uint32_t wave_off;     // byte offset of this wave's first fragment inside a chunk
-  char* lds;             // ring base (LDS)
-  u32x4 R[kChunkFrags];  // current chunk's fragments
+  uint32_t slot_cur;     // ring slot of the chunk being consumed (wave-uniform)
+  uint32_t rd_cur;       // LDS byte address of (current chunk, this lane)
+  uint32_t rd_next;      // LDS byte address of (next chunk, this lane)
+  uint32_t lds_base;     // LDS byte address of the ring
+  u32x4 R[kRegFrags];    // register ring: fragment p (position inside the chunk) lives in R[p % kRegFrags]
 };
 
-// LPW = fragments each wave DMA-copies per chunk (kChunkFrags / waves per workgroup)
-template <int LPW>
-__device__ __forceinline__ void ws_issue(WStream& st, int slot) {
+__device__ __forceinline__ u32x4 lds_read128(uint32_t byte_addr) {
+  typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
+  return *((lds_u32x4_ptr)(uintptr_t)byte_addr);
+}
+
+template <int CF, int RS, int LPW>
+__device__ __forceinline__ void ws_issue(WStream<CF, RS, LPW>& st, uint32_t slot) {
 #pragma unroll
   for (int i = 0; i < LPW; ++i) {
     const char* src = st.gbase + st.goff + st.wave_off + i * 1024 + st.lane_off;
+    const uint32_t dst = st.lds_base + slot * (CF * 1024) + st.wave_off + i * 1024;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(st.lds + slot * kChunkBytes + st.wave_off + i * 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)static_cast<uintptr_t>(dst), 16, 0, 0);
   }
-  st.goff += kChunkBytes;
+  st.goff += CF * 1024;
   if (st.goff >= st.gbytes) st.goff = 0;
 }
 
-__device__ __forceinline__ u32x4 ws_read(const WStream& st, int slot, int frag) {
-  return *reinterpret_cast<const u32x4*>(st.lds + slot * kChunkBytes + frag * 1024 + st.lane_off);
-}
-
-// chunk boundary k: own pieces of chunk k+1 have landed (<= LPW younger DMAs outstanding); barrier =>
+// chunk boundary k: own pieces of chunk k+1 have landed (<= (RS-3) LPW younger DMAs outstanding); barrier =>
 // chunk k+1 complete in LDS for every wave and every wave has consumed chunk k-1 (its MFMAs were
-// issued before the barrier, so its ds_reads returned) => refill the slot of chunk k-1 with chunk k+3.
-template <int LPW>
-__device__ __forceinline__ void ws_boundary(WStream& st, int slot_prev) {
-  static_assert(LPW == 1 || LPW == 2, "waitcnt immediates below");
-  if (LPW == 1) asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-  ws_issue<LPW>(st, slot_prev);
+// issued before the barrier, so its ds_reads returned) => refill the slot of chunk k-1 with chunk k+RS-1.
+template <int ABL, int CF, int RS, int LPW>
+__device__ __forceinline__ void ws_boundary(WStream<CF, RS, LPW>& st) {
+  static_assert(RS >= 3 && (RS - 2) * LPW < 64, "vmcnt is a 6-bit counter");
+  if (ABL & 1) return;
+  if (!(ABL & 32)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 3) * LPW) : "memory");   // 32: no wait/barrier
+  const uint32_t old = st.slot_cur;
+  st.slot_cur = (old + 1 == RS) ? 0 : old + 1;
+  const uint32_t nxt = (st.slot_cur + 1 == RS) ? 0 : st.slot_cur + 1;
+  if (!(ABL & 16)) ws_issue(st, old);                                                                       // 16: no DMA
+  st.rd_cur = st.rd_next;
+  st.rd_next = st.lds_base + nxt * (CF * 1024) + st.lane_off;
 }
 
-template <int LPW>
-__device__ __forceinline__ void ws_prologue(WStream& st) {
-#pragma unroll
-  for (int k = 0; k < kRingSlots - 1; ++k) ws_issue<LPW>(st, k);
-  if (LPW == 1) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-#pragma unroll
-  for (int i = 0; i < kChunkFrags; ++i) st.R[i] = ws_read(st, 0, i);
+// fragment position p inside the current chunk has just been consumed: re-fill its register with fragment
+// p + kRegFrags (same chunk, or the next chunk -- already landed: see ws_boundary)
+template <int ABL, int CF, int RS, int LPW>
+__device__ __forceinline__ void ws_refill(WStream<CF, RS, LPW>& st, int p) {
+  if (ABL & 2) {
+    asm volatile("" : "+v"(st.R[p % kRegFrags]));
+    return;
+  }
+  const int q = p + kRegFrags;
+  st.R[p % kRegFrags] = (q < CF) ? lds_read128(st.rd_cur + q * 1024) : lds_read128(st.rd_next + (q - CF) * 1024);
 }
 
-__device__ __forceinline__ void ws_init(WStream& st, const void* gbase, uint32_t gbytes, char* lds, int wave, int lane, int lpw) {
+template <int CF, int RS, int LPW>
+__device__ __forceinline__ void ws_start(WStream<CF, RS, LPW>& st, const void* gbase, uint32_t gbytes, char* lds, int wave, int lane) {
   st.gbase = reinterpret_cast<const char*>(gbase);
   st.gbytes = gbytes;
   st.goff = 0;
   st.lane_off = lane * 16;
-  st.wave_off = wave * lpw * 1024;
-  st.lds = lds;
+  st.wave_off = wave * LPW * 1024;
+  st.lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds));
+#pragma unroll
+  for (int k = 0; k < RS - 1; ++k) ws_issue(st, k);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 2) * LPW) : "memory");
+  st.slot_cur = RS - 1;                       // the first boundary moves to slot 0 = chunk 0
+  st.rd_cur = st.lds_base + st.lane_off;      // unused until then
+  st.rd_next = st.lds_base + st.lane_off;     // chunk 0
+#pragma unroll
+  for (int i = 0; i < kRegFrags; ++i) st.R[i] = lds_read128(st.rd_next + i * 1024);
 }
 
 // ReLU on the raw bits: max(int(x), 0) is +0.0 for every negative float and the identity for positive
@@ -612,51 +658,74 @@ __device__ __forceinline__ void pe_pack(const float x[3], int h, uint32_t* out) 
   for (int q = 0; q < pe_slots(F) / 2; ++q) out[q] = ET::pack(t[2 * q], t[2 * q + 1]);
 }
 
+// Bias block [m][h][16] for this lane-half from LDS with hand-issued reads: hipcc cannot see an asm
+// ds_read, so it neither assumes aliasing with the LDS-DMA ring (which costs an s_waitcnt vmcnt(0) drain
+// per tile) nor needs the 3-VALU-per-value SGPR select that scalar loads cost.  The wait statement names
+// every destination "+v" so no consumer is scheduled above it (cdna_hip_programming.md 5.7 form ii).
+__device__ __forceinline__ void lds_bias16(uint32_t byte_addr, f32x16* acc) {
+  f32x4 b0, b1, b2, b3;
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+               : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+               : "v"(byte_addr));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+  f32x16 a;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = b0[e];
+    a[4 + e] = b1[e];
+    a[8 + e] = b2[e];
+    a[12 + e] = b3[e];
+  }
+  *acc = a;
+}
+
 // One 16-bit layer for one 32-sample column block.  Input = two register segments (S1 then S2
 // k-steps of 8 slots = 4 packed dwords each); output tile m lands in out[8m .. 8m+7] (packed pairs).
-// FPOS = position of the layer's first fragment in the stream modulo 32 (4 chunks).
+// FPOS = position of the layer's first fragment in the stream modulo the chunk size.
 // KEEP_F32_TILE >= 0: that tile's raw accumulator is returned in *keep instead (alpha / rgb rows).
-template <class ET, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
-__device__ __forceinline__ void layer_16(WStream& st, const float* __restrict__ bias, int lane, const uint32_t* in1, const uint32_t* in2,
+template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
+__device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, const uint32_t* in1, const uint32_t* in2,
                                          uint32_t* out, f32x16* keep = nullptr) {
+  constexpr int CF = ADN_CF;
   constexpr int KS = S1 + S2;
-  const bool hi = lane >= 32;
+  // bias_addr: LDS byte address of this layer's bias block for THIS lane-half ([m][h][16] floats)
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    // bias block [m][h][16]: wave-uniform addresses -> scalar loads (lgkmcnt, never vmcnt: an
-    // ordinary vector load here would make hipcc drain the LDS-DMA queue with vmcnt(0))
-    // The constant address space lets the backend pick s_load for these wave-uniform reads.
     f32x16 acc;
-    const __attribute__((address_space(4))) float* cb = (const __attribute__((address_space(4))) float*)(bias + m * 32);
+    if (ADN_ABLATE & 4) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float b0 = cb[r], b1 = cb[16 + r];
-      acc[r] = hi ? b1 : b0;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    } else {
+      lds_bias16(bias_addr + m * 128, &acc);
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const int p = FPOS + m * KS + s;            // compile-time after unrolling
-      const int chunk = p / kChunkFrags, f = p % kChunkFrags;
-      if (f == 0) ws_boundary<1>(st, (chunk + kRingSlots - 1) % kRingSlots);
+      const int f = (FPOS + m * KS + s) % CF;     // position inside the chunk; compile-time after unrolling
+      if (f == 0) ws_boundary<ADN_ABLATE>(st);
       const uint32_t* src = (s < S1) ? (in1 + 4 * s) : (in2 + 4 * (s - S1));
       u32x4 b = {src[0], src[1], src[2], src[3]};
-      acc = ET::mfma(st.R[f], b, acc);
-      st.R[f] = ws_read(st, (chunk + 1) % kRingSlots, f);
+      acc = ET::mfma(st.R[f % kRegFrags], b, acc);
+      ws_refill<ADN_ABLATE>(st, f);
     }
     if (KEEP_F32_TILE == m) {
       *keep = acc;
+    } else if (ADN_ABLATE & 8) {
+      asm volatile("" ::"v"(acc));
+#pragma unroll
+      for (int g = 0; g < 8; ++g) asm volatile("" : "=v"(out[8 * m + g]));
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float v0 = acc[4 * g + 0], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
+        // convert first, then ReLU on the packed pair: max(int16, 0) clears every negative bf16/f16
+        // (one v_cvt_pk + one v_pk_max_i16 per two values)
+        uint32_t p0 = ET::pack(acc[4 * g + 0], acc[4 * g + 1]), p1 = ET::pack(acc[4 * g + 2], acc[4 * g + 3]);
         if (RELU) {
-          v0 = relu_bits(v0);
-          v1 = relu_bits(v1);
-          v2 = relu_bits(v2);
-          v3 = relu_bits(v3);
+          const s16x2 z = {0, 0};
+          p0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p0), z));
+          p1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p1), z));
         }
-        out[8 * m + 2 * g + 0] = ET::pack(v0, v1);
-        out[8 * m + 2 * g + 1] = ET::pack(v2, v3);
+        out[8 * m + 2 * g + 0] = p0;
+        out[8 * m + 2 * g + 1] = p1;
       }
     }
   }
@@ -679,14 +748,20 @@ __device__ __forceinline__ void load_sample(const ShadeArgs& a, int s, int total
   }
 }
 
-// A5+A6, 16-bit MFMA path.  Workgroup = 8 waves (2 per SIMD) = 256 samples per tile; persistent
-// over tiles; the weight stream is cyclic so DMA prefetch runs across tile boundaries.
-template <class ET, int FP, int FD>
-__global__ __launch_bounds__(512) void shade_mlp16_kernel(ShadeArgs a) {
+// A5+A6, 16-bit MFMA path.  Workgroup = WAVES waves x 32 samples; persistent over tiles; the weight
+// stream is cyclic so DMA prefetch runs across tile boundaries.  WAVES = 4 with two workgroups per CU
+// (two waves per SIMD from DIFFERENT workgroups): each workgroup has its own ring and barriers, so the
+// two waves sharing a SIMD are not in lockstep and one computes while the other waits at its barrier.
+template <class ET, int FP, int FD, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_kernel(ShadeArgs a) {
   static_assert(FP == 10 && FD == 4, "fragment positions below assume the 10-4 shading encoding");
+  static_assert(WAVES == 4 || WAVES == 8, "chunk = 8 fragments");
   constexpr int QP = pe_slots(FP), QD = pe_slots(FD);
-  constexpr int WAVES = 8, TILE = WAVES * 32;
-  __shared__ __attribute__((aligned(16))) char lds[kRingBytes];
+  constexpr int TILE = WAVES * 32, CF = ADN_CF, RS = ADN_RS, LPW = CF / WAVES;
+  constexpr int kRingBytes = CF * RS * 1024;
+  static_assert(CF % WAVES == 0 && CF % kRegFrags == 0 && kShadeFrags16 % CF == 0 && CF % 8 == 0 && CF <= 32, "chunk geometry");
+  typedef WStream<CF, RS, LPW> WS;
+  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kShadeBiasFloats * 4];
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -695,46 +770,55 @@ __global__ __launch_bounds__(512) void shade_mlp16_kernel(ShadeArgs a) {
   const int ntiles = (total + TILE - 1) / TILE;
   if (static_cast<int>(blockIdx.x) >= ntiles) return;    // workgroup-uniform
 
-  WStream st;
-  ws_init(st, a.net.w, kShadeFrags16 * 1024, lds, wave, lane, 1);
-  ws_prologue<1>(st);
+  {
+    float* lds_bias = reinterpret_cast<float*>(lds + kRingBytes);
+    for (int i = threadIdx.x; i < kShadeBiasFloats; i += blockDim.x) lds_bias[i] = a.net.bias[i];
+  }
+  __syncthreads();
+  WS st;
+  ws_start(st, a.net.w, kShadeFrags16 * 1024, lds, wave, lane);
 
-  const float* __restrict__ bias = a.net.bias;
+  // LDS byte address of the bias blocks of this lane-half
+  const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
   const uint32_t* bo = a.net.b_off;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int s = tile * TILE + wave * 32 + j;
-    float x[3], dpe[3];
-    load_sample(a, s, total, x, dpe);
     uint32_t hA[64], hB[64];
     {
+      float x[3], dpe[3];
+      load_sample(a, s, total, x, dpe);
       uint32_t pts[QP / 2];
       pe_pack<ET, FP>(x, h, pts);
-      layer_16<ET, QP / 8, 0, 8, true, 0>(st, bias + bo[0], lane, pts, pts, hA);
+      layer_16<ET, WS, QP / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, lane, pts, pts, hA);
     }
 #pragma unroll 1
     for (int l = 1; l <= 3; l += 2) {
-      layer_16<ET, 16, 0, 8, true, 0>(st, bias + bo[l], lane, hA, hA, hB);
-      layer_16<ET, 16, 0, 8, true, 0>(st, bias + bo[l + 1], lane, hB, hB, hA);
+      layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l] * 4, lane, hA, hA, hB);
+      layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l + 1] * 4, lane, hB, hB, hA);
     }
     {
-      // the skip connection re-evaluates the 32 position slots instead of holding 16 VGPRs across
-      // layers 1-4 (30 v_sin per lane vs ~600 MFMA issue slots)
+      // the skip connection re-loads the sample and re-evaluates the 32 position slots instead of
+      // holding 16 (+6) VGPRs across layers 1-4 (30 v_sin per lane vs ~600 MFMA issue slots)
+      float x[3], dpe[3];
+      load_sample(a, s, total, x, dpe);
       uint32_t pts[QP / 2];
       pe_pack<ET, FP>(x, h, pts);
-      layer_16<ET, QP / 8, 16, 8, true, 0>(st, bias + bo[5], lane, pts, hA, hB);   // cat([pts, h])
+      layer_16<ET, WS, QP / 8, 16, 8, true, 0>(st, bias0 + bo[5] * 4, lane, pts, hA, hB);   // cat([pts, h])
     }
-    layer_16<ET, 16, 0, 8, true, 0>(st, bias + bo[6], lane, hB, hB, hA);
-    layer_16<ET, 16, 0, 8, true, 0>(st, bias + bo[7], lane, hA, hA, hB);
+    layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[6] * 4, lane, hB, hB, hA);
+    layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[7] * 4, lane, hA, hA, hB);
     f32x16 alpha_tile;
-    layer_16<ET, 16, 0, 9, false, 0, 8>(st, bias + bo[8], lane, hB, hB, hA, &alpha_tile);      // feature (+alpha row)
+    layer_16<ET, WS, 16, 0, 9, false, 0, 8>(st, bias0 + bo[8] * 4, lane, hB, hB, hA, &alpha_tile);      // feature (+alpha row)
     const float alpha = alpha_tile[0];
     {
+      float x[3], dpe[3];
+      load_sample(a, s, total, x, dpe);
       uint32_t dirs[QD / 2];
       pe_pack<ET, FD>(dpe, h, dirs);
-      layer_16<ET, 16, QD / 8, 4, true, 16>(st, bias + bo[9], lane, hA, dirs, hB);             // cat([feature, dir])
+      layer_16<ET, WS, 16, QD / 8, 4, true, (32 + 4 * 128 + 160 + 2 * 128 + 144) % CF>(st, bias0 + bo[9] * 4, lane, hA, dirs, hB);             // cat([feature, dir])
     }
     f32x16 rgb_tile;
-    layer_16<ET, 8, 0, 1, false, 24, 0>(st, bias + bo[10], lane, hB, hB, hA, &rgb_tile);
+    layer_16<ET, WS, 8, 0, 1, false, (32 + 4 * 128 + 160 + 2 * 128 + 144 + 72) % CF, 0>(st, bias0 + bo[10] * 4, lane, hB, hB, hA, &rgb_tile);
     if (h == 0 && s < total)
       *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(rgb_tile[0], rgb_tile[1], rgb_tile[2], alpha);
   }
@@ -835,33 +919,27 @@ __device__ __forceinline__ void split_pack(float v0, float v1, uint32_t* hi, uin
   *lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
 }
 
-// One layer, fragments arrive as (hi, lo') pairs per k-step.  FPOS: first fragment position mod 32.
-template <int KS, int MT, bool LAST, int FPOS, int LPW>
-__device__ __forceinline__ void layer_16x3(WStream& st, const float* __restrict__ bias, int lane, const uint32_t* in_hi,
+// One layer, fragments arrive as (hi, lo') pairs per k-step.  FPOS: first fragment position mod the chunk size.
+template <class WS, int KS, int MT, bool LAST, int FPOS>
+__device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane, const uint32_t* in_hi,
                                            const uint32_t* in_lo, uint32_t* out_hi, uint32_t* out_lo, float* out_f32) {
-  const bool hi_half = lane >= 32;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 acc, cross;
-    const __attribute__((address_space(4))) float* cb = (const __attribute__((address_space(4))) float*)(bias + m * 32);
+    lds_bias16(bias_addr + m * 128, &acc);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float b0 = cb[r], b1 = cb[16 + r];
-      acc[r] = hi_half ? b1 : b0;
-      cross[r] = 0.f;
-    }
+    for (int r = 0; r < 16; ++r) cross[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const int p = FPOS + 2 * (m * KS + s);        // compile-time after unrolling; always even
-      const int chunk = p / kChunkFrags, f = p % kChunkFrags;
-      if (f == 0) ws_boundary<LPW>(st, (chunk + kRingSlots - 1) % kRingSlots);
+      const int f = (FPOS + 2 * (m * KS + s)) % ADN_CF_S;   // compile-time after unrolling; always even
+      if (f == 0) ws_boundary<ADN_ABLATE_S>(st);
       const u32x4 bh = {in_hi[4 * s], in_hi[4 * s + 1], in_hi[4 * s + 2], in_hi[4 * s + 3]};
       const u32x4 bl = {in_lo[4 * s], in_lo[4 * s + 1], in_lo[4 * s + 2], in_lo[4 * s + 3]};
-      acc = Fp16::mfma(st.R[f], bh, acc);
-      cross = Fp16::mfma(st.R[f], bl, cross);
-      cross = Fp16::mfma(st.R[f + 1], bh, cross);
-      st.R[f] = ws_read(st, (chunk + 1) % kRingSlots, f);
-      st.R[f + 1] = ws_read(st, (chunk + 1) % kRingSlots, f + 1);
+      acc = Fp16::mfma(st.R[f % kRegFrags], bh, acc);
+      cross = Fp16::mfma(st.R[f % kRegFrags], bl, cross);
+      cross = Fp16::mfma(st.R[(f + 1) % kRegFrags], bh, cross);
+      ws_refill<ADN_ABLATE_S>(st, f);
+      ws_refill<ADN_ABLATE_S>(st, f + 1);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -887,21 +965,27 @@ __device__ __forceinline__ void layer_16x3(WStream& st, const float* __restrict_
 template <int FP, int FD>
 __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
   constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP;
-  constexpr int WAVES = 4, LPW = kChunkFrags / WAVES, TILE = WAVES * 32;
+  constexpr int WAVES = 4, CF = ADN_CF_S, RS = ADN_RS_S, LPW = CF / WAVES, TILE = WAVES * 32;
   constexpr int F0 = 2 * (Q0 / 8) * 8;                  // layer-0 fragments (hi + lo')
   constexpr int FRAGS = F0 + 6 * 256 + 128;
-  static_assert(F0 % 32 == 0 && FRAGS % (kChunkFrags * kRingSlots) == 0, "ring slot pattern must repeat per pass");
-  __shared__ __attribute__((aligned(16))) char lds[kRingBytes];
+  static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % WAVES == 0 && CF % kRegFrags == 0 && CF <= 32, "chunk geometry");
+  typedef WStream<CF, RS, LPW> WS;
+  constexpr int kRingBytes = CF * RS * 1024, kBiasFloats = 7 * 256 + 128;
+  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kBiasFloats * 4];
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int j = lane & 31, h = lane >> 5;
   const int ntiles = (a.n_rays + TILE - 1) / TILE;
   if (static_cast<int>(blockIdx.x) >= ntiles) return;
 
-  WStream st;
-  ws_init(st, a.net16.w, FRAGS * 1024, lds, wave, lane, LPW);
-  ws_prologue<LPW>(st);
-  const float* __restrict__ bias = a.net16.bias;
+  {
+    float* lds_bias = reinterpret_cast<float*>(lds + kRingBytes);
+    for (int i = threadIdx.x; i < kBiasFloats; i += blockDim.x) lds_bias[i] = a.net16.bias[i];
+  }
+  __syncthreads();
+  WS st;
+  ws_start(st, a.net16.w, FRAGS * 1024, lds, wave, lane);
+  const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
   const uint32_t* bo = a.net16.b_off;
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -922,14 +1006,14 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
 #pragma unroll
       for (int q = 0; q < Q0 / 2; ++q) split_pack(t[2 * q], t[2 * q + 1], &aH[q], &aL[q]);
     }
-    layer_16x3<Q0 / 8, 8, false, 0, LPW>(st, bias + bo[0], lane, aH, aL, bH, bL, nullptr);
+    layer_16x3<WS, Q0 / 8, 8, false, 0>(st, bias0 + bo[0] * 4, lane, aH, aL, bH, bL, nullptr);
 #pragma unroll 1
     for (int l = 1; l <= 5; l += 2) {
-      layer_16x3<16, 8, false, 0, LPW>(st, bias + bo[l], lane, bH, bL, aH, aL, nullptr);
-      layer_16x3<16, 8, false, 0, LPW>(st, bias + bo[l + 1], lane, aH, aL, bH, bL, nullptr);
+      layer_16x3<WS, 16, 8, false, 0>(st, bias0 + bo[l] * 4, lane, bH, bL, aH, aL, nullptr);
+      layer_16x3<WS, 16, 8, false, 0>(st, bias0 + bo[l + 1] * 4, lane, aH, aL, bH, bL, nullptr);
     }
     float out[64];
-    layer_16x3<16, 4, true, 0, LPW>(st, bias + bo[7], lane, bH, bL, nullptr, nullptr, out);
+    layer_16x3<WS, 16, 4, true, 0>(st, bias0 + bo[7] * 4, lane, bH, bL, nullptr, nullptr, out);
 
     if (valid) {
       if (a.oracle_out) {

@@ -65,7 +65,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or library_path()
+    p = path or os.environ.get("ADANERF_LIB") or library_path()   # ADANERF_LIB: tools/ablate.sh variants
     if not os.path.exists(p):
         raise AdaNeRFError("HIP library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % p)
     lib = C.CDLL(p)
