@@ -333,33 +333,65 @@ __device__ __forceinline__ void select_ray(float v0, float v1, int lane, int n_m
   const uint64_t b0 = __ballot(v0 >= thr), b1 = __ballot(v1 >= thr);
   const int c = __popcll(b0) + __popcll(b1);
   uint64_t sel0, sel1;
-  if (c == 0) {
-    const float m = wave_max_f32(fmaxf(v0, v1));
-    const uint64_t e0 = __ballot(v0 == m), e1 = __ballot(v1 == m);
-    sel0 = e0 & (~e0 + 1);
-    sel1 = e0 ? 0 : (e1 & (~e1 + 1));
-    if ((sel0 | sel1) == 0) sel0 = 1;   // all-NaN row: keep bin 0 (undefined in the reference)
-  } else if (c <= n_max) {
+  if (c <= n_max && c > 0) {
     sel0 = b0;
     sel1 = b1;
   } else {
-    sel0 = 0;
-    sel1 = 0;
-    uint64_t c0 = b0, c1 = b1;
-    const float ninf = -__builtin_inff();
-    for (int k = 0; k < n_max; ++k) {
-      const float x0 = ((c0 >> lane) & 1) ? v0 : ninf;
-      const float x1 = ((c1 >> lane) & 1) ? v1 : ninf;
-      const float m = wave_max_f32(fmaxf(x0, x1));
-      const uint64_t e0 = __ballot(x0 == m) & c0, e1 = __ballot(x1 == m) & c1;
-      if (e0) {
-        const uint64_t bit = e0 & (~e0 + 1);
-        sel0 |= bit;
-        c0 &= ~bit;
+    const float m = wave_max_f32(fmaxf(v0, v1));
+    const uint64_t e0 = __ballot(v0 == m), e1 = __ballot(v1 == m);
+    if (c == 0) {
+      // nothing clears the threshold: keep the arg-max alone (lowest bin among equal maxima)
+      sel0 = e0 & (~e0 + 1);
+      sel1 = e0 ? 0 : (e1 & (~e1 + 1));
+      if ((sel0 | sel1) == 0) sel0 = 1;   // all-NaN row: keep bin 0 (undefined in the reference)
+    } else {
+      // More than n_max candidates: bisect a value threshold t in [thr, max] until exactly n_max values
+      // are >= t (v_cmp yields the lane mask directly, ~10 instructions per step, ~log2(range / gap)
+      // steps).  If the interval closes on a tie that straddles the cut-off, keep everything above the
+      // tie value plus the lowest-index members of the tie (the set rule's "lower bin first").
+      float lo = thr, hi = m;                    // count(v >= lo) = c > n_max
+      uint64_t g0 = e0, g1 = e1;                 // {v >= hi}
+      int ch = __popcll(e0) + __popcll(e1);
+      uint64_t t0 = b0, t1 = b1;                 // {v >= lo}
+      while (ch < n_max) {
+        const float mid = lo + (hi - lo) * 0.5f;
+        if (!(mid > lo) || !(mid < hi)) break;   // lo and hi are adjacent floats
+        const uint64_t m0 = __ballot(v0 >= mid), m1 = __ballot(v1 >= mid);
+        const int cm = __popcll(m0) + __popcll(m1);
+        if (cm > n_max) {
+          lo = mid;
+          t0 = m0;
+          t1 = m1;
+        } else {
+          hi = mid;
+          g0 = m0;
+          g1 = m1;
+          ch = cm;
+        }
+      }
+      if (ch >= n_max) {
+        // ch == n_max: {v >= hi} is the answer; ch > n_max only when more than n_max values equal the
+        // maximum (then lo..hi never moved): fall through to the tie rule with an empty "above" set
+        if (ch == n_max) {
+          sel0 = g0;
+          sel1 = g1;
+        } else {
+          g0 = 0;
+          g1 = 0;
+          ch = 0;
+          t0 = e0;
+          t1 = e1;
+          goto tie;
+        }
       } else {
-        const uint64_t bit = e1 & (~e1 + 1);
-        sel1 |= bit;
-        c1 &= ~bit;
+      tie:
+        // every value in {v >= lo} \ {v >= hi} equals lo: take the first (n_max - ch) of them by bin index
+        const uint64_t q0 = t0 & ~g0, q1 = t1 & ~g1;
+        const int need = n_max - ch;
+        const int r0 = mbcnt64(q0), r1 = __popcll(q0) + mbcnt64(q1);
+        const uint64_t k0 = __ballot(((q0 >> lane) & 1) && r0 < need), k1 = __ballot(((q1 >> lane) & 1) && r1 < need);
+        sel0 = g0 | k0;
+        sel1 = g1 | k1;
       }
     }
   }
