@@ -568,6 +568,7 @@ struct Fp16 {
 //   1: no chunk boundary (no wait, no barrier, no DMA)   2: no LDS re-fill of the fragment registers
 //   4: no bias read (acc starts at 0)                    8: no ReLU/convert epilogue
 //  16: boundary without the DMA issue                   32: boundary without wait + barrier
+//  64: (sampling kernel) no cross-tile software pipeline of bias reads / epilogue
 // ADN_ABLATE applies to shade_mlp16_kernel, ADN_ABLATE_S to sample_mlp16x3_kernel.
 #ifndef ADN_ABLATE
 #define ADN_ABLATE 0
@@ -577,6 +578,10 @@ struct Fp16 {
 #endif
 // Ring geometry.  CF = fragments (KiB) per chunk = MFMAs per wave between barriers; RS = ring slots.
 // At boundary k a wave waits for its own pieces of chunk k+1, so RS-3 further chunks stay in flight.
+// ADN_SGB: pin the MFMA / ds_read interleave with sched_group_barrier (bit 0: shading, bit 1: sampling)
+#ifndef ADN_SGB
+#define ADN_SGB 0
+#endif
 #ifndef ADN_CF
 #define ADN_CF 16
 #endif
@@ -694,6 +699,28 @@ __device__ __forceinline__ void pe_pack(const float x[3], int h, uint32_t* out) 
 // ds_read, so it neither assumes aliasing with the LDS-DMA ring (which costs an s_waitcnt vmcnt(0) drain
 // per tile) nor needs the 3-VALU-per-value SGPR select that scalar loads cost.  The wait statement names
 // every destination "+v" so no consumer is scheduled above it (cdna_hip_programming.md 5.7 form ii).
+struct BiasRegs {
+  f32x4 b0, b1, b2, b3;
+};
+// issue now, consume later: the reads stay in flight behind the MFMAs of the current tile
+__device__ __forceinline__ void lds_bias_issue(uint32_t byte_addr, BiasRegs& r) {
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+               : "=&v"(r.b0), "=&v"(r.b1), "=&v"(r.b2), "=&v"(r.b3)
+               : "v"(byte_addr));
+}
+__device__ __forceinline__ void lds_bias_take(BiasRegs& r, f32x16* acc) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.b0), "+v"(r.b1), "+v"(r.b2), "+v"(r.b3));
+  f32x16 a;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = r.b0[e];
+    a[4 + e] = r.b1[e];
+    a[8 + e] = r.b2[e];
+    a[12 + e] = r.b3[e];
+  }
+  *acc = a;
+}
+
 __device__ __forceinline__ void lds_bias16(uint32_t byte_addr, f32x16* acc) {
   f32x4 b0, b1, b2, b3;
   asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
@@ -738,6 +765,10 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
       u32x4 b = {src[0], src[1], src[2], src[3]};
       acc = ET::mfma(st.R[f % kRegFrags], b, acc);
       ws_refill<ADN_ABLATE>(st, f);
+      if (ADN_SGB & 1) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // ... then the re-fill read it freed
+      }
     }
     if (KEEP_F32_TILE == m) {
       *keep = acc;
@@ -952,13 +983,41 @@ __device__ __forceinline__ void split_pack(float v0, float v1, uint32_t* hi, uin
 }
 
 // One layer, fragments arrive as (hi, lo') pairs per k-step.  FPOS: first fragment position mod the chunk size.
+// epilogue of one accumulator pair (values 2*pi, 2*pi+1 of tile m): v = acc + cross / 2048, then either
+// the fp32 output (last layer) or ReLU + hi/lo' split for the next layer
+template <bool LAST>
+__device__ __forceinline__ void epilogue_pair_16x3(const f32x16& acc, const f32x16& cross, int m, int pi, uint32_t* out_hi,
+                                                   uint32_t* out_lo, float* out_f32) {
+  float v0 = __builtin_fmaf(cross[2 * pi], 1.0f / kSplitScale, acc[2 * pi]);
+  float v1 = __builtin_fmaf(cross[2 * pi + 1], 1.0f / kSplitScale, acc[2 * pi + 1]);
+  if (LAST) {
+    out_f32[16 * m + 2 * pi] = v0;
+    out_f32[16 * m + 2 * pi + 1] = v1;
+  } else {
+    split_pack(relu_bits(v0), relu_bits(v1), &out_hi[8 * m + pi], &out_lo[8 * m + pi]);
+  }
+}
+
 template <class WS, int KS, int MT, bool LAST, int FPOS>
 __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane, const uint32_t* in_hi,
                                            const uint32_t* in_lo, uint32_t* out_hi, uint32_t* out_lo, float* out_f32) {
+  // Software pipeline across output tiles (one wave per SIMD: nothing else hides these latencies):
+  //  - the bias block of tile m+1 is requested right after tile m's accumulators are initialised,
+  //  - the epilogue of tile m-1 is spread, one accumulator pair per k-step, over tile m's MFMAs.
+  constexpr bool PIPE = !(ADN_ABLATE_S & 64);
+  BiasRegs br;
+  f32x16 pacc, pcross;   // previous tile's accumulators (PIPE)
+  if (!(ADN_ABLATE_S & 4)) lds_bias_issue(bias_addr, br);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 acc, cross;
-    lds_bias16(bias_addr + m * 128, &acc);
+    if (ADN_ABLATE_S & 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    } else {
+      lds_bias_take(br, &acc);
+      if (m + 1 < MT) lds_bias_issue(bias_addr + (m + 1) * 128, br);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) cross[r] = 0.f;
 #pragma unroll
@@ -972,21 +1031,32 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
       cross = Fp16::mfma(st.R[(f + 1) % kRegFrags], bh, cross);
       ws_refill<ADN_ABLATE_S>(st, f);
       ws_refill<ADN_ABLATE_S>(st, f + 1);
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(cross[4 * g + e], 1.0f / kSplitScale, acc[4 * g + e]);
-      if (LAST) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) out_f32[16 * m + 4 * g + e] = v[e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = relu_bits(v[e]);
-        split_pack(v[0], v[1], &out_hi[8 * m + 2 * g], &out_lo[8 * m + 2 * g]);
-        split_pack(v[2], v[3], &out_hi[8 * m + 2 * g + 1], &out_lo[8 * m + 2 * g + 1]);
+      if (ADN_SGB & 2) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
+      if (PIPE && m > 0 && !(ADN_ABLATE_S & 8)) {
+        // KS >= 2: spread the 8 pairs over the first k-steps (all 8 in step 0/1 when KS < 8)
+        constexpr int PER = (KS >= 8) ? 1 : (8 + KS - 1) / KS;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+          const int pi = s * PER + k;
+          if (pi < 8) epilogue_pair_16x3<LAST>(pacc, pcross, m - 1, pi, out_hi, out_lo, out_f32);
+        }
+      }
+    }
+    if ((ADN_ABLATE_S & 8) && !LAST) {
+      asm volatile("" ::"v"(acc), "v"(cross));
+#pragma unroll
+      for (int g = 0; g < 8; ++g) asm volatile("" : "=v"(out_hi[8 * m + g]), "=v"(out_lo[8 * m + g]));
+      continue;
+    }
+    if (PIPE && m + 1 < MT) {
+      pacc = acc;
+      pcross = cross;
+    } else {
+#pragma unroll
+      for (int pi = 0; pi < 8; ++pi) epilogue_pair_16x3<LAST>(acc, cross, m, pi, out_hi, out_lo, out_f32);
     }
   }
 }
