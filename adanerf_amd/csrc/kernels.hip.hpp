@@ -742,18 +742,45 @@ __device__ __forceinline__ void lds_bias16(uint32_t byte_addr, f32x16* acc) {
 // k-steps of 8 slots = 4 packed dwords each); output tile m lands in out[8m .. 8m+7] (packed pairs).
 // FPOS = position of the layer's first fragment in the stream modulo the chunk size.
 // KEEP_F32_TILE >= 0: that tile's raw accumulator is returned in *keep instead (alpha / rgb rows).
+// epilogue of one accumulator quad g (values 4g..4g+3 of tile m): convert, ReLU on the packed pairs
+template <class ET, bool RELU>
+__device__ __forceinline__ void epilogue_quad_16(const f32x16& acc, int m, int g, uint32_t* out) {
+  // convert first, then ReLU on the packed pair: max(int16, 0) clears every negative bf16/f16
+  // (one v_cvt_pk + one v_pk_max_i16 per two values)
+  uint32_t p0 = ET::pack(acc[4 * g + 0], acc[4 * g + 1]), p1 = ET::pack(acc[4 * g + 2], acc[4 * g + 3]);
+  if (RELU) {
+    const s16x2 z = {0, 0};
+    p0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p0), z));
+    p1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p1), z));
+  }
+  out[8 * m + 2 * g + 0] = p0;
+  out[8 * m + 2 * g + 1] = p1;
+}
+
+#ifndef ADN_PIPE16
+#define ADN_PIPE16 0   // bit 0: early bias reads, bit 1: epilogue of tile m-1 spread over tile m's MFMAs
+#endif
+
 template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
 __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, const uint32_t* in1, const uint32_t* in2,
                                          uint32_t* out, f32x16* keep = nullptr) {
   constexpr int CF = ADN_CF;
   constexpr int KS = S1 + S2;
+  constexpr bool EARLY_BIAS = (ADN_PIPE16 & 1) && !(ADN_ABLATE & 4);
+  constexpr bool SPREAD = (ADN_PIPE16 & 2) && !(ADN_ABLATE & 8) && KS >= 4;
   // bias_addr: LDS byte address of this layer's bias block for THIS lane-half ([m][h][16] floats)
+  BiasRegs br;
+  f32x16 pacc;
+  if (EARLY_BIAS) lds_bias_issue(bias_addr, br);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 acc;
     if (ADN_ABLATE & 4) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    } else if (EARLY_BIAS) {
+      lds_bias_take(br, &acc);
+      if (m + 1 < MT) lds_bias_issue(bias_addr + (m + 1) * 128, br);
     } else {
       lds_bias16(bias_addr + m * 128, &acc);
     }
@@ -769,6 +796,7 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // ... then the re-fill read it freed
       }
+      if (SPREAD && m > 0 && s < 4 && KEEP_F32_TILE != m - 1) epilogue_quad_16<ET, RELU>(pacc, m - 1, s, out);
     }
     if (KEEP_F32_TILE == m) {
       *keep = acc;
@@ -776,20 +804,11 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
       asm volatile("" ::"v"(acc));
 #pragma unroll
       for (int g = 0; g < 8; ++g) asm volatile("" : "=v"(out[8 * m + g]));
+    } else if (SPREAD && m + 1 < MT) {
+      pacc = acc;
     } else {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        // convert first, then ReLU on the packed pair: max(int16, 0) clears every negative bf16/f16
-        // (one v_cvt_pk + one v_pk_max_i16 per two values)
-        uint32_t p0 = ET::pack(acc[4 * g + 0], acc[4 * g + 1]), p1 = ET::pack(acc[4 * g + 2], acc[4 * g + 3]);
-        if (RELU) {
-          const s16x2 z = {0, 0};
-          p0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p0), z));
-          p1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p1), z));
-        }
-        out[8 * m + 2 * g + 0] = p0;
-        out[8 * m + 2 * g + 1] = p1;
-      }
+      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(acc, m, g, out);
     }
   }
 }

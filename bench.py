@@ -197,9 +197,21 @@ def main():
         flop_per_launch = SHADE_FLOP_PER_SAMPLE * (st.total_samples / launches)
         achieved = flop_per_launch / (shade_ms * 1e-3) / 1e12 if shade_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
-        roofline = {"bound": "mfma", "kernel": "shade_mlp%s_kernel" % ("32" if args.precision == "fp32" else "16"),
+        kname = "shade_mlp%s_kernel" % ("32" if args.precision == "fp32" else "16")
+        # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes of this same
+        # workload (tools/collect_profiles.sh -> profiles/; PMC cannot be read from inside this process)
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary_%s.json" % args.workload)
+        if os.path.exists(pmc_path) and world == 1 and args.precision == "bf16" and r.info.batch_rays >= r.info.rays_local:
+            try:
+                traffic = json.load(open(pmc_path)).get(kname, {}).get("hbm_bytes_per_launch")
+                traffic_src = os.path.relpath(pmc_path, ROOT)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "traffic": None, "avg_launch_ms": shade_ms, "samples_per_launch": st.total_samples / launches,
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "avg_launch_ms": shade_ms, "samples_per_launch": st.total_samples / launches,
                     "flop_per_sample": SHADE_FLOP_PER_SAMPLE}
         stage_ms = {"sample_mlp": st.ms_sample_mlp / frames, "compact": st.ms_compact / frames,
                     "shade_mlp": st.ms_shade_mlp / frames, "composite": st.ms_composite / frames}
@@ -233,7 +245,7 @@ def main():
                           "parallelism": "image-strip shard x%d (8-row strips, round-robin) + RCCL gather" % world if world > 1 else "single GPU",
                           "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame},
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,
-               "sampling_mlp_tflops_fp32": smp_tflops, "hbm_stages": hbm, "quality": quality}
+               "sampling_mlp_algorithmic_tflops": smp_tflops, "hbm_stages": hbm, "quality": quality}
         print(json.dumps(rec))
     r.close()
     if dist:
