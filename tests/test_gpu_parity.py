@@ -450,3 +450,77 @@ def test_errors_are_reported_not_thrown(cases):
             r.compact(buf, 4, 200, 0.2, buf, buf, buf, buf, buf)
     with pytest.raises(adanerf_amd.AdaNeRFError):
         adanerf_amd.NeuralRenderer(adanerf_amd.Settings("/nonexistent/", 32, 32)).init()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5 shape: 1920x1080, LLFF-NDC, 2-2 oracle encoding, fp16 shading path, threshold sweep
+# ---------------------------------------------------------------------------------------------
+
+def test_ndc_1080p_threshold_sweep_properties(cases):
+    z, meta, sc, wts, d = cases["ndc_synthetic_n8"]
+    w, h = 1920, 1080
+    prev = None
+    for thr in (0.05, 0.2, 0.4):
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="fp16", threshold=thr) as r:
+            r.set_camera(z["pose"], z["rot"])
+            rgb, rgba, st = r.render_numpy()
+            cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,))
+            off = r.buffer(R.BUF_RAY_OFFSETS, np.int32, (w * h,))
+            assert r.last_stats.sampling_overflow == 0
+        assert cnt.min() >= 1 and cnt.max() <= 8 and st.total_samples == int(cnt.sum())
+        assert np.array_equal(off[1:].astype(np.int64), np.cumsum(cnt.astype(np.int64))[:-1])
+        assert np.isfinite(rgb).all() and np.array_equal(rgba[:, :3], O.to_rgba8(rgb)[:, :3])
+        if prev is not None:
+            assert (cnt <= prev).all()          # a higher threshold never keeps more samples on any ray
+        prev = cnt
+        row = 517
+        import dataclasses
+        sct = dataclasses.replace(sc, threshold=thr)
+        ref = O.render_frame(sct, wts, w, h, z["pose"], z["rot"], rows=(row, row + 1))
+        sl = slice(row * w, (row + 1) * w)
+        same = cnt[sl] == ref["count"]
+        assert same.mean() >= 0.99
+        assert O.psnr(rgb[sl][same], ref["rgb"][same]) > 55.0
+
+
+def test_headless_cli_matches_library(cases, tmp_path):
+    """The C++ `adanerf` host (reference CLI) renders the same bytes as the Python host."""
+    import subprocess
+    from adanerf_amd import build as B
+    exe = B.build_cli()
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    md = str(tmp_path / "model")
+    O.write_model_dir(md, sc, wts)
+    w, h = 96, 72
+    out = subprocess.run([exe, md, "-s", str(w), str(h), "-bs", "5000", "-w", "-d", "--frames", "100", "--yaw", "100", "--pitch", "0"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "avg samples ppx" in out.stdout and "Inference 1:" in out.stdout      # the reference's 100-frame log line
+    bmp = open(os.path.join(md, "out.bmp"), "rb").read()
+    assert bmp[:2] == b"BM"
+    off = int.from_bytes(bmp[10:14], "little")
+    row_bytes = (w * 3 + 3) & ~3
+    px = np.frombuffer(bmp[off:off + row_bytes * h], dtype=np.uint8).reshape(h, row_bytes)[:, :w * 3].reshape(h, w, 3)
+    img = px[::-1, :, ::-1]                                                       # bottom-up BGR -> top-down RGB
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, w, h, batch_size=5000), precision="bf16") as r:
+        pose = np.array(sc.view_cell_center, dtype=np.float32)
+        r.set_camera(pose, O.camera_rotation(100.0, 0.0))
+        _, rgba, _ = r.render_numpy()
+    diff = np.abs(img.reshape(-1, 3).astype(np.int16) - rgba[:, :3].astype(np.int16))
+    assert diff.max() <= 1 and (diff == 0).mean() > 0.99     # the CLI builds its rotation in float64 -> a few LSB flips
+
+
+def test_profiling_api_accumulates_frames(cases):
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, 128, 96, batch_size=4096), precision="bf16") as r:
+        r.set_camera(z["pose"], z["rot"])
+        out = r.empty((128 * 96, 4), np.uint8)
+        st1 = r.render(out, None, stats=True)
+        r.set_profiling(True)
+        for _ in range(3):
+            r.render(out, None)
+        st, frames = r.collect_stats()
+        assert frames == 3 and st.batches == 9 and st.total_samples == 3 * st1.total_samples
+        assert st.ms_shade_mlp > 0 and st.ms_sample_mlp > 0 and st.ms_total >= st.ms_shade_mlp
+        st2, frames2 = r.collect_stats()
+        assert frames2 == 0 and st2.batches == 0
