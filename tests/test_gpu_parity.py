@@ -524,3 +524,30 @@ def test_profiling_api_accumulates_frames(cases):
         assert st.ms_shade_mlp > 0 and st.ms_sample_mlp > 0 and st.ms_total >= st.ms_shade_mlp
         st2, frames2 = r.collect_stats()
         assert frames2 == 0 and st2.batches == 0
+
+
+@pytest.mark.parametrize("w,h,bs", [(1, 1, -1), (37, 29, -1), (37, 29, 100), (129, 3, 128), (33, 65, 257)])
+def test_ragged_frame_sizes(cases, w, h, bs):
+    """Ray counts that are not multiples of the 32-ray wave block / 128-256-ray tiles / 256-ray scan blocks."""
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    ref = small_frame(cases["classroom_n8_thr02"], w, h)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=bs), precision="fp32") as r:
+        r.set_camera(z["pose"], z["rot"])
+        rgb, rgba, st = r.render_numpy()
+    assert st.total_samples == int(ref["count"].sum()) or abs(st.total_samples - int(ref["count"].sum())) <= 2
+    assert O.psnr(rgb, ref["rgb"]) > 45.0
+    np.testing.assert_allclose(rgb, ref["rgb"], rtol=0, atol=0.05)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=bs), precision="bf16") as r:
+        r.set_camera(z["pose"], z["rot"])
+        rgb2, _, st2 = r.render_numpy()
+    assert st2.total_samples == st.total_samples and O.psnr(rgb2, rgb) > 40.0
+
+
+def test_shard_with_no_rows_renders_nothing(cases):
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    # 5 rows / 8-row strips = 1 strip: ranks 1..3 own nothing
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, 64, 5), precision="bf16", shard_rank=2, shard_world=4) as r:
+        r.set_camera(z["pose"], z["rot"])
+        assert r.info.rays_local == 0 and r.info.rays_local_max == 64 * 5
+        st = r.render(None, None, stats=True)
+        assert st.total_samples == 0 and st.batches == 0
