@@ -757,6 +757,9 @@ __device__ __forceinline__ void epilogue_quad_16(const f32x16& acc, int m, int g
   out[8 * m + 2 * g + 1] = p1;
 }
 
+#ifndef ADN_PRIO
+#define ADN_PRIO 0     // 1: s_setprio 1 while a tile's MFMA chain issues, 0 during its epilogue; 2: per MFMA
+#endif
 #ifndef ADN_PIPE16
 #define ADN_PIPE16 0   // bit 0: early bias reads, bit 1: epilogue of tile m-1 spread over tile m's MFMAs
 #endif
@@ -784,13 +787,16 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
     } else {
       lds_bias16(bias_addr + m * 128, &acc);
     }
+    if (ADN_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int f = (FPOS + m * KS + s) % CF;     // position inside the chunk; compile-time after unrolling
       if (f == 0) ws_boundary<ADN_ABLATE>(st);
       const uint32_t* src = (s < S1) ? (in1 + 4 * s) : (in2 + 4 * (s - S1));
       u32x4 b = {src[0], src[1], src[2], src[3]};
+      if (ADN_PRIO == 2) __builtin_amdgcn_s_setprio(1);
       acc = ET::mfma(st.R[f % kRegFrags], b, acc);
+      if (ADN_PRIO == 2) __builtin_amdgcn_s_setprio(0);
       ws_refill<ADN_ABLATE>(st, f);
       if (ADN_SGB & 1) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
@@ -798,6 +804,7 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
       }
       if (SPREAD && m > 0 && s < 4 && KEEP_F32_TILE != m - 1) epilogue_quad_16<ET, RELU>(pacc, m - 1, s, out);
     }
+    if (ADN_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     if (KEEP_F32_TILE == m) {
       *keep = acc;
     } else if (ADN_ABLATE & 8) {

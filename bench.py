@@ -24,7 +24,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 SHADE_FLOP_PER_SAMPLE = 1186816      # 2 x 593408 MAC
 SAMPLE_FLOP_PER_RAY = 898048         # 2 x 449024 MAC
@@ -39,31 +38,36 @@ WORKLOADS = {
 
 
 def build_model_dir(td, tag, n, thr):
-    import adanerf_oracle as O
+    """Model directory for the GPU path, written with the package's own format tools (adanerf_amd.modeldir)."""
+    from adanerf_amd import modeldir as M
     gold = os.path.join(ROOT, "tests", "golden")
     wpath = os.path.join(gold, "weights_%s.npz" % tag)
     spath = os.path.join(gold, "scene_%s.json" % tag)
     if os.path.exists(wpath) and os.path.exists(spath):
         z = np.load(wpath)
-        wts = O.Weights({k[3:]: z[k] for k in z.files if k.startswith("n0/")},
-                        {k[3:]: z[k] for k in z.files if k.startswith("n1/")})
+        n0 = {k[3:]: z[k] for k in z.files if k.startswith("n0/")}
+        n1 = {k[3:]: z[k] for k in z.files if k.startswith("n1/")}
         s = json.load(open(spath))
         data = "synthetic rays; weights = reference's exported %s model (fixture)" % tag
     else:
-        wts = O.synthetic_weights(0, oracle_bias=0.1, oracle_scale=0.3)
+        n0, n1 = M.random_init_weights(0)
         s = dict(view_cell_center=(0.783, -3.19, 1.39), view_cell_size=(0.7, 0.7, 0.2),
                  depth_range=(0.1542200982570648, 8.358194804191589), fov=1.1386263370513916, max_depth=8.79825210571289)
         data = "synthetic rays; random-init weights (seed 0)"
-    sc = O.Scene(tuple(s["view_cell_center"]), tuple(s["view_cell_size"]), tuple(s["depth_range"]), s["fov"],
-                 s["max_depth"], n, thr)
-    O.write_model_dir(td, sc, wts)
-    return sc, wts, data
+    scene = dict(view_cell_center=s["view_cell_center"], view_cell_size=s["view_cell_size"], depth_range=s["depth_range"],
+                 fov=s["fov"], max_depth=s["max_depth"], num_samples=n, threshold=thr)
+    M.write_model_dir(td, scene, n0, n1)
+    return scene, data
 
 
-def cpu_baseline(sc, wts, w, h, pose, rot, budget_s=15.0):
+def cpu_baseline(model_dir, w, h, pose, rot, budget_s=15.0):
     """The oracle (numpy port of the reference's PyTorch path, validated against the golden vectors)
-    timed on this box's host cores over a bounded band of image rows of the same frame."""
+    timed on this box's host cores over a bounded band of image rows of the same frame.  This leg (and the
+    quality check that reuses its output) is the ONLY place bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import adanerf_oracle as O
+    sc = O.load_scene(model_dir)
+    wts = O.load_weights(model_dir)
     try:
         from threadpoolctl import threadpool_info
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
@@ -80,7 +84,7 @@ def cpu_baseline(sc, wts, w, h, pose, rot, budget_s=15.0):
     fps = 1.0 / (dt * h / rows)
     return {"value": fps, "unit": "frames/s", "cores": int(cores), "kind": "port",
             "sample": "%d of %d image rows (%d rays, %.2f samples/ray) of the same frame, numpy fp32, %.1f s" %
-                      (rows, h, rows * w, float(res["count"].mean()), dt)}, res, (r0 - rows // 2, rows)
+                      (rows, h, rows * w, float(res["count"].mean()), dt)}, res, (r0 - rows // 2, rows), O.psnr
 
 
 def main():
@@ -96,9 +100,9 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import adanerf_oracle as O
     import adanerf_amd
     from adanerf_amd import build as B
+    from adanerf_amd import modeldir as M
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -122,9 +126,9 @@ def main():
 
     w, h, n_max, thr, tag = WORKLOADS[args.workload]
     td = tempfile.mkdtemp(prefix="adanerf_bench_%d_" % rank)
-    sc, wts, data = build_model_dir(td, tag, n_max, thr)
-    pose = np.array(sc.view_cell_center, dtype=np.float32)
-    rot = O.camera_rotation(100.0, 0.0)
+    scene, data = build_model_dir(td, tag, n_max, thr)
+    pose = np.array(scene["view_cell_center"], dtype=np.float32)
+    rot = M.camera_rotation(100.0, 0.0)
 
     r = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision,
                                    device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=8)
@@ -229,12 +233,12 @@ def main():
         cpu = None
         quality = {}
         if not args.no_cpu_baseline and world == 1:
-            cpu, ref, (row0, rows) = cpu_baseline(sc, wts, w, h, pose, rot, args.cpu_budget)
+            cpu, ref, (row0, rows), psnr = cpu_baseline(td, w, h, pose, rot, args.cpu_budget)
             mine = rgb.cpu().numpy()[row0 * w:(row0 + rows) * w]
             cnt = r.buffer(3, np.int32, (r.info.rays_local,))[row0 * w:(row0 + rows) * w] if r.info.batch_rays >= r.info.rays_local else None
             if cnt is not None:
                 same = cnt == ref["count"]
-                quality = {"psnr_vs_oracle_db": O.psnr(mine[same], ref["rgb"][same]),
+                quality = {"psnr_vs_oracle_db": psnr(mine[same], ref["rgb"][same]),
                            "max_abs_err_vs_oracle": float(np.abs(mine[same] - ref["rgb"][same]).max()),
                            "rays_with_identical_sample_count": float(same.mean()), "rays_checked": int(same.size)}
         rec = {"metric": "FPS at 800x800", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,

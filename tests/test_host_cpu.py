@@ -205,3 +205,27 @@ def test_settings_batch_semantics():
     assert S("x", 800, 800, batch_size=10 ** 9).resolved_batch() == 640000
     assert S("x", 800, 800, number_of_batches=8).resolved_batch() == 80000
     assert S("x", 10, 10, number_of_batches=3).resolved_batch() == 34
+
+
+def test_package_model_dir_writer_round_trips(lib, tmp_path):
+    """adanerf_amd.modeldir (the product-side writer bench.py uses) produces files the library's host parser,
+    its packer and the oracle's independent reader all agree on."""
+    from adanerf_amd import modeldir as M
+    n0, n1 = M.random_init_weights(3)
+    d = str(tmp_path / "pm")
+    scene = dict(view_cell_center=(0.5, -1.0, 1.25), view_cell_size=(0.7, 0.7, 0.2), depth_range=(0.15, 8.25), fov=1.125,
+                 max_depth=8.75, num_samples=8, threshold=0.2)
+    M.write_model_dir(d, scene, n0, n1)
+    sc = O.load_scene(d)
+    w = O.load_weights(d)
+    assert sc.num_samples == 8 and abs(sc.threshold - 0.2) < 1e-9 and sc.view_cell_center == (0.5, -1.0, 1.25)
+    assert all(np.array_equal(v, w.net0[k]) for k, v in n0.items()) and all(np.array_equal(v, w.net1[k]) for k, v in n1.items())
+    lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+    info = R.Info()
+    o = _opts()
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == 0
+    assert info.num_samples == 8 and info.n_in0 == 90
+    wq, b, lay = pack_weights(lib, d, 1, 0)
+    assert wq.size == 1184 * 1024
+    assert np.allclose(M.camera_rotation(100.0, 0.0), O.camera_rotation(100.0, 0.0))
+    assert np.allclose(M.camera_rotation(-80.0, 10.0) @ M.camera_rotation(-80.0, 10.0).T, np.eye(3), atol=1e-6)
