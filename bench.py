@@ -244,7 +244,7 @@ def main():
         rec = {"metric": "FPS at 800x800", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": args.precision, "data": data,
-               "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, 8x256 shading MLP %s, sampling MLP fp32" %
+               "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, 8x256 shading MLP %s, sampling MLP split-fp16 (3 MFMAs per term)" %
                                       (args.workload, w, h, n_max, thr, args.precision),
                           "parallelism": "image-strip shard x%d (8-row strips, round-robin) + RCCL gather" % world if world > 1 else "single GPU",
                           "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame},
