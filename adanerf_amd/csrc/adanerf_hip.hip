@@ -63,7 +63,8 @@ struct adanerf_ctx {
   // per-batch buffers
   int cap_rays = 0, cap_nmax = 0;
   DevBuf rays, oracle, ray_offsets, ray_counts, selbin, selw, block_total, block_offset, total;
-  DevBuf sample_key, sample_w, raw;
+  DevBuf sample_key, sample_w, raw, sample_z;
+  DepthMap dm{};
   int shade_grid[3] = {0, 0, 0};
 };
 
@@ -125,6 +126,7 @@ struct ModelSetup {
   int mult_mode = 1;
   int fp0 = 10, fd0 = 4, fp1 = 10, fd1 = 4;
   std::vector<float> ztab;
+  DepthMap dm{};
 };
 
 Elem elem_of(int prec) {
@@ -156,8 +158,16 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
     return bad(ADANERF_EUNSUPPORTED, "inFeatures must be [SpherePosDir, RayMarchFromPoses]");
   if (cf.posEnc.size() != 2 || cf.posEnc[0] != "nerf" || cf.posEnc[1] != "nerf" || cf.posEncArgs.size() != 2)
     return bad(ADANERF_EUNSUPPORTED, "posEnc must be [nerf, nerf] with two posEncArgs entries");
-  if (cf.rayMarchSampler.size() != 2 || !contains(cf.rayMarchSampler[1], "FromClassifiedDepthAdaptive"))
-    return bad(ADANERF_EUNSUPPORTED, "rayMarchSampler[1] must be FromClassifiedDepthAdaptive[NoDepthRange]");
+  const bool pdf_mode = cf.rayMarchSampler.size() == 2 && cf.rayMarchSampler[1] == "FromClassifiedDepth";
+  if (cf.rayMarchSampler.size() != 2 || (!pdf_mode && !contains(cf.rayMarchSampler[1], "FromClassifiedDepthAdaptive")))
+    return bad(ADANERF_EUNSUPPORTED, "rayMarchSampler[1] must be FromClassifiedDepthAdaptive[NoDepthRange] or FromClassifiedDepth");
+  if (pdf_mode) {
+    // the oracle-output transform follows losses[0] (src/nerf_raymarch_common.py:624-630); the viewer's samplePDF
+    // always applies the sigmoid (base_cuda_kernels.cu:296-372).  Softmax variants are not on this path.
+    if (!cf.losses.empty() && cf.losses[0] != "BCEWithLogitsLoss")
+      return bad(ADANERF_EUNSUPPORTED, "FromClassifiedDepth is supported with losses[0] == BCEWithLogitsLoss (sigmoid) only");
+    if (cf.useNDC) return bad(ADANERF_EUNSUPPORTED, "FromClassifiedDepth with useNDC is not supported");
+  }
   for (int v : cf.raySampleInput)
     if (v != 0) return bad(ADANERF_EUNSUPPORTED, "raySampleInput != 0 is outside the supported path");
   if (cf.viewcellCenter.size() != 3 || cf.viewcellSize.size() != 3 || cf.depthRange.size() != 2 || cf.fov <= 0.f)
@@ -184,6 +194,7 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
 
   int n_max = opt->num_samples > 0 ? opt->num_samples : cf.numRaymarchSamples.back();
   float thr = opt->threshold >= 0.f ? opt->threshold : cf.adaptiveSamplingThreshold;
+  if (pdf_mode) thr = 1.0f;   // unused by the inverse-CDF sampler; any positive value keeps the bin-centre depth table
   if (thr < 0.f) return bad(ADANERF_EUNSUPPORTED, "adaptiveSamplingThreshold < 0 is unsupported on the adaptive path (as in the reference)");
   if (thr == 0.f && n_max != kBins) return bad(ADANERF_EUNSUPPORTED, "adaptiveSamplingThreshold == 0 (dense) requires numRaymarchSamples == 128");
   if (n_max < 1 || n_max > kBins) return bad(ADANERF_EINVAL, "numRaymarchSamples must be in 1..128");
@@ -212,6 +223,7 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   I.threshold = thr;
   I.dense = thr == 0.f;
   I.use_ndc = ndc;
+  I.sampler_mode = pdf_mode ? ADANERF_SAMPLER_PDF : ADANERF_SAMPLER_ADAPTIVE;
   I.precision = opt->precision;
   I.fov = cf.fov;
   const double fov = cf.fov;
@@ -258,6 +270,9 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   sp.unit_dir = ndc;
   sp.ztab = nullptr;
 
+  ms->dm.d0 = cf.depthRange[0];
+  ms->dm.d1 = cf.depthRange[1];
+  ms->dm.log_transform = cf.depthTransform == "log";
   // ---- depth table: world depth of each of the 128 bins (A4/A5) ----
   ms->ztab.resize(kBins);
   const float znear = cf.zNear.empty() ? 0.001f : cf.zNear.back();
@@ -312,6 +327,7 @@ int ensure_batch_buffers(adanerf_ctx* c, int n_rays, int n_max) {
   if ((rc = dev_alloc(c, &c->sample_key, S * sizeof(uint32_t)))) return rc;
   if ((rc = dev_alloc(c, &c->sample_w, S * sizeof(float)))) return rc;
   if ((rc = dev_alloc(c, &c->raw, S * 4 * sizeof(float)))) return rc;
+  if (c->info.sampler_mode == ADANERF_SAMPLER_PDF && (rc = dev_alloc(c, &c->sample_z, S * sizeof(float)))) return rc;
   c->cap_rays = n_rays;
   c->cap_nmax = n_max;
   return ADANERF_OK;
@@ -387,7 +403,7 @@ int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max,
 constexpr int kShadeWaves = ADN_SHADE_WAVES;
 
 int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, const int32_t* d_total, int max_samples, int prec,
-                     float* d_raw) {
+                     float* d_raw, const float* d_z = nullptr) {
   if (max_samples <= 0) return ADANERF_OK;
   int rc = ensure_net1(c, prec);
   if (rc) return rc;
@@ -396,6 +412,7 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
   a.net = c->net1[prec].params;
   a.rays = d_rays;
   a.sample_key = d_key;
+  a.sample_z = d_z;
   a.total = d_total;
   a.max_samples = max_samples;
   a.raw_out = d_raw;
@@ -417,6 +434,24 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
                          c->stream, a);
     }
   }
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+int launch_sample_pdf(adanerf_ctx* c, const float* d_oracle, int n_rays, int n, int32_t* d_off, int32_t* d_cnt, uint32_t* d_key, float* d_w,
+                      float* d_z, int32_t* d_total) {
+  if (n_rays <= 0) return ADANERF_OK;
+  const int grid = std::min((n_rays + 3) / 4, c->info.compute_units * 8);
+  hipLaunchKernelGGL(pdf_sample_kernel, dim3(grid), dim3(256), 0, c->stream, d_oracle, n_rays, n, c->dm, d_off, d_cnt, d_key, d_w, d_z, d_total);
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+int launch_composite_classic(adanerf_ctx* c, const float* d_raw, const float* d_z, const float* d_rays, int n_rays, int n, float* d_rgb,
+                             void* d_rgba8) {
+  if (n_rays <= 0) return ADANERF_OK;
+  hipLaunchKernelGGL(composite_classic_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw),
+                     d_z, d_rays, n_rays, n, d_rgb, reinterpret_cast<uchar4*>(d_rgba8));
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;
 }
@@ -460,6 +495,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   c->rg = ms.rg;
   c->sp = ms.sp;
   c->mult_mode = ms.mult_mode;
+  c->dm = ms.dm;
   c->fp0 = ms.fp0;
   c->fd0 = ms.fd0;
   c->fp1 = ms.fp1;
@@ -571,7 +607,7 @@ int adanerf_destroy(adanerf_ctx* c) {
   for (int32_t* p : c->pinned_totals) (void)hipHostFree(p);
   DevBuf* bufs[] = {&c->net0_split.w, &c->net0_split.b, &c->overflow, &c->net0.w, &c->net0.b, &c->net1[0].w, &c->net1[0].b, &c->net1[1].w, &c->net1[1].b, &c->net1[2].w, &c->net1[2].b,
                     &c->ztab, &c->rays, &c->oracle, &c->ray_offsets, &c->ray_counts, &c->selbin, &c->selw, &c->block_total,
-                    &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw};
+                    &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw, &c->sample_z};
   for (DevBuf* b : bufs) dev_free(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -646,6 +682,29 @@ int adanerf_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key
   if (!c) return ADANERF_EINVAL;
   if (!d_rays || !d_key || !d_raw || max_samples < 0) return fail(c, ADANERF_EINVAL, "bad argument");
   return launch_shade_mlp(c, d_rays, d_key, d_total, max_samples, precision < 0 ? c->info.precision : precision, d_raw);
+}
+
+int adanerf_shade_mlp_z(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, const float* d_z, const int32_t* d_total,
+                        int32_t max_samples, int32_t precision, float* d_raw) {
+  if (!c) return ADANERF_EINVAL;
+  if (!d_rays || !d_key || !d_raw || max_samples < 0) return fail(c, ADANERF_EINVAL, "bad argument");
+  return launch_shade_mlp(c, d_rays, d_key, d_total, max_samples, precision < 0 ? c->info.precision : precision, d_raw, d_z);
+}
+
+int adanerf_sample_pdf(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, int32_t n, int32_t* d_off, int32_t* d_cnt, uint32_t* d_key,
+                       float* d_w, float* d_z, int32_t* d_total) {
+  if (!c) return ADANERF_EINVAL;
+  if (!d_oracle || !d_off || !d_cnt || !d_key || !d_w || !d_z || !d_total) return fail(c, ADANERF_EINVAL, "NULL buffer");
+  if (n_rays < 0 || n < 1 || n > 4096) return fail(c, ADANERF_EINVAL, "n_rays/n out of range");
+  if (static_cast<int64_t>(n_rays) * n > 0x7fffffffll || n_rays >= (1 << 25)) return fail(c, ADANERF_EINVAL, "n_rays * n too large");
+  return launch_sample_pdf(c, d_oracle, n_rays, n, d_off, d_cnt, d_key, d_w, d_z, d_total);
+}
+
+int adanerf_composite_classic(adanerf_ctx* c, const float* d_raw, const float* d_z, const float* d_rays, int32_t n_rays, int32_t n,
+                              float* d_rgb, void* d_rgba8) {
+  if (!c) return ADANERF_EINVAL;
+  if (!d_raw || !d_z || !d_rays || n_rays < 0 || n < 1) return fail(c, ADANERF_EINVAL, "bad argument");
+  return launch_composite_classic(c, d_raw, d_z, d_rays, n_rays, n, d_rgb, d_rgba8);
 }
 
 int adanerf_composite(adanerf_ctx* c, const float* d_raw, const float* d_w, const int32_t* d_off, const int32_t* d_cnt, int32_t n_rays,
@@ -730,15 +789,21 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     if ((rc = launch_sample_mlp(c, first, n, oracle, rays))) return rc;
     if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
-    if ((rc = launch_compact(c, oracle, n, N, thr, off, cnt, key, sw, total))) return rc;
+    float* sz = reinterpret_cast<float*>(c->sample_z.p);
+    const bool pdf = c->info.sampler_mode == ADANERF_SAMPLER_PDF;
+    if (pdf) rc = launch_sample_pdf(c, oracle, n, N, off, cnt, key, sw, sz, total);
+    else rc = launch_compact(c, oracle, n, N, thr, off, cnt, key, sw, total);
+    if (rc) return rc;
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     const int64_t max_s = static_cast<int64_t>(n) * N;
     if (max_s > 0x7fffffffll) return fail(c, ADANERF_EINVAL, "batch_rays * num_samples exceeds 2^31; use a smaller batch");
-    if ((rc = launch_shade_mlp(c, rays, key, total, static_cast<int>(max_s), c->info.precision, raw))) return rc;
+    if ((rc = launch_shade_mlp(c, rays, key, total, static_cast<int>(max_s), c->info.precision, raw, pdf ? sz : nullptr))) return rc;
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
-    if ((rc = launch_composite(c, raw, sw, off, cnt, n, d_rgb ? d_rgb + static_cast<size_t>(first) * 3 : nullptr,
-                               d_rgba8 ? static_cast<char*>(d_rgba8) + static_cast<size_t>(first) * 4 : nullptr)))
-      return rc;
+    float* rgb_b = d_rgb ? d_rgb + static_cast<size_t>(first) * 3 : nullptr;
+    void* rgba_b = d_rgba8 ? static_cast<char*>(d_rgba8) + static_cast<size_t>(first) * 4 : nullptr;
+    if (pdf) rc = launch_composite_classic(c, raw, sz, rays, n, N, rgb_b, rgba_b);
+    else rc = launch_composite(c, raw, sw, off, cnt, n, rgb_b, rgba_b);
+    if (rc) return rc;
     if (ev) {
       HIP_TRY(c, hipEventRecord(ev[4], c->stream));
       HIP_TRY(c, hipMemcpyAsync(c->pinned_totals[c->events_used / 5], total, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -834,6 +899,7 @@ int adanerf_get_buffer(adanerf_ctx* c, int32_t which, void** d_out, size_t* byte
     case ADANERF_BUF_SAMPLE_W: b = &c->sample_w; break;
     case ADANERF_BUF_RAW: b = &c->raw; break;
     case ADANERF_BUF_TOTAL: b = &c->total; break;
+    case ADANERF_BUF_SAMPLE_Z: b = &c->sample_z; break;
     default: return fail(c, ADANERF_EINVAL, "unknown buffer id");
   }
   *d_out = b->p;

@@ -89,6 +89,7 @@ void Config::store(std::string key, std::string value) {
   else if (key == "rayMarchSampler") rayMarchSampler = L;
   else if (key == "rayMarchNormalization") rayMarchNormalization = L;
   else if (key == "activation") activation = L;
+  else if (key == "losses") losses = L;
   else if (key == "numRaymarchSamples") numRaymarchSamples = to_ints(L);
   else if (key == "rayMarchSamplingStep") rayMarchSamplingStep = to_floats(L);
   else if (key == "rayMarchSamplingNoise") rayMarchSamplingNoise = to_floats(L);

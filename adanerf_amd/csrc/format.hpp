@@ -24,6 +24,7 @@ struct Config {
   std::vector<std::string> posEnc, inFeatures, outFeatures;
   std::vector<int> numRaymarchSamples;
   std::vector<std::string> rayMarchSampler, rayMarchNormalization, activation;
+  std::vector<std::string> losses;   // training config key; only losses[0] matters (oracle output transform)
   std::vector<float> rayMarchSamplingStep, rayMarchSamplingNoise;
   std::vector<int> raySampleInput, multiDepthFeatures;
   std::string depthTransform = "linear";

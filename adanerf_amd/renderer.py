@@ -21,7 +21,8 @@ from .build import library_path
 PREC_BF16, PREC_FP16, PREC_FP32 = 0, 1, 2
 _PREC = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "fp32": PREC_FP32, "f32": PREC_FP32}
 
-BUF_RAYS, BUF_ORACLE, BUF_RAY_OFFSETS, BUF_RAY_COUNTS, BUF_SAMPLE_KEY, BUF_SAMPLE_W, BUF_RAW, BUF_TOTAL = range(8)
+BUF_RAYS, BUF_ORACLE, BUF_RAY_OFFSETS, BUF_RAY_COUNTS, BUF_SAMPLE_KEY, BUF_SAMPLE_W, BUF_RAW, BUF_TOTAL, BUF_SAMPLE_Z = range(9)
+SAMPLER_ADAPTIVE, SAMPLER_PDF = 0, 1
 
 
 class AdaNeRFError(RuntimeError):
@@ -41,7 +42,7 @@ class Info(C.Structure):
                 ("num_samples", C.c_int32), ("threshold", C.c_float), ("dense", C.c_int32), ("use_ndc", C.c_int32),
                 ("precision", C.c_int32), ("compute_units", C.c_int32), ("fov", C.c_float), ("focal", C.c_float),
                 ("view_cell_center", C.c_float * 3), ("view_cell_radius", C.c_float), ("depth_range", C.c_float * 2),
-                ("max_depth", C.c_float)]
+                ("max_depth", C.c_float), ("sampler_mode", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -54,7 +55,8 @@ class Stats(C.Structure):
 EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_last_error", "adanerf_set_camera",
            "adanerf_render", "adanerf_assemble_strips", "adanerf_sync", "adanerf_set_stream", "adanerf_set_profiling",
            "adanerf_collect_stats", "adanerf_ray_features", "adanerf_sample_mlp",
-           "adanerf_compact", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_composite", "adanerf_malloc",
+           "adanerf_compact", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_shade_mlp_z", "adanerf_sample_pdf",
+           "adanerf_composite", "adanerf_composite_classic", "adanerf_malloc",
            "adanerf_free", "adanerf_memcpy_h2d", "adanerf_memcpy_d2h", "adanerf_get_buffer"]
 
 _lib = None
@@ -88,6 +90,9 @@ def load_library(path: Optional[str] = None):
     lib.adanerf_shade_features.argtypes = [vp, vp, vp, i32, vp]
     lib.adanerf_shade_mlp.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     lib.adanerf_composite.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
+    lib.adanerf_shade_mlp_z.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
+    lib.adanerf_sample_pdf.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.adanerf_composite_classic.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     lib.adanerf_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.adanerf_free.argtypes = [vp, vp]
     lib.adanerf_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -304,6 +309,18 @@ class NeuralRenderer:
     def shade_mlp(self, rays, sample_key, total, max_samples: int, raw_out, precision: int = -1):
         self._check(self.lib.adanerf_shade_mlp(self.handle, _ptr(rays), _ptr(sample_key), _ptr(total), max_samples,
                                                precision, _ptr(raw_out)))
+
+    def shade_mlp_z(self, rays, sample_key, sample_z, total, max_samples: int, raw_out, precision: int = -1):
+        self._check(self.lib.adanerf_shade_mlp_z(self.handle, _ptr(rays), _ptr(sample_key), _ptr(sample_z), _ptr(total),
+                                                 max_samples, precision, _ptr(raw_out)))
+
+    def sample_pdf(self, oracle, n_rays: int, n: int, ray_offsets, ray_counts, sample_key, sample_w, sample_z, total):
+        self._check(self.lib.adanerf_sample_pdf(self.handle, _ptr(oracle), n_rays, n, _ptr(ray_offsets), _ptr(ray_counts),
+                                                _ptr(sample_key), _ptr(sample_w), _ptr(sample_z), _ptr(total)))
+
+    def composite_classic(self, raw, sample_z, rays, n_rays: int, n: int, rgb_out=None, rgba8_out=None):
+        self._check(self.lib.adanerf_composite_classic(self.handle, _ptr(raw), _ptr(sample_z), _ptr(rays), n_rays, n,
+                                                       _ptr(rgb_out), _ptr(rgba8_out)))
 
     def composite(self, raw, sample_w, ray_offsets, ray_counts, n_rays: int, rgb_out=None, rgba8_out=None):
         self._check(self.lib.adanerf_composite(self.handle, _ptr(raw), _ptr(sample_w), _ptr(ray_offsets), _ptr(ray_counts),

@@ -64,6 +64,13 @@ enum {
   ADANERF_SAMPLING_FP32 = 1        /* v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain */
 };
 
+/* sample placement (config.ini rayMarchSampler[1]) */
+enum {
+  ADANERF_SAMPLER_ADAPTIVE = 0, /* FromClassifiedDepthAdaptive[NoDepthRange]: AdaNeRF top-N / threshold selection */
+  ADANERF_SAMPLER_PDF = 1       /* FromClassifiedDepth: DONeRF inverse-CDF sampling of sigmoid(oracle), fixed N samples
+                                   per ray, classic sigma/delta compositing */
+};
+
 /* arithmetic of the shading MLP's MFMA path */
 enum {
   ADANERF_PREC_BF16 = 0,  /* v_mfma_f32_32x32x16_bf16, fp32 accumulate */
@@ -106,6 +113,7 @@ typedef struct adanerf_info {
   float   view_cell_radius;
   float   depth_range[2];
   float   max_depth;
+  int32_t sampler_mode;     /* ADANERF_SAMPLER_* (from rayMarchSampler[1]) */
 } adanerf_info;
 
 /* per-frame statistics: the fields the reference logs every 100 frames
@@ -202,6 +210,24 @@ int adanerf_shade_features(adanerf_ctx* ctx, const float* d_rays, const uint32_t
 int adanerf_shade_mlp(adanerf_ctx* ctx, const float* d_rays, const uint32_t* d_sample_key,
                       const int32_t* d_total, int32_t max_samples, int32_t precision, float* d_raw_out);
 
+/* As adanerf_shade_mlp with an explicit world depth per sample (d_sample_z [S] fp32, may be NULL -> the bin
+ * centre of sample_key's bin): the inverse-CDF sampler places samples anywhere inside a bin. */
+int adanerf_shade_mlp_z(adanerf_ctx* ctx, const float* d_rays, const uint32_t* d_sample_key, const float* d_sample_z,
+                        const int32_t* d_total, int32_t max_samples, int32_t precision, float* d_raw_out);
+
+/* DONeRF sampler (reference: updateRayMarchFromPoses / samplePDF, include/cuda/adanerf_cuda_kernels.cuh:47-52,
+ * src/cuda/base_cuda_kernels.cu:296-372; PyTorch: FromClassifiedDepth + nerf_sample_pdf): n samples per ray by
+ * inverting the CDF of sigmoid(oracle) + 1e-5 at u = k/(n+1).  Outputs as adanerf_compact plus d_sample_z
+ * [n_rays*n] world depths; counts are all n; sample_w is zero-filled. */
+int adanerf_sample_pdf(adanerf_ctx* ctx, const float* d_oracle, int32_t n_rays, int32_t n, int32_t* d_ray_offsets,
+                       int32_t* d_ray_counts, uint32_t* d_sample_key, float* d_sample_w, float* d_sample_z,
+                       int32_t* d_total);
+
+/* Classic NeRF compositing over a fixed n samples per ray (reference: copyResultRaymarch / nerf_raw_2_output,
+ * adanerf_cuda_kernels.cuh:23-24; PyTorch nerf_raw2outputs): alpha = 1 - exp(-relu(raw.a) * dz * |dir|). */
+int adanerf_composite_classic(adanerf_ctx* ctx, const float* d_raw, const float* d_sample_z, const float* d_rays,
+                              int32_t n_rays, int32_t n, float* d_rgb_out, void* d_rgba8_out);
+
 /* Per-ray front-to-back compositing: c = sigmoid(raw.rgb), a = sigmoid(raw.a) * w. */
 int adanerf_composite(adanerf_ctx* ctx, const float* d_raw, const float* d_sample_w,
                       const int32_t* d_ray_offsets, const int32_t* d_ray_counts, int32_t n_rays,
@@ -222,7 +248,8 @@ enum {
   ADANERF_BUF_SAMPLE_KEY = 4,  /* [S] uint32 */
   ADANERF_BUF_SAMPLE_W = 5,    /* [S] fp32 */
   ADANERF_BUF_RAW = 6,         /* [S,4] fp32 */
-  ADANERF_BUF_TOTAL = 7        /* [1] int32 */
+  ADANERF_BUF_TOTAL = 7,       /* [1] int32 */
+  ADANERF_BUF_SAMPLE_Z = 8     /* [S] fp32 (ADANERF_SAMPLER_PDF only) */
 };
 int adanerf_get_buffer(adanerf_ctx* ctx, int32_t which, void** d_out, size_t* bytes_out);
 

@@ -76,6 +76,9 @@ class Scene:
     pos_enc: Tuple[Tuple[int, int], Tuple[int, int]] = ((10, 4), (10, 4))
     normalization: str = "InverseSqrtDistCentered"   # rayMarchNormalization[1]
     accumulation_mult: str = "alpha"
+    # "FromClassifiedDepthAdaptive" (AdaNeRF) or "FromClassifiedDepth" (DONeRF inverse-CDF sampling)
+    sampler: str = "FromClassifiedDepthAdaptive"
+    losses0: str = "NeRFWeightMultiplicationLoss"    # losses[0]: BCEWithLogitsLoss -> sigmoid on the oracle output
 
     @property
     def radius(self) -> float:
@@ -124,6 +127,10 @@ def load_scene(model_dir: str, num_samples: Optional[int] = None,
         normalization=norm[-1] if norm else "None",
         accumulation_mult=kv.get("accumulationMult", ""),
     )
+    smp = _parse_list(kv.get("rayMarchSampler", "[none,FromClassifiedDepthAdaptive]"))
+    sc.sampler = "FromClassifiedDepth" if smp[-1] == "FromClassifiedDepth" else "FromClassifiedDepthAdaptive"
+    ls = _parse_list(kv.get("losses", "[NeRFWeightMultiplicationLoss,MSE]"))
+    sc.losses0 = ls[0] if ls else "NeRFWeightMultiplicationLoss"
     if num_samples is not None:
         sc.num_samples = num_samples
     if threshold is not None:
@@ -302,7 +309,10 @@ def write_model_dir(path: str, scene: Scene, weights: Weights) -> None:
     src/export.py:47-54)."""
     os.makedirs(path, exist_ok=True)
     sampler = "FromClassifiedDepthAdaptiveNoDepthRange" if scene.use_ndc else "FromClassifiedDepthAdaptive"
+    if scene.sampler == "FromClassifiedDepth":
+        sampler = "FromClassifiedDepth"
     with open(os.path.join(path, "config.ini"), "w") as f:
+        f.write("losses = [%s, MSE]\n" % scene.losses0)
         f.write("posEnc = [nerf, nerf]\n")
         f.write("posEncArgs = [%d-%d, %d-%d]\n" % (scene.pos_enc[0] + scene.pos_enc[1]))
         f.write("inFeatures = [SpherePosDir, RayMarchFromPoses]\n")
@@ -521,6 +531,44 @@ def to_world_depth(t: np.ndarray, scene: Scene) -> np.ndarray:
     return (t * F32(d1 - d0) + F32(d0)).astype(F32)
 
 
+def sample_pdf(orc: np.ndarray, n: int) -> np.ndarray:
+    """DONeRF sampler: FromClassifiedDepth.generate, src/nerf_raymarch_common.py:606-660, with
+    the BCEWithLogitsLoss transform (sigmoid), then nerf_sample_pdf (:160-192) with det=True over the 129 bin
+    edges linspace(0,1,129), n+2 uniform u values, first and last dropped.  Returns warped depths t [R,n]."""
+    w = (sigmoid(orc) + F32(1e-5)).astype(F32)
+    pdf = (w / np.sum(w, axis=-1, keepdims=True, dtype=F32)).astype(F32)
+    cdf = np.cumsum(pdf, axis=-1, dtype=F32)
+    cdf = np.concatenate([np.zeros_like(cdf[:, :1]), cdf], axis=-1)          # [R,129]
+    bins = np.linspace(0.0, 1.0, orc.shape[1] + 1, dtype=F32)
+    u = np.linspace(0.0, 1.0, n + 2, dtype=F32)
+    out = np.empty((orc.shape[0], n + 2), dtype=F32)
+    for k in range(n + 2):
+        inds = np.sum(cdf <= u[k], axis=1)                                     # searchsorted(..., right=True)
+        below = np.maximum(inds - 1, 0)
+        above = np.minimum(inds, cdf.shape[1] - 1)
+        c0 = np.take_along_axis(cdf, below[:, None], 1)[:, 0]
+        c1 = np.take_along_axis(cdf, above[:, None], 1)[:, 0]
+        denom = (c1 - c0).astype(F32)
+        denom = np.where(denom < F32(1e-5), F32(1.0), denom)
+        t = ((u[k] - c0) / denom).astype(F32)
+        out[:, k] = (bins[below] + t * (bins[above] - bins[below])).astype(F32)
+    return out[:, 1:-1]
+
+
+def composite_classic(raw: np.ndarray, z: np.ndarray, rays_d: np.ndarray) -> np.ndarray:
+    """nerf_raw2outputs, src/nerf_raymarch_common.py:19-68 (no noise, no white background, no oracle weights):
+    alpha = 1 - exp(-relu(raw_a) * dist * |d|), dist = z[k+1] - z[k] (last 1e10), rgb = sigmoid(raw).
+    raw [R,N,4], z [R,N] world depths, rays_d [R,3] -> [R,3]."""
+    raw = raw.astype(F32)
+    dists = np.concatenate([z[:, 1:] - z[:, :-1], np.full((z.shape[0], 1), 1e10, dtype=F32)], -1).astype(F32)
+    dists = (dists * np.sqrt(np.sum(rays_d * rays_d, -1, keepdims=True, dtype=F32))).astype(F32)
+    rgb = sigmoid(raw[..., :3])
+    alpha = (F32(1.0) - np.exp(-np.maximum(raw[..., 3], F32(0)) * dists, dtype=F32)).astype(F32)
+    trans = np.cumprod(np.concatenate([np.ones((alpha.shape[0], 1), F32), F32(1.0) - alpha + F32(1e-10)], -1), -1, dtype=F32)[:, :-1]
+    wts = (alpha * trans).astype(F32)
+    return np.sum(wts[..., None] * rgb, -2, dtype=F32).astype(F32)
+
+
 # --------------------------------------------------------------------------------------
 # A5  sample position + normalisation + shading PE
 # --------------------------------------------------------------------------------------
@@ -631,6 +679,20 @@ def render_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: 
         nds, p = world_rays(dc, pose, rot, scene)
         feat0 = oracle_features(nds, p, scene)
         orc = sampling_mlp(feat0, weights.net0)
+        if scene.sampler == "FromClassifiedDepth":
+            r, n = orc.shape[0], scene.num_samples
+            tt = sample_pdf(orc, n)
+            z2 = to_world_depth(tt, scene)
+            sray = np.repeat(np.arange(r, dtype=np.int32), n)
+            feat1 = shading_inputs(p, nds, sray, z2.reshape(-1), scene, w, h)
+            raw = shading_mlp(feat1, weights.net1, n_pos)
+            rgb = composite_classic(raw.reshape(r, n, 4), z2, nds)
+            out_rgb.append(rgb)
+            out_cnt.append(np.full(r, n, dtype=np.int32))
+            if keep:
+                for k, v in dict(nds=nds, p=p, feat0=feat0, orc=orc, z=z2.reshape(-1), t=tt, feat1=feat1, raw=raw).items():
+                    kept.setdefault(k, []).append(v)
+            continue
         if scene.threshold == 0.0:
             r = orc.shape[0]
             count = np.full(r, D_BINS, dtype=np.int32)

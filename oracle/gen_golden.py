@@ -52,18 +52,20 @@ def import_reference():
 def make_config(scene: O.Scene):
     n = scene.num_samples
     sampler = "FromClassifiedDepthAdaptiveNoDepthRange" if scene.use_ndc else "FromClassifiedDepthAdaptive"
+    if scene.sampler == "FromClassifiedDepth":
+        sampler = "FromClassifiedDepth"
     return SimpleNamespace(
         inFeatures=["SpherePosDir", "RayMarchFromPoses"], outFeatures=["Raw", "RGBARayMarch"],
         posEnc=["nerf", "nerf"],
         posEncArgs=["%d-%d" % scene.pos_enc[0], "%d-%d" % scene.pos_enc[1]],
         raySampleInput=[0, 0], multiDepthFeatures=[128, 128], multiDepthIgnoreValue=[1.01, 1.01],
         multiDepthWindowSize=[], activation=["relu", "nerf"], layers=[8, 8], layerWidth=[256, 256],
-        skips=["", "auto"], losses=["NeRFWeightMultiplicationLoss", "MSE"],
+        skips=["", "auto"], losses=[scene.losses0, "MSE"],
         numRaymarchSamples=[n, n], rayMarchSampler=["none", sampler],
         rayMarchSamplingStep=[1 / 128.0, 1 / 128.0], rayMarchSamplingNoise=[0.0, 0.0],
         rayMarchNormalization=["InverseSqrtDistCentered", scene.normalization],
         rayMarchNormalizationCenter=[], adaptiveSamplingThreshold=scene.threshold,
-        accumulationMult=scene.accumulation_mult, zNear=[scene.z_near, scene.z_near],
+        accumulationMult=scene.accumulation_mult if scene.sampler != "FromClassifiedDepth" else None, zNear=[scene.z_near, scene.z_near],
         zFar=[scene.z_far, scene.z_far], trainWithGTDepth=False, deterministicSampling=False,
         useNDC=scene.use_ndc, perturb=False, device="cpu", storeFullData=True,
         depthTransform=scene.depth_transform)
@@ -122,8 +124,15 @@ def run_reference(R, tc, dirs, pose, rot, chunk=8192):
         raw = d1[K.network_output]
         zv = d1[K.nerf_input_feature_z_vals]
         f1 = d1[K.input_feature_batch]
-        ow = d1[K.oracle_weights]
-        if raw.dim() == 3:   # adaptive path restored to [R, N, 4] with zero fill / NaN markers
+        ow = d1[K.oracle_weights] if K.oracle_weights in d1 else torch.zeros((n, 1))
+        if K.oracle_weights not in d1:   # FromClassifiedDepth: [R*N,4] raw, [R,N] z, no selection
+            item["count"] = torch.full((n,), zv.shape[1], dtype=torch.int32)
+            item["z"] = zv.reshape(-1)
+            item["raw"] = raw
+            item["feat1"] = f1
+            item["wts_slot"] = ow
+            item["z_slot"] = zv
+        elif raw.dim() == 3:   # adaptive path restored to [R, N, 4] with zero fill / NaN markers
             fin = torch.isfinite(zv)
             item["count"] = fin.sum(1).to(torch.int32)
             item["z"] = zv[fin]
@@ -172,7 +181,10 @@ def subset_dirs(w, h, fov, x0, y0, cw, ch, stride=1):
 
 def save_case(name, scene, meta, dirs, pose, rot, ref, n_max, weights_tag):
     count = ref["count"].astype(np.int32)
-    if scene.threshold == 0.0:
+    if scene.sampler == "FromClassifiedDepth":
+        bins = np.zeros((count.shape[0], n_max), dtype=np.int16)
+        wts = np.zeros((count.shape[0], n_max), dtype=np.float32)
+    elif scene.threshold == 0.0:
         bins = np.repeat(np.arange(128, dtype=np.int16)[None], count.shape[0], 0)
         wts = ref["wts_slot"].astype(np.float32)
     else:
@@ -185,7 +197,7 @@ def save_case(name, scene, meta, dirs, pose, rot, ref, n_max, weights_tag):
                   z_far=scene.z_far, use_ndc=scene.use_ndc, depth_transform=scene.depth_transform,
                   pos_enc=[list(scene.pos_enc[0]), list(scene.pos_enc[1])],
                   normalization=scene.normalization, accumulation_mult=scene.accumulation_mult,
-                  weights=weights_tag))
+                  sampler=scene.sampler, losses0=scene.losses0, weights=weights_tag))
     n_f = min(64, ref["feat0"].shape[0])
     m_f = min(64, ref["feat1"].shape[0])
     raw = ref["raw"].astype(np.float32)
@@ -198,7 +210,7 @@ def save_case(name, scene, meta, dirs, pose, rot, ref, n_max, weights_tag):
         nds=ref["nds"].astype(np.float32), p=ref["p"].astype(np.float32),
         oracle_in=ref["feat0"][:n_f].astype(np.float32), oracle_out=ref["orc"].astype(np.float32),
         sel_count=count.astype(np.uint8), sel_bins=bins, sel_weight=wts,
-        z_world=ref["z"][:4096].astype(np.float32), shade_in=ref["feat1"][:m_f].astype(np.float32),
+        z_world=ref["z"][:16384].astype(np.float32), shade_in=ref["feat1"][:m_f].astype(np.float32),
         shade_out=raw, rgb=ref["rgb"].astype(np.float32))
     sz = os.path.getsize(os.path.join(GOLD, name + ".npz"))
     print("wrote %s.npz (%d KB)  rays=%d samples=%d mean=%.2f" %
@@ -349,6 +361,16 @@ def main():
     save_case("ndc_synthetic_n8", sc, dict(w=480, h=270, crop=[200, 100, 48, 32], yaw=0.0, pitch=0.0,
                                            syn=dict(seed=7, n_in0=30, oracle_bias=-0.55, oracle_scale=0.5)),
               dirs, pose_f, rot_f, ref, 8, "synthetic")
+
+    # --- case G: DONeRF-style inverse-CDF sampler + classic sigma/delta compositing
+    import dataclasses
+    sc = dataclasses.replace(classroom_scene(8, 0.2), sampler="FromClassifiedDepth", losses0="BCEWithLogitsLoss",
+                             accumulation_mult="")
+    dirs = subset_dirs(800, 800, sc.fov, 8, 10, 48, 32, 16)
+    tc = build_reference(R, sc, w_class, 800, 800)
+    ref = run_reference(R, tc, dirs, pose, rot)
+    save_case("classroom_pdf_n8", sc, dict(w=800, h=800, crop=[8, 10, 48, 32, 16], yaw=100.0, pitch=0.0),
+              dirs, pose, rot, ref, 8, "sample_pavillon_16")
 
     gen_selection_edge_cases(R)
 

@@ -25,7 +25,9 @@ def load_case(name):
                  num_samples=meta["num_samples"], threshold=meta["threshold"], z_near=meta["z_near"],
                  z_far=meta["z_far"], use_ndc=meta["use_ndc"], depth_transform=meta["depth_transform"],
                  pos_enc=(tuple(meta["pos_enc"][0]), tuple(meta["pos_enc"][1])),
-                 normalization=meta["normalization"], accumulation_mult=meta["accumulation_mult"])
+                 normalization=meta["normalization"], accumulation_mult=meta["accumulation_mult"],
+                 sampler=meta.get("sampler", "FromClassifiedDepthAdaptive"),
+                 losses0=meta.get("losses0", "NeRFWeightMultiplicationLoss"))
     return z, meta, sc
 
 
