@@ -615,3 +615,40 @@ def test_pdf_frame_matches_oracle(pdf_case, prec, min_psnr):
     # a displaced sample (ill-conditioned inverse, see above) moves one ray's colour; judge by PSNR + a robust bound
     assert O.psnr(rgb, ref["rgb"]) > min_psnr
     assert np.quantile(np.abs(rgb - ref["rgb"]), 0.99) < (2e-3 if prec == "fp32" else 3e-2)
+
+
+# ---------------------------------------------------------------------------------------------
+# dataset-directory evaluator (counterpart of src/evaluate.py's image evaluation)
+# ---------------------------------------------------------------------------------------------
+
+def test_dataset_evaluator_end_to_end(cases, tmp_path):
+    import json
+    from adanerf_amd.evaluate import evaluate
+    from adanerf_amd.png import read_png, write_png
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    w, h = 64, 48
+    ds = tmp_path / "dataset"
+    (ds / "test").mkdir(parents=True)
+    json.dump(dict(resolution=[w, h], camera_angle_x=sc.fov, view_cell_center=list(sc.view_cell_center),
+                   view_cell_size=list(sc.view_cell_size), flip_depth=False, depth_distance_adjustment=False),
+              open(ds / "dataset_info.json", "w"))
+    frames = []
+    poses = [(np.array(sc.view_cell_center, np.float32), O.camera_rotation(100.0, 0.0)),
+             (np.array(sc.view_cell_center, np.float32) + np.float32([0.1, 0.05, -0.02]), O.camera_rotation(60.0, -8.0))]
+    for i, (pose, rot) in enumerate(poses):
+        m = np.eye(4, dtype=np.float32)
+        m[:3, :3], m[:3, 3] = rot, pose
+        frames.append(dict(file_path="./test/%05d" % i, transform_matrix=m.tolist()))
+        gt = O.render_frame(sc, wts, w, h, pose, rot)["rgb"]                   # ground truth = the oracle's image
+        write_png(str(ds / "test" / ("%05d.png" % i)), O.to_rgba8(gt)[:, :3].reshape(h, w, 3))
+    json.dump(dict(frames=frames), open(ds / "transforms_test.json", "w"))
+    out = tmp_path / "pred"
+    summary, results = evaluate(d, str(ds), "test", str(out), precision="fp32", quiet=True)
+    assert summary["frames"] == 2 and 1.0 <= summary["mean_samples_per_ray"] <= 8.0
+    # fp32 path vs an 8-bit-quantised oracle image: error = quantisation only (uniform 1/255 truncation -> ~53 dB)
+    assert summary["mean_psnr"] > 48.0
+    pred = read_png(str(out / "00000.png"))
+    gt8 = read_png(str(ds / "test" / "00000.png"))
+    assert pred.shape == (h, w, 3) and (np.abs(pred.astype(np.int16) - gt8.astype(np.int16)) <= 1).mean() > 0.999
+    s2, _ = evaluate(d, str(ds), "test", None, precision="bf16", quiet=True)
+    assert s2["mean_psnr"] > 40.0

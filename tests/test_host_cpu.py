@@ -229,3 +229,68 @@ def test_package_model_dir_writer_round_trips(lib, tmp_path):
     assert wq.size == 1184 * 1024
     assert np.allclose(M.camera_rotation(100.0, 0.0), O.camera_rotation(100.0, 0.0))
     assert np.allclose(M.camera_rotation(-80.0, 10.0) @ M.camera_rotation(-80.0, 10.0).T, np.eye(3), atol=1e-6)
+
+
+def test_png_codec_round_trip_and_filters(tmp_path):
+    import struct
+    import zlib
+    from adanerf_amd.png import read_png, write_png
+    rng = np.random.default_rng(0)
+    for c in (3, 4):
+        img = rng.integers(0, 256, size=(17, 23, c), dtype=np.uint8)
+        p = str(tmp_path / ("a%d.png" % c))
+        write_png(p, img)
+        assert np.array_equal(read_png(p), img)
+    # hand-build a PNG that uses every scanline filter (what real encoders emit)
+    img = rng.integers(0, 256, size=(5, 7, 3), dtype=np.uint8)
+    bpp, stride = 3, 21
+    rows = bytearray()
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(5):
+        cur = img[y].reshape(-1).astype(np.int32)
+        ft = y % 5
+        enc = np.zeros(stride, dtype=np.int32)
+        for x in range(stride):
+            a = cur[x - bpp] if x >= bpp else 0
+            b = prev[x]
+            cc = prev[x - bpp] if x >= bpp else 0
+            if ft == 0:
+                pr = 0
+            elif ft == 1:
+                pr = a
+            elif ft == 2:
+                pr = b
+            elif ft == 3:
+                pr = (a + b) >> 1
+            else:
+                pa, pb, pc = abs(b - cc), abs(a - cc), abs(a + b - 2 * cc)
+                pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else cc)
+            enc[x] = (cur[x] - pr) & 255
+        rows += bytes([ft]) + bytes(enc.astype(np.uint8))
+        prev = cur
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+    p = str(tmp_path / "filters.png")
+    comp = zlib.compress(bytes(rows))
+    with open(p, "wb") as f:     # two IDAT chunks, like streaming encoders
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 7, 5, 8, 2, 0, 0, 0)) +
+                chunk(b"IDAT", comp[:10]) + chunk(b"IDAT", comp[10:]) + chunk(b"IEND", b""))
+    assert np.array_equal(read_png(p), img)
+
+
+def test_evaluator_dataset_loader(tmp_path):
+    import json
+    from adanerf_amd.evaluate import load_dataset, psnr_from_mse
+    d = tmp_path / "ds"
+    (d / "test").mkdir(parents=True)
+    json.dump(dict(resolution=[64, 48], camera_angle_x=1.1, view_cell_center=[0, 0, 0], view_cell_size=[1, 1, 1]),
+              open(d / "dataset_info.json", "w"))
+    m = np.eye(4)
+    m[:3, 3] = [1, 2, 3]
+    json.dump(dict(frames=[dict(file_path="./test/00000", transform_matrix=m.tolist())]), open(d / "transforms_test.json", "w"))
+    meta, frames = load_dataset(str(d), "test")
+    assert (meta["w"], meta["h"]) == (64, 48) and abs(meta["fov"] - 1.1) < 1e-9
+    assert np.allclose(frames[0]["pose"], [1, 2, 3]) and np.allclose(frames[0]["rot"], np.eye(3))
+    assert frames[0]["image"].endswith(os.path.join("test", "00000.png"))
+    assert abs(psnr_from_mse(0.01) - 20.0) < 1e-9
