@@ -841,6 +841,33 @@ __device__ __forceinline__ void load_sample(const ShadeArgs& a, int s, int total
   }
 }
 
+// Wave-private LDS stash for packed PE slots (hand-issued so hipcc neither orders them against the LDS-DMA
+// ring with vmcnt(0) nor keeps 24 VGPRs alive across the layer stack).  Layout [dword group of 4][lane]:
+// b128 accesses are lane-linear, hence conflict-free.
+template <int NQ>   // NQ = number of b128 groups
+__device__ __forceinline__ void lds_stash_write(uint32_t byte_addr, const uint32_t* v) {
+#pragma unroll
+  for (int g = 0; g < NQ; ++g) {
+    const u32x4 t = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+    asm volatile("ds_write_b128 %0, %1" ::"v"(byte_addr + g * 1024), "v"(t) : "memory");
+  }
+}
+template <int NQ>
+__device__ __forceinline__ void lds_stash_read(uint32_t byte_addr, uint32_t* v) {
+  u32x4 t[NQ];
+#pragma unroll
+  for (int g = 0; g < NQ; ++g) asm volatile("ds_read_b128 %0, %1" : "=&v"(t[g]) : "v"(byte_addr + g * 1024));
+  if (NQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[NQ > 3 ? 3 : 0]));
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[NQ > 1 ? 1 : 0]));
+#pragma unroll
+  for (int g = 0; g < NQ; ++g) {
+    v[4 * g] = t[g][0];
+    v[4 * g + 1] = t[g][1];
+    v[4 * g + 2] = t[g][2];
+    v[4 * g + 3] = t[g][3];
+  }
+}
+
 // A5+A6, 16-bit MFMA path.  Workgroup = WAVES waves x 32 samples; persistent over tiles; the weight
 // stream is cyclic so DMA prefetch runs across tile boundaries.  WAVES = 4 with two workgroups per CU
 // (two waves per SIMD from DIFFERENT workgroups): each workgroup has its own ring and barriers, so the
@@ -854,10 +881,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
   constexpr int kRingBytes = CF * RS * 1024;
   static_assert(CF % WAVES == 0 && CF % kRegFrags == 0 && kShadeFrags16 % CF == 0 && CF % 8 == 0 && CF <= 32, "chunk geometry");
   typedef WStream<CF, RS, LPW> WS;
-  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kShadeBiasFloats * 4];
+#ifndef ADN_STASH
+#define ADN_STASH 1   // 1: PE slots computed once per tile and parked in LDS; 0: sample re-loaded at layers 5 / view
+#endif
+  constexpr int kStashBytes = ADN_STASH ? WAVES * (QP / 8 + QD / 8) * 1024 : 0;
+  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kShadeBiasFloats * 4 + kStashBytes];
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int j = lane & 31, h = lane >> 5;
+  const uint32_t stash = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + kShadeBiasFloats * 4 +
+                         wave * (QP / 8 + QD / 8) * 1024 + lane * 16;
   int total = a.total ? *a.total : a.max_samples;
   if (total > a.max_samples) total = a.max_samples;
   const int ntiles = (total + TILE - 1) / TILE;
@@ -882,6 +915,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
       load_sample(a, s, total, x, dpe);
       uint32_t pts[QP / 2];
       pe_pack<ET, FP>(x, h, pts);
+      if (ADN_STASH) {
+        uint32_t dirs[QD / 2];
+        pe_pack<ET, FD>(dpe, h, dirs);
+        lds_stash_write<QP / 8>(stash, pts);
+        lds_stash_write<QD / 8>(stash + (QP / 8) * 1024, dirs);
+      }
       layer_16<ET, WS, QP / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, lane, pts, pts, hA);
     }
 #pragma unroll 1
@@ -892,10 +931,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
     {
       // the skip connection re-loads the sample and re-evaluates the 32 position slots instead of
       // holding 16 (+6) VGPRs across layers 1-4 (30 v_sin per lane vs ~600 MFMA issue slots)
-      float x[3], dpe[3];
-      load_sample(a, s, total, x, dpe);
       uint32_t pts[QP / 2];
-      pe_pack<ET, FP>(x, h, pts);
+      if (ADN_STASH) {
+        lds_stash_read<QP / 8>(stash, pts);
+      } else {
+        float x[3], dpe[3];
+        load_sample(a, s, total, x, dpe);
+        pe_pack<ET, FP>(x, h, pts);
+      }
       layer_16<ET, WS, QP / 8, 16, 8, true, 0>(st, bias0 + bo[5] * 4, lane, pts, hA, hB);   // cat([pts, h])
     }
     layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[6] * 4, lane, hB, hB, hA);
@@ -904,10 +947,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
     layer_16<ET, WS, 16, 0, 9, false, 0, 8>(st, bias0 + bo[8] * 4, lane, hB, hB, hA, &alpha_tile);      // feature (+alpha row)
     const float alpha = alpha_tile[0];
     {
-      float x[3], dpe[3];
-      load_sample(a, s, total, x, dpe);
       uint32_t dirs[QD / 2];
-      pe_pack<ET, FD>(dpe, h, dirs);
+      if (ADN_STASH) {
+        lds_stash_read<QD / 8>(stash + (QP / 8) * 1024, dirs);
+      } else {
+        float x[3], dpe[3];
+        load_sample(a, s, total, x, dpe);
+        pe_pack<ET, FD>(dpe, h, dirs);
+      }
       layer_16<ET, WS, 16, QD / 8, 4, true, (32 + 4 * 128 + 160 + 2 * 128 + 144) % CF>(st, bias0 + bo[9] * 4, lane, hA, dirs, hB);             // cat([feature, dir])
     }
     f32x16 rgb_tile;
