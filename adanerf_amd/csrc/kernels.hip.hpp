@@ -184,10 +184,12 @@ __device__ __forceinline__ int mbcnt64(uint64_t mask) {
 // ------------------------------------------------------------------------------------------
 
 // One layer for one 32-sample column block.  QS input slots (per lane-half), MT output tiles.
-template <int QS, int MT, bool RELU>
+// Input = two register segments (Q1 then Q2 slots; a concatenation costs nothing).
+template <int Q1, int Q2, int MT, bool RELU>
 __device__ __forceinline__ void layer_f32(const u32x4* __restrict__ w, const float* __restrict__ bias, int lane,
-                                          const float* in, float* out) {
-  static_assert(QS % 4 == 0, "fp32 engine groups 4 k-steps per 16-byte fragment");
+                                          const float* in1, const float* in2, float* out) {
+  constexpr int QS = Q1 + Q2;
+  static_assert(Q1 % 4 == 0 && Q2 % 4 == 0, "fp32 engine groups 4 k-steps per 16-byte fragment");
   const int h = lane >> 5;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -206,10 +208,11 @@ __device__ __forceinline__ void layer_f32(const u32x4* __restrict__ w, const flo
       // NB: load as a float vector.  __builtin_bit_cast(float, u32x4_value[i]) miscompiles on
       // ROCm 7.2 hipcc (every element reads lane register 0).
       const f32x4 a = reinterpret_cast<const f32x4*>(w)[(m * (QS / 4) + s4) * 64 + lane];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], in[4 * s4 + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], in[4 * s4 + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], in[4 * s4 + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], in[4 * s4 + 3], acc, 0, 0, 0);
+      const float* in = (4 * s4 < Q1) ? (in1 + 4 * s4) : (in2 + (4 * s4 - Q1));
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], in[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], in[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], in[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], in[3], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[16 * m + r] = RELU ? fmaxf(acc[r], 0.f) : acc[r];
@@ -251,13 +254,13 @@ __global__ __launch_bounds__(256) void sample_mlp_kernel(SampleArgs a) {
 
   const u32x4* w = a.net.w;
   const float* b = a.net.bias;
-  layer_f32<Q0, 8, true>(w + a.net.w_off[0], b + a.net.b_off[0], lane, bufA, bufB);
+  layer_f32<Q0, 0, 8, true>(w + a.net.w_off[0], b + a.net.b_off[0], lane, bufA, bufA, bufB);
 #pragma unroll 1
   for (int l = 1; l <= 5; l += 2) {
-    layer_f32<128, 8, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, bufB, bufA);
-    layer_f32<128, 8, true>(w + a.net.w_off[l + 1], b + a.net.b_off[l + 1], lane, bufA, bufB);
+    layer_f32<128, 0, 8, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, bufB, bufB, bufA);
+    layer_f32<128, 0, 8, true>(w + a.net.w_off[l + 1], b + a.net.b_off[l + 1], lane, bufA, bufA, bufB);
   }
-  layer_f32<128, 4, false>(w + a.net.w_off[7], b + a.net.b_off[7], lane, bufB, bufA);
+  layer_f32<128, 0, 4, false>(w + a.net.w_off[7], b + a.net.b_off[7], lane, bufB, bufB, bufA);
 
   if (valid) {
     if (a.oracle_out) {
@@ -981,33 +984,28 @@ __global__ __launch_bounds__(256) void shade_mlp32_kernel(ShadeArgs a) {
   for (int tile = blockIdx.x; tile * TILE < total; tile += gridDim.x) {
     const int s = tile * TILE + wave * 32 + j;
     if (tile * TILE + wave * 32 >= total) continue;
+    // the weight addresses do not depend on the tile: without this the compiler hoists every A-fragment
+    // load out of the tile loop (loop-invariant code motion) and spills thousands of registers
+    asm volatile("" : "+v"(w), "+v"(b));
     float x[3], dpe[3];
     load_sample(a, s, total, x, dpe);
-    // bufA/bufB: [pts slots QP | 128 activation slots]; layer 5 reads the concatenation in place
-    float bufA[QP + 128], bufB[QP + 128 + QD];
-    pe_eval<FP, true>(x, h, bufA);
-#pragma unroll
-    for (int q = 0; q < QP; ++q) bufB[q] = bufA[q];
-    float* hA = bufA + QP;
-    float* hB = bufB + QP;
-    layer_f32<QP, 8, true>(w + a.net.w_off[0], b + a.net.b_off[0], lane, bufA, hB);
+    float pts[QP], dirs[QD], hA[144], hB[128];      // hA also receives the 9-tile feature(+alpha) layer
+    pe_eval<FP, true>(x, h, pts);
+    pe_eval<FD, true>(dpe, h, dirs);
+    layer_f32<QP, 0, 8, true>(w + a.net.w_off[0], b + a.net.b_off[0], lane, pts, pts, hA);
 #pragma unroll 1
     for (int l = 1; l <= 3; l += 2) {
-      layer_f32<128, 8, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, hB, hA);
-      layer_f32<128, 8, true>(w + a.net.w_off[l + 1], b + a.net.b_off[l + 1], lane, hA, hB);
+      layer_f32<128, 0, 8, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, hA, hA, hB);
+      layer_f32<128, 0, 8, true>(w + a.net.w_off[l + 1], b + a.net.b_off[l + 1], lane, hB, hB, hA);
     }
-    // hB holds h4; bufB = [pts | h4]
-    layer_f32<QP + 128, 8, true>(w + a.net.w_off[5], b + a.net.b_off[5], lane, bufB, hA);
-    layer_f32<128, 8, true>(w + a.net.w_off[6], b + a.net.b_off[6], lane, hA, hB);
-    layer_f32<128, 8, true>(w + a.net.w_off[7], b + a.net.b_off[7], lane, hB, hA);
-    float feat[144 + QD];                 // 9 tiles (tile 8 = alpha row) then dir slots
-    layer_f32<128, 9, false>(w + a.net.w_off[8], b + a.net.b_off[8], lane, hA, feat);
-    const float alpha = feat[128];
-    pe_eval<FD, true>(dpe, h, feat + 128);   // overwrite tile 8 with the dir slots: [feature | dir]
-    float v[64];
-    layer_f32<128 + QD, 4, true>(w + a.net.w_off[9], b + a.net.b_off[9], lane, feat, v);
+    layer_f32<QP, 128, 8, true>(w + a.net.w_off[5], b + a.net.b_off[5], lane, pts, hA, hB);       // cat([pts, h])
+    layer_f32<128, 0, 8, true>(w + a.net.w_off[6], b + a.net.b_off[6], lane, hB, hB, hA);
+    layer_f32<128, 0, 8, true>(w + a.net.w_off[7], b + a.net.b_off[7], lane, hA, hA, hB);
+    layer_f32<128, 0, 9, false>(w + a.net.w_off[8], b + a.net.b_off[8], lane, hB, hB, hA);         // feature (+alpha row)
+    const float alpha = hA[128];
+    layer_f32<128, QD, 4, true>(w + a.net.w_off[9], b + a.net.b_off[9], lane, hA, dirs, hB);       // cat([feature, dir])
     float rgb[16];
-    layer_f32<64, 1, false>(w + a.net.w_off[10], b + a.net.b_off[10], lane, v, rgb);
+    layer_f32<64, 0, 1, false>(w + a.net.w_off[10], b + a.net.b_off[10], lane, hB, hB, rgb);
     if (h == 0 && s < total)
       *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(rgb[0], rgb[1], rgb[2], alpha);
   }
