@@ -459,8 +459,12 @@ int launch_composite_classic(adanerf_ctx* c, const float* d_raw, const float* d_
 int launch_composite(adanerf_ctx* c, const float* d_raw, const float* d_w, const int32_t* d_off, const int32_t* d_cnt, int n_rays,
                      float* d_rgb, void* d_rgba8) {
   if (n_rays <= 0) return ADANERF_OK;
-  hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw), d_w,
-                     d_off, d_cnt, n_rays, c->mult_mode, d_rgb, reinterpret_cast<uchar4*>(d_rgba8));
+  if (c->info.num_samples > 32)   // long rays (dense mode): one wave per ray, coalesced
+    hipLaunchKernelGGL(composite_wave_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw), d_w,
+                       d_off, d_cnt, n_rays, c->mult_mode, d_rgb, reinterpret_cast<uchar4*>(d_rgba8));
+  else
+    hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw), d_w,
+                       d_off, d_cnt, n_rays, c->mult_mode, d_rgb, reinterpret_cast<uchar4*>(d_rgba8));
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;
 }

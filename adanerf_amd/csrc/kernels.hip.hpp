@@ -1377,6 +1377,77 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict
   }
 }
 
+// Long rays (dense mode: 128 samples each): one wave per ray, lane holds samples (lane, lane + 64);
+// transmittance = exclusive product scan of (1 - alpha + 1e-10) across the wave, colour = wave sum.
+// Coalesced 16-byte loads instead of one thread striding through 2 KiB per ray.
+__device__ __forceinline__ float wave_incl_prod_f32(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float t = __shfl_up(v, off);
+    if (lane >= off) v *= t;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void composite_wave_kernel(const float4* __restrict__ raw, const float* __restrict__ sample_w,
+                                                             const int32_t* __restrict__ ray_offsets, const int32_t* __restrict__ counts,
+                                                             int n_rays, int mult_mode, float* __restrict__ rgb_out, uchar4* __restrict__ rgba8_out) {
+  const int lane = lane_id();
+  const int r = blockIdx.x * 4 + (static_cast<int>(threadIdx.x) >> 6);
+  if (r >= n_rays) return;
+  const int o = ray_offsets[r], c = counts[r];
+  float al[2], col[2][3];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = lane + 64 * u;
+    al[u] = 0.f;
+    col[u][0] = col[u][1] = col[u][2] = 0.f;
+    if (k < c) {
+      const float4 v = raw[o + k];
+      float a0 = sigmoidf_dev(v.w);
+      const float wv = sample_w[o + k];
+      if (mult_mode == 1) a0 = __fmul_rn(a0, wv);
+      al[u] = a0;
+      const float m = (mult_mode == 2) ? wv : 1.0f;
+      col[u][0] = sigmoidf_dev(v.x) * m;
+      col[u][1] = sigmoidf_dev(v.y) * m;
+      col[u][2] = sigmoidf_dev(v.z) * m;
+    }
+  }
+  const float f0 = __fadd_rn(__fsub_rn(1.0f, al[0]), 1e-10f), f1 = __fadd_rn(__fsub_rn(1.0f, al[1]), 1e-10f);
+  const float p0 = wave_incl_prod_f32(lane + 0 < c ? f0 : 1.0f, lane);
+  const float tot0 = __shfl(p0, 63);
+  const float p1 = wave_incl_prod_f32(lane + 64 < c ? f1 : 1.0f, lane);
+  float e0 = __shfl_up(p0, 1), e1 = __shfl_up(p1, 1);      // exclusive products
+  if (lane == 0) {
+    e0 = 1.0f;
+    e1 = 1.0f;
+  }
+  const float w0 = al[0] * e0, w1 = al[1] * (tot0 * e1);
+  float cr = w0 * col[0][0] + w1 * col[1][0], cg = w0 * col[0][1] + w1 * col[1][1], cb = w0 * col[0][2] + w1 * col[1][2];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    cr += __shfl_xor(cr, off);
+    cg += __shfl_xor(cg, off);
+    cb += __shfl_xor(cb, off);
+  }
+  if (lane == 0) {
+    if (rgb_out) {
+      rgb_out[3 * static_cast<size_t>(r) + 0] = cr;
+      rgb_out[3 * static_cast<size_t>(r) + 1] = cg;
+      rgb_out[3 * static_cast<size_t>(r) + 2] = cb;
+    }
+    if (rgba8_out) {
+      uchar4 px;
+      px.x = static_cast<unsigned char>(fminf(fmaxf(cr, 0.f), 1.f) * 255.0f);
+      px.y = static_cast<unsigned char>(fminf(fmaxf(cg, 0.f), 1.f) * 255.0f);
+      px.z = static_cast<unsigned char>(fminf(fmaxf(cb, 0.f), 1.f) * 255.0f);
+      px.w = 255;
+      rgba8_out[r] = px;
+    }
+  }
+}
+
 // multi-GPU: gathered [world][rays_local_max] uchar4 (rank-major) -> row-major image
 __global__ __launch_bounds__(256) void assemble_strips_kernel(const uchar4* __restrict__ gathered, uchar4* __restrict__ image, int w, int h,
                                                               int strip_rows, int world, int rays_local_max) {
