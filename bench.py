@@ -34,6 +34,9 @@ WORKLOADS = {
     "config2": (800, 800, 8, 0.2, "sample_pavillon_16"),
     "config3_dense": (800, 800, 128, 0.0, "sample_pavillon_16"),
     "config4": (800, 800, 8, 0.1, "sample_pavillon_16"),
+    # BASELINE configs[4]: 1920x1080 LLFF-NDC scene (2-2 oracle encoding, linear depth, no normalisation); no NDC
+    # weights ship with the reference -> seeded random-init weights; sweep the threshold with --threshold
+    "config5_ndc": (1920, 1080, 8, 0.2, "ndc_random_init"),
 }
 
 
@@ -49,6 +52,10 @@ def build_model_dir(td, tag, n, thr):
         n1 = {k[3:]: z[k] for k in z.files if k.startswith("n1/")}
         s = json.load(open(spath))
         data = "synthetic rays; weights = reference's exported %s model (fixture)" % tag
+    elif tag == "ndc_random_init":
+        n0, n1 = M.random_init_weights(7, n_in0=30, oracle_bias=-0.55, oracle_scale=0.5)
+        s = dict(view_cell_center=(0.0, 0.0, 0.0), view_cell_size=(2.0, 2.0, 1.0), depth_range=(0.9, 12.0), fov=1.0, max_depth=12.0)
+        data = "synthetic rays; random-init weights (seed 7), NDC / linear depth / 2-2 oracle encoding"
     else:
         n0, n1 = M.random_init_weights(0)
         s = dict(view_cell_center=(0.783, -3.19, 1.39), view_cell_size=(0.7, 0.7, 0.2),
@@ -56,6 +63,8 @@ def build_model_dir(td, tag, n, thr):
         data = "synthetic rays; random-init weights (seed 0)"
     scene = dict(view_cell_center=s["view_cell_center"], view_cell_size=s["view_cell_size"], depth_range=s["depth_range"],
                  fov=s["fov"], max_depth=s["max_depth"], num_samples=n, threshold=thr)
+    if tag == "ndc_random_init":
+        scene.update(use_ndc=True, depth_transform="linear", pos_enc=((2, 2), (10, 4)), normalization="None")
     M.write_model_dir(td, scene, n0, n1)
     return scene, data
 
@@ -95,6 +104,7 @@ def main():
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--batch-rays", type=int, default=-1)
+    ap.add_argument("--threshold", type=float, default=None, help="override the workload's adaptive sampling threshold")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -125,10 +135,12 @@ def main():
         dist.barrier()
 
     w, h, n_max, thr, tag = WORKLOADS[args.workload]
+    if args.threshold is not None:
+        thr = args.threshold
     td = tempfile.mkdtemp(prefix="adanerf_bench_%d_" % rank)
     scene, data = build_model_dir(td, tag, n_max, thr)
     pose = np.array(scene["view_cell_center"], dtype=np.float32)
-    rot = M.camera_rotation(100.0, 0.0)
+    rot = M.camera_rotation(100.0, 0.0) if tag != "ndc_random_init" else np.eye(3, dtype=np.float32)   # LLFF: looking down -z
 
     r = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision,
                                    device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=8)
@@ -241,7 +253,7 @@ def main():
                 quality = {"psnr_vs_oracle_db": psnr(mine[same], ref["rgb"][same]),
                            "max_abs_err_vs_oracle": float(np.abs(mine[same] - ref["rgb"][same]).max()),
                            "rays_with_identical_sample_count": float(same.mean()), "rays_checked": int(same.size)}
-        rec = {"metric": "FPS at 800x800", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        rec = {"metric": "FPS at %dx%d" % (w, h), "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": args.precision, "data": data,
                "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, 8x256 shading MLP %s, sampling MLP split-fp16 (3 MFMAs per term)" %
