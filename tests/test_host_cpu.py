@@ -294,3 +294,24 @@ def test_evaluator_dataset_loader(tmp_path):
     assert np.allclose(frames[0]["pose"], [1, 2, 3]) and np.allclose(frames[0]["rot"], np.eye(3))
     assert frames[0]["image"].endswith(os.path.join("test", "00000.png"))
     assert abs(psnr_from_mse(0.01) - 20.0) < 1e-9
+
+
+def test_header_is_plain_c_and_links_from_c(lib, tmp_path):
+    """include/adanerf_hip.h compiled as C99 with gcc; the program drives the library through the C ABI only and the
+    struct sizes match the ctypes mirrors in adanerf_amd/renderer.py."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not available")
+    from adanerf_amd.build import LIBDIR
+    exe = str(tmp_path / "c_abi_check")
+    src = os.path.join(ROOT, "tests", "c_abi_check.c")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", src, "-L", LIBDIR, "-ladanerf_hip",
+                    "-Wl,-rpath," + LIBDIR, "-o", exe], check=True)
+    d, _, _ = _model_dir(tmp_path)
+    out = subprocess.run([exe, d], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "couldn't open" in out.stdout and "rays=3072" in out.stdout
+    sizes = out.stdout.strip().splitlines()[-1]
+    assert sizes == "sizeof options=%d info=%d stats=%d" % (C.sizeof(R._Options), C.sizeof(R.Info), C.sizeof(R.Stats))
