@@ -77,23 +77,49 @@ def cpu_baseline(model_dir, w, h, pose, rot, budget_s=15.0):
     import adanerf_oracle as O
     sc = O.load_scene(model_dir)
     wts = O.load_weights(model_dir)
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    backend = "numpy"
+    try:                                       # pick the faster fp32 GEMM on this host (the reference's CPU path is PyTorch)
+        import numpy as np
+        import torch
+        torch.set_num_threads(os.cpu_count() or 1)
+        xs = np.random.rand(32768, 256).astype(np.float32)
+        ws = np.random.rand(256, 256).astype(np.float32)
+        bs = np.zeros(256, np.float32)
+        best = {}
+        for be in ("numpy", "torch"):
+            O.set_matmul_backend(be)
+            ts = []
+            for _ in range(4):
+                t0 = time.time()
+                O._linear(xs, ws, bs)
+                ts.append(time.time() - t0)
+            best[be] = min(ts[1:])
+        if best["torch"] < best["numpy"]:
+            backend = "numpy + torch CPU GEMM"
+        O.set_matmul_backend("torch" if backend != "numpy" else "numpy")
     except Exception:
-        cores = os.cpu_count() or 1
+        O.set_matmul_backend("numpy")
+    cores = os.cpu_count() or 1
+    if backend == "numpy":
+        try:
+            from threadpoolctl import threadpool_info
+            cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        except Exception:
+            pass
+    CH = 65536
     r0 = h // 2
+    O.render_frame(sc, wts, w, h, pose, rot, chunk=CH, rows=(r0, r0 + 2))     # warm up thread pools
     t0 = time.time()
-    O.render_frame(sc, wts, w, h, pose, rot, rows=(r0, r0 + 2))
+    O.render_frame(sc, wts, w, h, pose, rot, chunk=CH, rows=(r0, r0 + 2))
     probe = max(time.time() - t0, 1e-3)
     rows = int(max(2, min(h // 4, (budget_s / probe) * 2)))
     t0 = time.time()
-    res = O.render_frame(sc, wts, w, h, pose, rot, rows=(r0 - rows // 2, r0 - rows // 2 + rows))
+    res = O.render_frame(sc, wts, w, h, pose, rot, chunk=CH, rows=(r0 - rows // 2, r0 - rows // 2 + rows))
     dt = time.time() - t0
     fps = 1.0 / (dt * h / rows)
     return {"value": fps, "unit": "frames/s", "cores": int(cores), "kind": "port",
-            "sample": "%d of %d image rows (%d rays, %.2f samples/ray) of the same frame, numpy fp32, %.1f s" %
-                      (rows, h, rows * w, float(res["count"].mean()), dt)}, res, (r0 - rows // 2, rows), O.psnr
+            "sample": "%d of %d image rows (%d rays, %.2f samples/ray) of the same frame, %s fp32, chunk %d, %.1f s" %
+                      (rows, h, rows * w, float(res["count"].mean()), backend, CH, dt)}, res, (r0 - rows // 2, rows), O.psnr
 
 
 def main():
@@ -107,6 +133,7 @@ def main():
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's adaptive sampling threshold")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--dump-image", default=None, help="rank 0 writes the last frame's RGBA8 image [h,w,4] as .npy (tests)")
     args = ap.parse_args()
 
     import torch
@@ -123,12 +150,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # Validation hooks for a 1-GPU box (tests/test_gpu_parity.py::test_bench_two_ranks_share_one_gpu): all ranks on
+    # device 0 and gloo for the exchange, because RCCL refuses two ranks on one device.  Never set by the driver.
+    backend = os.environ.get("ADANERF_BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("ADANERF_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if rank == 0:
         B.build_library()
     if dist:
@@ -199,6 +234,9 @@ def main():
     else:
         samples_all = float(st.total_samples)
 
+    if rank == 0 and args.dump_image:
+        np.save(args.dump_image, (image if world > 1 else out[:h * w]).cpu().numpy().reshape(h, w, 4))
+
     ms_per_step = dt / args.steps * 1e3
     fps = args.steps / dt
     frames = max(frames, 1)
@@ -258,7 +296,8 @@ def main():
                "vs_baseline": None, "dtype": args.precision, "data": data,
                "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, 8x256 shading MLP %s, sampling MLP split-fp16 (3 MFMAs per term)" %
                                       (args.workload, w, h, n_max, thr, args.precision),
-                          "parallelism": "image-strip shard x%d (8-row strips, round-robin) + RCCL gather" % world if world > 1 else "single GPU",
+                          "parallelism": ("image-strip shard x%d (8-row strips, round-robin) + %s gather" %
+                                          (world, "RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
                           "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame},
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,
                "sampling_mlp_algorithmic_tflops": smp_tflops, "hbm_stages": hbm, "quality": quality}

@@ -432,7 +432,25 @@ def oracle_features(nds: np.ndarray, p: np.ndarray, scene: Scene) -> np.ndarray:
 # A3 / A6  the two MLPs
 # --------------------------------------------------------------------------------------
 
+_MATMUL = "numpy"
+
+
+def set_matmul_backend(name: str) -> None:
+    """'numpy' (default; what the golden tests pin) or 'torch': the same fp32 x @ W.T + b through torch's CPU GEMM
+    (oneDNN/MKL, all host threads) -- the reference's own CPU path is PyTorch, and numpy's wheel BLAS is ~4x slower
+    on these [chunk,256] x [256,256] products, so bench.py's cpu_baseline uses this."""
+    global _MATMUL
+    if name not in ("numpy", "torch"):
+        raise ValueError(name)
+    _MATMUL = name
+
+
 def _linear(x, w, b):
+    if _MATMUL == "torch":
+        import torch
+        with torch.no_grad():
+            y = torch.addmm(torch.from_numpy(b), torch.from_numpy(np.ascontiguousarray(x, dtype=F32)), torch.from_numpy(w).t())
+        return y.numpy()
     return (x @ w.T + b).astype(F32)
 
 

@@ -652,3 +652,33 @@ def test_dataset_evaluator_end_to_end(cases, tmp_path):
     assert pred.shape == (h, w, 3) and (np.abs(pred.astype(np.int16) - gt8.astype(np.int16)) <= 1).mean() > 0.999
     s2, _ = evaluate(d, str(ds), "test", None, precision="bf16", quiet=True)
     assert s2["mean_psnr"] > 40.0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    """bench.py's N>1 flow (strip shard -> gather -> assemble_strips, max-over-ranks timing, one JSON line from rank 0)
+    launched exactly as the driver launches it, but with both ranks on the one GPU of this box and gloo for the
+    exchange (RCCL refuses two ranks on one device).  The assembled frame must equal the single-rank frame byte for byte."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    a = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--dump-image", one] + common, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0, a.stderr[-2000:]
+    env = dict(os.environ, ADANERF_BENCH_DIST_BACKEND="gloo", ADANERF_BENCH_ONE_DEVICE="1")
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29731", "bench.py", "--gpus", "2",
+                        "--dump-image", two] + common, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-2000:]
+    lines = [ln for ln in b.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, b.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    r1 = json.loads([ln for ln in a.stdout.splitlines() if ln.startswith("{")][0])
+    assert abs(rec["config"]["samples_per_frame"] - r1["config"]["samples_per_frame"]) < 0.5
+    img1, img2 = np.load(one), np.load(two)
+    assert img1.shape == img2.shape == (800, 800, 4)
+    assert np.array_equal(img1, img2)
