@@ -8,6 +8,16 @@ module is what the host uses to size gather payloads and what the CPU tests chec
 import numpy as np
 
 
+def balanced_strip_rows(h: int, world: int, max_rows: int = 8) -> int:
+    """Largest strip height <= ``max_rows`` that gives every rank the same number of full strips (800 rows on 8
+    ranks: 5, not 8 -- 100 strips of 8 rows would leave ranks 0-3 with 13 strips and ranks 4-7 with 12, an 8% longer
+    critical path).  Falls back to ``max_rows`` when no such height exists."""
+    for sr in range(max_rows, 0, -1):
+        if h % sr == 0 and (h // sr) % world == 0:
+            return sr
+    return max_rows
+
+
 def rows_of_rank(h: int, strip_rows: int, world: int, rank: int) -> np.ndarray:
     """Global image rows owned by ``rank``, in local order."""
     n_strips = -(-h // strip_rows)

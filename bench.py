@@ -177,34 +177,64 @@ def main():
     pose = np.array(scene["view_cell_center"], dtype=np.float32)
     rot = M.camera_rotation(100.0, 0.0) if tag != "ndc_random_init" else np.eye(3, dtype=np.float32)   # LLFF: looking down -z
 
+    from adanerf_amd import sharding
+    strip_rows = sharding.balanced_strip_rows(h, world)
     r = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision,
-                                   device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=8)
+                                   device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=strip_rows)
     r.init()
     r.set_camera(pose, rot)
     dev = torch.device("cuda", local_rank)
-    # one non-default stream for the renderer AND torch.distributed, so the gather is stream-ordered
-    # behind the compositing kernel without a host sync
+    # Streams: the renderer enqueues on `tstream`; on N > 1 the exchange of frame k (RGBA8 strip payloads -> rank 0
+    # over RCCL/xGMI) runs on `cstream` behind an event, so it overlaps the render of frame k+1.  Payload and gather
+    # buffers are double-buffered; rank 0 de-interleaves frame k (adanerf_assemble_strips) on `tstream` right after it
+    # has enqueued frame k+1.  No host sync anywhere in a step; flush() drains the last frame inside the timed region.
     tstream = torch.cuda.Stream(device=dev)
     r.set_stream(tstream.cuda_stream)
-    out = torch.zeros((r.info.rays_local_max, 4), dtype=torch.uint8, device=dev)
+    n_buf = 2 if world > 1 else 1
+    outs = [torch.zeros((r.info.rays_local_max, 4), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
+    out = outs[0]
     rgb = torch.zeros((max(r.info.rays_local, 1), 3), dtype=torch.float32, device=dev)
-    gathered = image = None
+    gathered = image = cstream = None
+    ev_render = ev_gather = None
     if world > 1:
+        cstream = torch.cuda.Stream(device=dev)
+        ev_render = [torch.cuda.Event() for _ in range(2)]
+        ev_gather = [None, None]
         if rank == 0:
-            gathered = torch.zeros((world, r.info.rays_local_max, 4), dtype=torch.uint8, device=dev)
+            gathered = [torch.zeros((world, r.info.rays_local_max, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
             image = torch.zeros((h * w, 4), dtype=torch.uint8, device=dev)
+    state = {"k": 0, "pending": None}
+
+    def finish(b):
+        # frame in buffer b: its gather is complete -> de-interleave into the image on the render stream
+        with torch.cuda.stream(tstream):
+            tstream.wait_event(ev_gather[b])
+            if rank == 0:
+                r.assemble_strips(gathered[b], image)
 
     def step():
+        b = state["k"] & (n_buf - 1)
+        state["k"] += 1
         with torch.cuda.stream(tstream):
-            _step()
-
-    def _step():
-        r.render(out, rgb)
+            if world > 1 and ev_gather[b] is not None:
+                tstream.wait_event(ev_gather[b])            # frame k-2's payload has left this buffer
+            r.render(outs[b], rgb)
+            if world > 1:
+                ev_render[b].record(tstream)
         if world > 1:
-            # the one exchange step: RGBA8 strip payloads -> rank 0 over RCCL (xGMI), then de-interleave
-            dist.gather(out, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-            if rank == 0:
-                r.assemble_strips(gathered, image)
+            with torch.cuda.stream(cstream):
+                cstream.wait_event(ev_render[b])
+                dist.gather(outs[b], list(gathered[b].unbind(0)) if rank == 0 else None, dst=0)
+                ev_gather[b] = torch.cuda.Event()
+                ev_gather[b].record(cstream)
+            if state["pending"] is not None:
+                finish(state["pending"])
+            state["pending"] = b
+
+    def flush():
+        if state["pending"] is not None:
+            finish(state["pending"])
+            state["pending"] = None
 
     def fence():
         torch.cuda.synchronize()
@@ -214,11 +244,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    flush()
     fence()
     r.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    flush()
     fence()
     dt = time.perf_counter() - t0
     st, frames = r.collect_stats()
@@ -235,7 +267,7 @@ def main():
         samples_all = float(st.total_samples)
 
     if rank == 0 and args.dump_image:
-        np.save(args.dump_image, (image if world > 1 else out[:h * w]).cpu().numpy().reshape(h, w, 4))
+        np.save(args.dump_image, (image if world > 1 else outs[0][:h * w]).cpu().numpy().reshape(h, w, 4))
 
     ms_per_step = dt / args.steps * 1e3
     fps = args.steps / dt
@@ -296,8 +328,8 @@ def main():
                "vs_baseline": None, "dtype": args.precision, "data": data,
                "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, 8x256 shading MLP %s, sampling MLP split-fp16 (3 MFMAs per term)" %
                                       (args.workload, w, h, n_max, thr, args.precision),
-                          "parallelism": ("image-strip shard x%d (8-row strips, round-robin) + %s gather" %
-                                          (world, "RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
+                          "parallelism": ("image-strip shard x%d (%d-row strips, round-robin) + %s gather overlapped with the next frame" %
+                                          (world, strip_rows, "RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
                           "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame},
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,
                "sampling_mlp_algorithmic_tflops": smp_tflops, "hbm_stages": hbm, "quality": quality}

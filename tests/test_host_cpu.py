@@ -315,3 +315,14 @@ def test_header_is_plain_c_and_links_from_c(lib, tmp_path):
     assert "couldn't open" in out.stdout and "rays=3072" in out.stdout
     sizes = out.stdout.strip().splitlines()[-1]
     assert sizes == "sizeof options=%d info=%d stats=%d" % (C.sizeof(R._Options), C.sizeof(R.Info), C.sizeof(R.Stats))
+
+
+def test_balanced_strip_rows():
+    from adanerf_amd import sharding as S
+    assert S.balanced_strip_rows(800, 1) == 8 and S.balanced_strip_rows(800, 2) == 8 and S.balanced_strip_rows(800, 4) == 8
+    assert S.balanced_strip_rows(800, 8) == 5 and S.balanced_strip_rows(1080, 8) == 5
+    assert S.balanced_strip_rows(7, 4) == 8          # no balanced height: documented fallback
+    for h, world in ((800, 8), (1080, 8), (400, 4)):
+        sr = S.balanced_strip_rows(h, world)
+        per = [S.rays_local(64, h, sr, world, k) for k in range(world)]
+        assert len(set(per)) == 1 and sum(per) == 64 * h
