@@ -390,7 +390,7 @@ int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max,
                      reinterpret_cast<int32_t*>(c->block_total.p));
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, c->stream, reinterpret_cast<const int32_t*>(c->block_total.p), nblk,
                      reinterpret_cast<int32_t*>(c->block_offset.p), d_total);
-  hipLaunchKernelGGL(expand_kernel, dim3(nblk), dim3(256), 0, c->stream, reinterpret_cast<const int32_t*>(d_cnt),
+  hipLaunchKernelGGL(expand_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const int32_t*>(d_cnt),
                      reinterpret_cast<const uint8_t*>(c->selbin.p), reinterpret_cast<const float*>(c->selw.p),
                      reinterpret_cast<const int32_t*>(c->block_offset.p), n_rays, n_max, d_off, d_key, d_w);
   HIP_TRY(c, hipGetLastError());
@@ -750,6 +750,32 @@ int sum_stats(adanerf_ctx* c, adanerf_stats* stats) {
 }
 
 }  // namespace
+
+int adanerf_copy_result_sampling_network(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, void* d_rgba8) {
+  if (!c) return ADANERF_EINVAL;
+  if (!d_oracle || !d_rgba8) return fail(c, ADANERF_EINVAL, "NULL buffer");
+  if (n_rays < 0) return fail(c, ADANERF_EINVAL, "n_rays out of range");
+  if (n_rays == 0) return ADANERF_OK;
+  hipLaunchKernelGGL(oracle_view_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, c->stream, d_oracle, n_rays, static_cast<uchar4*>(d_rgba8));
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+int adanerf_render_oracle(adanerf_ctx* c, void* d_rgba8) {
+  if (!c) return ADANERF_EINVAL;
+  if (!d_rgba8) return fail(c, ADANERF_EINVAL, "NULL buffer");
+  const int R = c->info.rays_local, B = c->info.batch_rays;
+  int rc = ensure_batch_buffers(c, std::min(B, std::max(R, 1)), c->info.num_samples);
+  if (rc) return rc;
+  float* rays = reinterpret_cast<float*>(c->rays.p);
+  float* oracle = reinterpret_cast<float*>(c->oracle.p);
+  for (int first = 0; first < R; first += B) {
+    const int n = std::min(B, R - first);
+    if ((rc = launch_sample_mlp(c, first, n, oracle, rays))) return rc;
+    if ((rc = adanerf_copy_result_sampling_network(c, oracle, n, static_cast<char*>(d_rgba8) + static_cast<size_t>(first) * 4))) return rc;
+  }
+  return ADANERF_OK;
+}
 
 int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* stats) {
   if (!c) return ADANERF_EINVAL;

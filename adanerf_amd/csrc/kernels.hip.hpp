@@ -328,7 +328,15 @@ __global__ __launch_bounds__(256) void ray_features_kernel(RayGenParams g, int f
 // A4: adaptive selection + deterministic compaction
 // ------------------------------------------------------------------------------------------
 
-constexpr int kSelRaysPerBlock = 256;   // 4 waves x 64 rays
+// Rays per workgroup of select_kernel (4 waves x kSelRaysPerBlock/4 rays, one ray at a time per wave) = rays per
+// entry of the block-total scan.  Small on purpose: a wave's serial loop over its rays is the critical path of a
+// small batch (an 83 200-ray shard of an 8-GPU frame), and more, shorter waves also schedule better on a whole
+// frame (measured 0.207 ms at 256 rays, 0.167 ms at 64 for 640 000 rays).
+#ifndef ADN_SEL_RPB
+#define ADN_SEL_RPB 64
+#endif
+constexpr int kSelRaysPerBlock = ADN_SEL_RPB;
+static_assert(kSelRaysPerBlock == 16 || kSelRaysPerBlock == 32 || kSelRaysPerBlock == 64, "segment must fit one wave");
 
 // Selection rule (src/nerf_raymarch_common.py:699-757 as a set rule):
 // keep the n_max largest values (ties: lower bin first) that are >= thr; if none is >= thr keep the
@@ -408,11 +416,12 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ o
                                                      int32_t* __restrict__ counts, uint8_t* __restrict__ selbin,
                                                      float* __restrict__ selw, int32_t* __restrict__ block_total) {
   __shared__ int wave_tot[4];
+  constexpr int RPW = kSelRaysPerBlock / 4;   // rays per wave
   const int lane = lane_id();
   const int wave = static_cast<int>(threadIdx.x) >> 6;
-  const int base = blockIdx.x * kSelRaysPerBlock + wave * 64;
+  const int base = blockIdx.x * kSelRaysPerBlock + wave * RPW;
   int total = 0;
-  for (int i = 0; i < 64; i += 4) {
+  for (int i = 0; i < RPW; i += 4) {
     float v0[4], v1[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -482,29 +491,60 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const int32_t* __rest
 }
 
 // ray offsets + compacted (key, weight) arrays, ray-major / bins ascending
+// One thread per ray; the rays of one select_kernel workgroup are one wave segment, so the in-segment prefix is a
+// width-limited shuffle scan (no LDS, no barrier).
 __global__ __launch_bounds__(256) void expand_kernel(const int32_t* __restrict__ counts, const uint8_t* __restrict__ selbin,
                                                      const float* __restrict__ selw, const int32_t* __restrict__ block_offset,
                                                      int n_rays, int n_max, int32_t* __restrict__ ray_offsets,
                                                      uint32_t* __restrict__ sample_key, float* __restrict__ sample_w) {
-  __shared__ int sc[256];
-  const int t = threadIdx.x;
-  const int r = blockIdx.x * kSelRaysPerBlock + t;
+  const int r = blockIdx.x * 256 + static_cast<int>(threadIdx.x);
   const int c = (r < n_rays) ? counts[r] : 0;
-  sc[t] = c;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    int v = (t >= off) ? sc[t - off] : 0;
-    __syncthreads();
-    sc[t] += v;
-    __syncthreads();
+  const int seg_lane = r & (kSelRaysPerBlock - 1);
+  int x = c;
+#pragma unroll
+  for (int off = 1; off < kSelRaysPerBlock; off <<= 1) {
+    const int y = __shfl_up(x, off, kSelRaysPerBlock);
+    if (seg_lane >= off) x += y;
   }
   if (r >= n_rays) return;
-  const int o = block_offset[blockIdx.x] + sc[t] - c;
+  const int o = block_offset[r / kSelRaysPerBlock] + x - c;
   ray_offsets[r] = o;
   const size_t src = static_cast<size_t>(r) * n_max;
   for (int k = 0; k < c; ++k) {
     sample_key[o + k] = (static_cast<uint32_t>(r) << 7) | selbin[src + k];
     sample_w[o + k] = selw[src + k];
+  }
+}
+
+// Debug view of the sampling network (viewer 'O' key: copyResultSamplingNetwork -> samplesToImage,
+// adanerf_real_time_viewer/src/cuda/base_cuda_kernels.cu:487-528): pixel = ((0.5 + bin) / 128) of the three largest
+// outputs of the ray, largest first, in R, G, B.  The viewer sorts with a stable block radix sort, so equal values
+// rank lower bin first.  One wave per ray, three arg-max rounds.
+__global__ __launch_bounds__(256) void oracle_view_kernel(const float* __restrict__ oracle, int n_rays, uchar4* __restrict__ rgba8) {
+  const int lane = lane_id();
+  const int r = blockIdx.x * 4 + (static_cast<int>(threadIdx.x) >> 6);
+  if (r >= n_rays) return;   // wave-uniform
+  const float* row = oracle + static_cast<size_t>(r) * kBins;
+  float v0 = row[lane], v1 = row[64 + lane];
+  int bin[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float m = wave_max_f32(fmaxf(v0, v1));
+    const uint64_t e0 = __ballot(v0 == m), e1 = __ballot(v1 == m);
+    int b = k;   // all-NaN row: undefined in the reference
+    if (e0) b = __builtin_ctzll(e0);
+    else if (e1) b = 64 + __builtin_ctzll(e1);
+    bin[k] = b;
+    if (b == lane) v0 = -INFINITY;
+    if (b == 64 + lane) v1 = -INFINITY;
+  }
+  if (lane == 0) {
+    uchar4 px;
+    px.x = static_cast<unsigned char>((0.5f + static_cast<float>(bin[0])) / 128.0f * 255.0f);
+    px.y = static_cast<unsigned char>((0.5f + static_cast<float>(bin[1])) / 128.0f * 255.0f);
+    px.z = static_cast<unsigned char>((0.5f + static_cast<float>(bin[2])) / 128.0f * 255.0f);
+    px.w = 255;
+    rgba8[r] = px;
   }
 }
 

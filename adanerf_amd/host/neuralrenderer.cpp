@@ -36,6 +36,7 @@ bool NeuralRenderer::init() {
     return false;
   }
   camera.setPosition(info_.view_cell_center);   // Camera::init: pos = view-cell centre (camera.cpp:49)
+  render_oracle = settings.render_oracle;
   return true;
 }
 
@@ -45,6 +46,14 @@ bool NeuralRenderer::render() {
   if (adanerf_set_camera(ctx, camera.getPosition(), rot) != ADANERF_OK) {
     err = adanerf_last_error(ctx);
     return false;
+  }
+  if (render_oracle) {   // imagegenerator.cpp:316-317: sampling network only, top-3 bins as RGB
+    if (adanerf_render_oracle(ctx, d_frame) != ADANERF_OK || adanerf_sync(ctx) != ADANERF_OK) {
+      err = adanerf_last_error(ctx);
+      return false;
+    }
+    sample_count++;
+    return settings.write_images ? writeImageToFile() : true;
   }
   adanerf_stats st;
   if (adanerf_render(ctx, d_frame, nullptr, &st) != ADANERF_OK) {

@@ -16,6 +16,7 @@ class NeuralRenderer {
 
   bool init();
   bool render();                     // one frame; logs every 100 frames like imagegenerator.cpp:379-393
+  void switchRenderOracle() { render_oracle = !render_oracle; }   // neuralrenderer.h: the 'O' key toggle
   bool writeImageToFile();           // out.bmp in the model directory (neuralrenderer.cpp:184-222)
   const adanerf_info& info() const { return info_; }
   const std::string& error() const { return err; }
@@ -27,6 +28,7 @@ class NeuralRenderer {
   adanerf_info info_{};
   void* d_frame = nullptr;           // uchar4 [h*w]
   std::string err;
+  bool render_oracle = false;
   // 100-frame running sums
   int logging_interval = 100, sample_count = 0;
   double s_inference1 = 0, s_inference2 = 0, s_fc2 = 0, s_rm = 0, s_total = 0;

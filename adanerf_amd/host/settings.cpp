@@ -9,7 +9,7 @@ const char* Settings::usage() {
   return "Usage: adanerf [modelPath] [-s|--size W H] [-ws|--windowSize W H] [-bs|--batchSize N]\n"
          "               [-nb|--numberOfBatches N] [-w|--writeImages] [-d|--debug]\n"
          "               [--frames N] [--precision bf16|fp16|fp32] [--yaw DEG] [--pitch DEG]\n"
-         "               [--samples N] [--threshold T]\n";
+         "               [--samples N] [--threshold T] [--oracle]\n";
 }
 
 bool Settings::init(int argc, char** argv, std::string* err) {
@@ -65,6 +65,8 @@ bool Settings::init(int argc, char** argv, std::string* err) {
     } else if (a == "--threshold") {
       if (!need(i, 1)) return false;
       threshold = static_cast<float>(std::atof(argv[++i]));
+    } else if (a == "--oracle") {
+      render_oracle = true;
     } else if (a == "-h" || a == "--help") {
       *err = usage();
       return false;

@@ -17,6 +17,7 @@ class Settings {
   float yaw = -80.f, pitch = 0.f;   // Camera::init defaults (camera.cpp:90-91)
   int num_samples = 0;
   float threshold = -1.f;
+  bool render_oracle = false;   // --oracle: the viewer's 'O' key (inputhandler.cpp:76), sampling-network debug view
 
   // returns false and fills err on a malformed command line
   bool init(int argc, char** argv, std::string* err);

@@ -56,7 +56,8 @@ EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_las
            "adanerf_render", "adanerf_assemble_strips", "adanerf_sync", "adanerf_set_stream", "adanerf_set_profiling",
            "adanerf_collect_stats", "adanerf_ray_features", "adanerf_sample_mlp",
            "adanerf_compact", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_shade_mlp_z", "adanerf_sample_pdf",
-           "adanerf_composite", "adanerf_composite_classic", "adanerf_malloc",
+           "adanerf_composite", "adanerf_composite_classic", "adanerf_copy_result_sampling_network",
+           "adanerf_render_oracle", "adanerf_malloc",
            "adanerf_free", "adanerf_memcpy_h2d", "adanerf_memcpy_d2h", "adanerf_get_buffer"]
 
 _lib = None
@@ -93,6 +94,8 @@ def load_library(path: Optional[str] = None):
     lib.adanerf_shade_mlp_z.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
     lib.adanerf_sample_pdf.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.adanerf_composite_classic.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
+    lib.adanerf_copy_result_sampling_network.argtypes = [vp, vp, i32, vp]
+    lib.adanerf_render_oracle.argtypes = [vp, vp]
     lib.adanerf_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.adanerf_free.argtypes = [vp, vp]
     lib.adanerf_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -251,6 +254,13 @@ class NeuralRenderer:
         if stats:
             self.last_stats = st
         return st
+
+    def render_oracle(self, rgba8_out):
+        """Sampling-network debug view of this rank's rays (the viewer's 'O' key): [rays_local] uchar4."""
+        self._check(self.lib.adanerf_render_oracle(self.handle, _ptr(rgba8_out)))
+
+    def copy_result_sampling_network(self, oracle, n_rays: int, rgba8_out):
+        self._check(self.lib.adanerf_copy_result_sampling_network(self.handle, _ptr(oracle), n_rays, _ptr(rgba8_out)))
 
     def render_numpy(self):
         """Convenience for tests/tools: renders and returns (rgb fp32 [R,3], rgba8 [R,4], Stats)."""

@@ -215,6 +215,17 @@ int adanerf_shade_mlp(adanerf_ctx* ctx, const float* d_rays, const uint32_t* d_s
 int adanerf_shade_mlp_z(adanerf_ctx* ctx, const float* d_rays, const uint32_t* d_sample_key, const float* d_sample_z,
                         const int32_t* d_total, int32_t max_samples, int32_t precision, float* d_raw_out);
 
+/* Debug view of the sampling network (reference: copyResultSamplingNetwork(output, surf, batch_size, batch_offset,
+ * width, 128), include/cuda/adanerf_cuda_kernels.cuh:20-21 -> samplesToImage, src/cuda/base_cuda_kernels.cu:487-528;
+ * the viewer's 'O' key, src/inputhandler.cpp:76): per ray the three bins with the largest raw outputs, largest
+ * first (equal values: lower bin first), written as RGBA8 ((0.5 + bin) / 128 * 255, truncated; A = 255).
+ * d_rgba8 [n_rays] uchar4. */
+int adanerf_copy_result_sampling_network(adanerf_ctx* ctx, const float* d_oracle, int32_t n_rays, void* d_rgba8);
+
+/* Whole-frame version of the above for this rank's rays (ImageGenerator::inference with render_oracle set,
+ * src/imagegenerator.cpp:316-317): sampling MLP, then the view; the shading half is skipped. */
+int adanerf_render_oracle(adanerf_ctx* ctx, void* d_rgba8);
+
 /* DONeRF sampler (reference: updateRayMarchFromPoses / samplePDF, include/cuda/adanerf_cuda_kernels.cuh:47-52,
  * src/cuda/base_cuda_kernels.cu:296-372; PyTorch: FromClassifiedDepth + nerf_sample_pdf): n samples per ray by
  * inverting the CDF of sigmoid(oracle) + 1e-5 at u = k/(n+1).  Outputs as adanerf_compact plus d_sample_z

@@ -664,6 +664,18 @@ def composite(raw: np.ndarray, sample_w: np.ndarray, ray_offset: np.ndarray, cou
     return rgb
 
 
+def oracle_view(orc: np.ndarray) -> np.ndarray:
+    """Sampling-network debug view, [n,128] raw outputs -> [n,4] uint8.  Restates the VIEWER kernel samplesToImage
+    (adanerf_real_time_viewer/src/cuda/base_cuda_kernels.cu:487-528; the PyTorch path has no counterpart, and the viewer
+    cannot be built here, so this function is pinned only by reading the kernel: "parity unpinned").  Stable descending
+    sort of the 128 values, first three bin ids -> (0.5 + id) / 128 in R, G, B, clamp, * 255, truncate."""
+    order = np.argsort(-orc.astype(F32), axis=1, kind="stable")[:, :3]
+    v = np.clip((F32(0.5) + order.astype(F32)) / F32(128.0), F32(0), F32(1)) * F32(255.0)
+    out = np.full((orc.shape[0], 4), 255, dtype=np.uint8)
+    out[:, :3] = v.astype(np.uint8)
+    return out
+
+
 def to_rgba8(rgb: np.ndarray) -> np.ndarray:
     """Viewer output contract (adaptive_cuda_kernels.cu:846-851): (uchar)(clamp(v,0,1)*255), A=255."""
     v = np.clip(rgb.astype(F32), F32(0), F32(1)) * F32(255.0)

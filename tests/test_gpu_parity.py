@@ -682,3 +682,38 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     img1, img2 = np.load(one), np.load(two)
     assert img1.shape == img2.shape == (800, 800, 4)
     assert np.array_equal(img1, img2)
+
+
+@pytest.mark.gpu
+def test_oracle_debug_view(cases):
+    """adanerf_copy_result_sampling_network / adanerf_render_oracle (viewer 'O' key) vs the restated samplesToImage."""
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    with make(cases["classroom_n8_thr02"]) as r:
+        rng = np.random.default_rng(11)
+        orc = rng.normal(size=(1001, 128)).astype(np.float32)
+        orc[0, :] = 0.25                         # all equal -> bins 0, 1, 2
+        orc[1, :] = -3.0
+        orc[1, [127, 64, 63]] = [2.0, 2.0, 1.0]   # tie for first place: lower bin first -> 64, 127, 63
+        orc[2, 5] = np.inf
+        for src in (orc, z["oracle_out"]):
+            n = src.shape[0]
+            out = r.empty((n, 4), np.uint8)
+            r.copy_result_sampling_network(r.to_device(src.astype(np.float32)), n, out)
+            assert np.array_equal(out.numpy(), O.oracle_view(src))
+        got = r.empty((3, 4), np.uint8)
+        r.copy_result_sampling_network(r.to_device(orc[:3]), 3, got)
+        g = got.numpy()
+        assert list(g[0]) == [0, 2, 4, 255] and list(g[1]) == [int((0.5 + 64) / 128 * 255), int((0.5 + 127) / 128 * 255), int((0.5 + 63) / 128 * 255), 255]
+    # whole frame: the view of the library's own sampling pass, batched, equals the view of its oracle buffer
+    w, h = 96, 64
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=2048), precision="bf16") as r:
+        r.set_camera(z["pose"], z["rot"])
+        img = r.empty((w * h, 4), np.uint8)
+        r.render_oracle(img)
+        r.sync()
+        orc = r.empty((w * h, 128), np.float32)
+        rays = r.empty((w * h, 8), np.float32)
+        r.sample_mlp(0, w * h, orc, rays)
+        assert np.array_equal(img.numpy(), O.oracle_view(orc.numpy()))
+        ref = O.render_rays(O.generate_ray_directions(w, h, sc.fov), z["pose"], z["rot"], sc, wts, w, h, keep=True)
+        assert (img.numpy() == O.oracle_view(ref["orc"])).all(axis=1).mean() > 0.98    # split-fp16 sampling vs fp32: a few rank swaps
