@@ -199,9 +199,11 @@ def main():
     if world > 1:
         cstream = torch.cuda.Stream(device=dev)
         ev_render = [torch.cuda.Event() for _ in range(2)]
-        ev_gather = [None, None]
+        ev_gather = [torch.cuda.Event() for _ in range(2)]
+        gather_lists = [None, None]
         if rank == 0:
             gathered = [torch.zeros((world, r.info.rays_local_max, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+            gather_lists = [list(g.unbind(0)) for g in gathered]
             image = torch.zeros((h * w, 4), dtype=torch.uint8, device=dev)
     state = {"k": 0, "pending": None}
 
@@ -216,7 +218,7 @@ def main():
         b = state["k"] & (n_buf - 1)
         state["k"] += 1
         with torch.cuda.stream(tstream):
-            if world > 1 and ev_gather[b] is not None:
+            if world > 1 and state["k"] > 2:
                 tstream.wait_event(ev_gather[b])            # frame k-2's payload has left this buffer
             r.render(outs[b], rgb)
             if world > 1:
@@ -224,8 +226,7 @@ def main():
         if world > 1:
             with torch.cuda.stream(cstream):
                 cstream.wait_event(ev_render[b])
-                dist.gather(outs[b], list(gathered[b].unbind(0)) if rank == 0 else None, dst=0)
-                ev_gather[b] = torch.cuda.Event()
+                dist.gather(outs[b], gather_lists[b], dst=0)
                 ev_gather[b].record(cstream)
             if state["pending"] is not None:
                 finish(state["pending"])
