@@ -421,16 +421,28 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ o
   const int wave = static_cast<int>(threadIdx.x) >> 6;
   const int base = blockIdx.x * kSelRaysPerBlock + wave * RPW;
   int total = 0;
+  // rows of the next group of 4 rays are requested before the current group is processed, so each wave keeps
+  // 8 row loads in flight while it computes (the kernel is bound by latency x bytes in flight, not by issue)
+  float n0[4], n1[4];
+  auto fetch = [&](int i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = base + i + u;
+      const float* row = oracle + static_cast<size_t>(r < n_rays ? r : 0) * kBins;
+      n0[u] = row[lane];
+      n1[u] = row[64 + lane];
+    }
+  };
+  fetch(0);
+#pragma unroll
   for (int i = 0; i < RPW; i += 4) {
     float v0[4], v1[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int r = base + i + u;
-      const bool ok = r < n_rays;
-      const float* row = oracle + static_cast<size_t>(ok ? r : 0) * kBins;
-      v0[u] = row[lane];
-      v1[u] = row[64 + lane];
+      v0[u] = n0[u];
+      v1[u] = n1[u];
     }
+    if (i + 4 < RPW) fetch(i + 4);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int r = base + i + u;
