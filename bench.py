@@ -264,8 +264,13 @@ def main():
         tot_all = tot.clone()
         dist.all_reduce(tot_all, op=dist.ReduceOp.SUM)
         samples_all = float(tot_all[0].item())
+        per_rank = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(per_rank, tot)
+        shard_samples = [float(x[0].item()) / max(frames, 1) for x in per_rank]
+        shard_shade_ms = [float(x[1].item()) / max(frames, 1) for x in per_rank]
     else:
         samples_all = float(st.total_samples)
+        shard_samples = shard_shade_ms = None
 
     if rank == 0 and args.dump_image:
         np.save(args.dump_image, (image if world > 1 else outs[0][:h * w]).cpu().numpy().reshape(h, w, 4))
@@ -334,6 +339,10 @@ def main():
                           "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame},
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,
                "sampling_mlp_algorithmic_tflops": smp_tflops, "hbm_stages": hbm, "quality": quality}
+        if shard_samples:
+            mean_s = sum(shard_samples) / len(shard_samples)
+            rec["shards"] = {"samples_per_frame": shard_samples, "shade_ms_per_frame": shard_shade_ms,
+                             "sample_imbalance_max_over_mean": max(shard_samples) / mean_s if mean_s > 0 else None}
         print(json.dumps(rec))
     r.close()
     if dist:

@@ -10,14 +10,20 @@ from adanerf_amd import modeldir as M
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "config2"
 w, h, n_max, thr, tag = Bn.WORKLOADS[wl]
+if len(sys.argv) > 2:
+    thr = float(sys.argv[2])
+worlds = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (1, 2, 4, 8)
+prec = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+from adanerf_amd import sharding
 td = tempfile.mkdtemp()
 scene, _ = Bn.build_model_dir(td, tag, n_max, thr)
 pose = np.array(scene["view_cell_center"], np.float32)
 rot = M.camera_rotation(100.0, 0.0) if tag != "ndc_random_init" else np.eye(3, dtype=np.float32)
 rows = []
-for world in (1, 2, 4, 8):
+for world in worlds:
     for rank in range(world):
-        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h), shard_rank=rank, shard_world=world, strip_rows=8) as r:
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h), precision=prec, shard_rank=rank, shard_world=world,
+                                       strip_rows=sharding.balanced_strip_rows(h, world)) as r:
             r.set_camera(pose, rot)
             out = r.empty((r.info.rays_local_max, 4), np.uint8)
             for _ in range(5):
@@ -39,8 +45,8 @@ for world in (1, 2, 4, 8):
                        shade_ms=st.ms_shade_mlp / frames, composite_ms=st.ms_composite / frames)
             rows.append(rec)
             print(json.dumps(rec), flush=True)
-base = rows[0]["wall_ms"]
-for world in (2, 4, 8):
+base = rows[0]["wall_ms"] if worlds[0] == 1 else float("nan")
+for world in [x for x in worlds if x > 1]:
     ws = [x for x in rows if x["world"] == world]
     mx = max(x["wall_ms"] for x in ws)
     sm = [x["samples"] for x in ws]
