@@ -53,7 +53,10 @@ struct adanerf_ctx {
 
   PackedDev net0;                 // sampling net, fp32 fragments (exact engine)
   PackedDev net0_split;           // sampling net, fp16 hi/lo' fragment pairs (split-precision engine)
-  int sampling_mode = 0;          // 0: split-precision fp16x3 (default), 1: exact fp32 MFMA
+  PackedDev net0_f16;             // sampling net, plain fp16 fragments (ADANERF_SAMPLING_FP16, packed on first use)
+  TensorMap net0_host;
+  int sample16_grid = 0;
+  int sampling_mode = 0;          // 0: split-precision fp16x3 (default), 1: exact fp32 MFMA, 2: plain fp16
   DevBuf overflow;                // int32 counter: rays whose oracle values came out non-finite
   int sample_grid = 0;
   PackedDev net1[3];              // shading net per precision (packed lazily)
@@ -199,7 +202,7 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   if (thr == 0.f && n_max != kBins) return bad(ADANERF_EUNSUPPORTED, "adaptiveSamplingThreshold == 0 (dense) requires numRaymarchSamples == 128");
   if (n_max < 1 || n_max > kBins) return bad(ADANERF_EINVAL, "numRaymarchSamples must be in 1..128");
   if (opt->precision < 0 || opt->precision > 2) return bad(ADANERF_EINVAL, "precision must be ADANERF_PREC_{BF16,FP16,FP32}");
-  if (opt->sampling_mode < 0 || opt->sampling_mode > 1) return bad(ADANERF_EINVAL, "sampling_mode must be ADANERF_SAMPLING_{SPLIT_FP16,FP32}");
+  if (opt->sampling_mode < 0 || opt->sampling_mode > 2) return bad(ADANERF_EINVAL, "sampling_mode must be ADANERF_SAMPLING_{SPLIT_FP16,FP32,FP16}");
 
   // ---- info / ray generation constants (A1: src/util/raygeneration.py:10-26, float64) ----
   const int w = opt->width, h = opt->height;
@@ -360,6 +363,24 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
   if (c->sampling_mode == 1) {
     if (full) hipLaunchKernelGGL((sample_mlp_kernel<10, 4>), grid, block, 0, c->stream, a);
     else hipLaunchKernelGGL((sample_mlp_kernel<2, 2>), grid, block, 0, c->stream, a);
+  } else if (c->sampling_mode == 2) {
+    if (!c->net0_f16.w.p) {
+      PackedNet pn;
+      std::string err;
+      NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1};
+      if (!pack_sampling_net(c->net0_host, sh, Elem::F16, &pn, &err)) return fail(c, ADANERF_EIO, "model0.onnx: " + err);
+      int rc = upload_net(c, pn, &c->net0_f16);
+      if (rc) return rc;
+    }
+    a.net16 = c->net0_f16.params;
+    if (!c->sample16_grid) {
+      int rc = full ? occupancy_grid(c, sample_mlp16_kernel<10, 4>, 512, &c->sample16_grid)
+                    : occupancy_grid(c, sample_mlp16_kernel<2, 2>, 512, &c->sample16_grid);
+      if (rc) return rc;
+    }
+    dim3 g16(std::min<unsigned>((n_rays + 255) / 256, static_cast<unsigned>(c->sample16_grid))), b16(512);
+    if (full) hipLaunchKernelGGL((sample_mlp16_kernel<10, 4>), g16, b16, 0, c->stream, a);
+    else hipLaunchKernelGGL((sample_mlp16_kernel<2, 2>), g16, b16, 0, c->stream, a);
   } else {
     if (!c->sample_grid) {
       int rc = full ? occupancy_grid(c, sample_mlp16x3_kernel<10, 4>, 256, &c->sample_grid)
@@ -506,7 +527,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   c->fd1 = ms.fd1;
 
   // ---- weights: parse + pack on the host before touching the device ----
-  TensorMap n0;
+  TensorMap& n0 = c->net0_host;
   if (!read_onnx_initializers(join_path(model_dir, "model0.onnx"), &n0, &err)) return bail(ADANERF_EIO, err);
   if (!read_onnx_initializers(join_path(model_dir, "model1.onnx"), &c->net1_host, &err)) return bail(ADANERF_EIO, err);
   NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1};
@@ -609,7 +630,7 @@ int adanerf_destroy(adanerf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
   for (int32_t* p : c->pinned_totals) (void)hipHostFree(p);
-  DevBuf* bufs[] = {&c->net0_split.w, &c->net0_split.b, &c->overflow, &c->net0.w, &c->net0.b, &c->net1[0].w, &c->net1[0].b, &c->net1[1].w, &c->net1[1].b, &c->net1[2].w, &c->net1[2].b,
+  DevBuf* bufs[] = {&c->net0_split.w, &c->net0_split.b, &c->net0_f16.w, &c->net0_f16.b, &c->overflow, &c->net0.w, &c->net0.b, &c->net1[0].w, &c->net1[0].b, &c->net1[1].w, &c->net1[1].b, &c->net1[2].w, &c->net1[2].b,
                     &c->ztab, &c->rays, &c->oracle, &c->ray_offsets, &c->ray_counts, &c->selbin, &c->selw, &c->block_total,
                     &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw, &c->sample_z};
   for (DevBuf* b : bufs) dev_free(b);

@@ -799,7 +799,8 @@ __device__ __forceinline__ void lds_bias16(uint32_t byte_addr, f32x16* acc) {
 // One 16-bit layer for one 32-sample column block.  Input = two register segments (S1 then S2
 // k-steps of 8 slots = 4 packed dwords each); output tile m lands in out[8m .. 8m+7] (packed pairs).
 // FPOS = position of the layer's first fragment in the stream modulo the chunk size.
-// KEEP_F32_TILE >= 0: that tile's raw accumulator is returned in *keep instead (alpha / rgb rows).
+// KEEP_F32_TILE >= 0: that tile's raw accumulator is returned in *keep instead (alpha / rgb rows);
+// kKeepAllF32: all of them, in keep[0 .. MT-1] (the sampling net's 128 raw outputs).
 // epilogue of one accumulator quad g (values 4g..4g+3 of tile m): convert, ReLU on the packed pairs
 template <class ET, bool RELU>
 __device__ __forceinline__ void epilogue_quad_16(const f32x16& acc, int m, int g, uint32_t* out) {
@@ -822,6 +823,7 @@ __device__ __forceinline__ void epilogue_quad_16(const f32x16& acc, int m, int g
 #define ADN_PIPE16 0   // bit 0: early bias reads, bit 1: epilogue of tile m-1 spread over tile m's MFMAs
 #endif
 
+constexpr int kKeepAllF32 = -2;   // layer_16 KEEP_F32_TILE: every tile's raw accumulator goes to keep[m]
 template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
 __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, const uint32_t* in1, const uint32_t* in2,
                                          uint32_t* out, f32x16* keep = nullptr) {
@@ -863,7 +865,9 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
       if (SPREAD && m > 0 && s < 4 && KEEP_F32_TILE != m - 1) epilogue_quad_16<ET, RELU>(pacc, m - 1, s, out);
     }
     if (ADN_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-    if (KEEP_F32_TILE == m) {
+    if (KEEP_F32_TILE == kKeepAllF32) {
+      keep[m] = acc;
+    } else if (KEEP_F32_TILE == m) {
       *keep = acc;
     } else if (ADN_ABLATE & 8) {
       asm volatile("" ::"v"(acc));
@@ -1266,6 +1270,88 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
         if (h == 0) r[0] = make_float4(ro[0], ro[1], ro[2], 0.f);
         else r[1] = make_float4(rd[0], rd[1], rd[2], 0.f);
       }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// A1+A2+A3 in plain fp16 (ADANERF_SAMPLING_FP16): one MFMA per term, fp32 accumulate -- the arithmetic the
+// reference VIEWER runs its sampling network in (TensorRT kFP16, adanerf_real_time_viewer/src/imagegenerator.cpp:155-156).
+// 11-bit operands move a few outputs across the threshold / the N-th rank (raw error <= 3e-3), so the selected bins
+// differ from the fp32 PyTorch path on 0.3-1.5 % of rays: an opt-in speed mode, never the default.  Same engine as the shading
+// kernel (8 waves x 32 rays per workgroup, activations in registers, weights through the LDS ring).
+template <int FP, int FD>
+constexpr int sample16_frags() { return ((pe_slots(FD) + pe_slots(FP)) / 8) * 8 + 6 * 128 + 64; }
+
+template <int FP, int FD>
+__global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
+  constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP;
+  constexpr int WAVES = 8, CF = ADN_CF, RS = ADN_RS, LPW = CF / WAVES, TILE = WAVES * 32;
+  constexpr int F0 = (Q0 / 8) * 8, FRAGS = sample16_frags<FP, FD>();
+  static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % WAVES == 0 && CF % kRegFrags == 0 && CF <= 32, "chunk geometry");
+  typedef WStream<CF, RS, LPW> WS;
+  constexpr int kRingBytes = CF * RS * 1024, kBiasFloats = 7 * 256 + 128;
+  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kBiasFloats * 4];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int ntiles = (a.n_rays + TILE - 1) / TILE;
+  if (static_cast<int>(blockIdx.x) >= ntiles) return;
+  {
+    float* lds_bias = reinterpret_cast<float*>(lds + kRingBytes);
+    for (int i = threadIdx.x; i < kBiasFloats; i += blockDim.x) lds_bias[i] = a.net16.bias[i];
+  }
+  __syncthreads();
+  WS st;
+  ws_start(st, a.net16.w, FRAGS * 1024, lds, wave, lane);
+  const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
+  const uint32_t* bo = a.net16.b_off;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int local = tile * TILE + wave * 32 + j;
+    const bool valid = local < a.n_rays;
+    const int ray = a.first_ray + (valid ? local : a.n_rays - 1);
+    int col, row;
+    ray_pixel(a.g, ray, &col, &row);
+    float nds[3], p[3], u[3];
+    gen_ray(a.g, col, row, nds, p);
+    unit3(nds, u);
+    if (valid && a.rays_out) {
+      float ro[3] = {p[0], p[1], p[2]}, rd[3] = {nds[0], nds[1], nds[2]};
+      if (a.g.use_ndc) ndc_ray(a.g, p, nds, ro, rd);
+      float4* r = reinterpret_cast<float4*>(a.rays_out + static_cast<size_t>(local) * 8);
+      if (h == 0) r[0] = make_float4(ro[0], ro[1], ro[2], 0.f);
+      else r[1] = make_float4(rd[0], rd[1], rd[2], 0.f);
+    }
+    uint32_t hA[64], hB[64];
+    {
+      float t[Q0];
+      pe_eval<FD, true>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
+      pe_eval<FP, true>(p, h, t + QD);
+      uint32_t in0[Q0 / 2];
+#pragma unroll
+      for (int q = 0; q < Q0 / 2; ++q) in0[q] = Fp16::pack(t[2 * q], t[2 * q + 1]);
+      layer_16<Fp16, WS, Q0 / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, lane, in0, in0, hA);
+    }
+#pragma unroll 1
+    for (int l = 1; l <= 5; l += 2) {
+      layer_16<Fp16, WS, 16, 0, 8, true, F0 % CF>(st, bias0 + bo[l] * 4, lane, hA, hA, hB);
+      layer_16<Fp16, WS, 16, 0, 8, true, F0 % CF>(st, bias0 + bo[l + 1] * 4, lane, hB, hB, hA);
+    }
+    f32x16 out[4];
+    layer_16<Fp16, WS, 16, 0, 4, false, F0 % CF, kKeepAllF32>(st, bias0 + bo[7] * 4, lane, hA, hA, hB, out);
+    if (valid && a.oracle_out) {
+      float* o = a.oracle_out + static_cast<size_t>(local) * kBins;
+      bool bad = false;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = make_float4(out[m][4 * g], out[m][4 * g + 1], out[m][4 * g + 2], out[m][4 * g + 3]);
+          bad |= !(fabsf(v.x) < 3.0e38f) | !(fabsf(v.y) < 3.0e38f) | !(fabsf(v.z) < 3.0e38f) | !(fabsf(v.w) < 3.0e38f);
+          *reinterpret_cast<float4*>(o + 32 * m + 8 * g + 4 * h) = v;
+        }
+      if (bad && a.overflow_flag) atomicAdd(a.overflow_flag, 1);   // an activation left the fp16 range
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -188,7 +188,7 @@ class NeuralRenderer:
                              device_id=device_id, precision=_PREC[precision] if isinstance(precision, str) else int(precision),
                              num_samples=num_samples, threshold=threshold, shard_rank=shard_rank,
                              shard_world=shard_world, strip_rows=strip_rows,
-                             sampling_mode={"split": 0, "fp16x3": 0, "fp32": 1}[sampling])
+                             sampling_mode={"split": 0, "fp16x3": 0, "fp32": 1, "fp16": 2}[sampling])
         self.info = Info()
         self.last_stats = Stats()
         self._own = []

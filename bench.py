@@ -131,7 +131,10 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--batch-rays", type=int, default=-1)
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's adaptive sampling threshold")
+    ap.add_argument("--sampling", default="split", choices=["split", "fp32", "fp16"],
+                    help="sampling-MLP arithmetic: split-fp16 (default, fp32-accurate), exact fp32, or the opt-in plain fp16 speed mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-speed-mode", action="store_true", help="skip the extra fp16-sampling measurement reported under speed_mode")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--dump-image", default=None, help="rank 0 writes the last frame's RGBA8 image [h,w,4] as .npy (tests)")
     args = ap.parse_args()
@@ -179,7 +182,7 @@ def main():
 
     from adanerf_amd import sharding
     strip_rows = sharding.balanced_strip_rows(h, world)
-    r = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision,
+    r = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision, sampling=args.sampling,
                                    device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=strip_rows)
     r.init()
     r.set_camera(pose, rot)
@@ -329,16 +332,42 @@ def main():
                 quality = {"psnr_vs_oracle_db": psnr(mine[same], ref["rgb"][same]),
                            "max_abs_err_vs_oracle": float(np.abs(mine[same] - ref["rgb"][same]).max()),
                            "rays_with_identical_sample_count": float(same.mean()), "rays_checked": int(same.size)}
+        # opt-in speed mode, reported beside the headline (never as it): the same frame with the sampling MLP in plain
+        # fp16 (the viewer's TensorRT arithmetic); selection then deviates from the fp32 path on ~1 % of rays
+        speed = None
+        if world == 1 and args.sampling == "split" and not args.no_speed_mode:
+            with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision,
+                                           sampling="fp16", device_id=local_rank) as r2:
+                r2.set_camera(pose, rot)
+                rgb2 = r2.empty((w * h, 3), np.float32)
+                for _ in range(args.warmup):
+                    r2.render(None, rgb2)
+                r2.sync()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    r2.render(None, rgb2)
+                r2.sync()
+                dt2 = time.perf_counter() - t1
+                st2 = r2.render(None, rgb2, stats=True)
+                speed = {"sampling": "plain fp16 (ADANERF_SAMPLING_FP16)", "value": args.steps / dt2, "unit": "frames/s",
+                         "sample_mlp_ms": st2.ms_sample_mlp, "mean_samples_per_ray": st2.total_samples / float(w * h)}
+                if cpu is not None:
+                    mine2 = rgb2.numpy()[row0 * w:(row0 + rows) * w]
+                    cnt2 = r2.buffer(3, np.int32, (w * h,))[row0 * w:(row0 + rows) * w] if r2.info.batch_rays >= w * h else None
+                    speed["psnr_vs_oracle_db_all_rays"] = psnr(mine2, ref["rgb"])
+                    if cnt2 is not None:
+                        speed["rays_with_identical_sample_count"] = float((cnt2 == ref["count"]).mean())
         rec = {"metric": "FPS at %dx%d" % (w, h), "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": args.precision, "data": data,
-               "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, 8x256 shading MLP %s, sampling MLP split-fp16 (3 MFMAs per term)" %
-                                      (args.workload, w, h, n_max, thr, args.precision),
+               "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, 8x256 shading MLP %s, sampling MLP %s" %
+                                      (args.workload, w, h, n_max, thr, args.precision,
+                                       {"split": "split-fp16 (3 MFMAs per term)", "fp32": "fp32 MFMA", "fp16": "plain fp16 (opt-in speed mode)"}[args.sampling]),
                           "parallelism": ("image-strip shard x%d (%d-row strips, round-robin) + %s gather overlapped with the next frame" %
                                           (world, strip_rows, "RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
                           "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame},
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,
-               "sampling_mlp_algorithmic_tflops": smp_tflops, "hbm_stages": hbm, "quality": quality}
+               "sampling_mlp_algorithmic_tflops": smp_tflops, "hbm_stages": hbm, "quality": quality, "speed_mode": speed}
         if shard_samples:
             mean_s = sum(shard_samples) / len(shard_samples)
             rec["shards"] = {"samples_per_frame": shard_samples, "shade_ms_per_frame": shard_shade_ms,

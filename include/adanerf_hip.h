@@ -61,7 +61,11 @@ enum {
 enum {
   ADANERF_SAMPLING_SPLIT_FP16 = 0, /* default: x = hi + 2^-11 lo' (two fp16), 3 x v_mfma_f32_32x32x16_f16 per term,
                                       fp32 accumulate; 22-bit operands, measured error <= fp32 sgemm's */
-  ADANERF_SAMPLING_FP32 = 1        /* v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain */
+  ADANERF_SAMPLING_FP32 = 1,       /* v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain */
+  ADANERF_SAMPLING_FP16 = 2        /* opt-in speed mode: plain fp16 operands, one MFMA per term, fp32 accumulate -- what the
+                                      reference viewer's TensorRT engine does (imagegenerator.cpp:155-156).  Raw outputs
+                                      are then within ~3e-3 of fp32 and the selected bins differ from the fp32 PyTorch
+                                      path on 0.3-1.5 % of rays (tools/probes/sampling_agreement.py); 3x faster. */
 };
 
 /* sample placement (config.ini rayMarchSampler[1]) */

@@ -717,3 +717,31 @@ def test_oracle_debug_view(cases):
         assert np.array_equal(img.numpy(), O.oracle_view(orc.numpy()))
         ref = O.render_rays(O.generate_ray_directions(w, h, sc.fov), z["pose"], z["rot"], sc, wts, w, h, keep=True)
         assert (img.numpy() == O.oracle_view(ref["orc"])).all(axis=1).mean() > 0.98    # split-fp16 sampling vs fp32: a few rank swaps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["classroom_n8_thr02", "barbershop_n4_thr015", "ndc_synthetic_n8"])
+def test_fp16_sampling_speed_mode(cases, name):
+    """ADANERF_SAMPLING_FP16 (opt-in): plain fp16 operands, the viewer's TensorRT arithmetic.  Stated tolerance:
+    raw outputs within 1e-2 of the fp32 reference (measured 2.4e-4 .. 2.7e-3), >= 97 % of rays keep the identical bin set
+    (measured 98.6 .. 99.7 %, tools/probes/sampling_agreement.py), and the whole frame (bf16 shading) stays above 40 dB
+    against the fp32 oracle INCLUDING the rays whose selection changed."""
+    z, meta, sc, wts, d = cases[name]
+    with make(cases[name], sampling="fp16") as r:
+        orc = run_rows(r, meta, lambda f, n, b: r.sample_mlp(f, n, b, None), 128)
+        rays = run_rows(r, meta, lambda f, n, b: r.sample_mlp(f, n, None, b), 8)
+        rays2 = run_rows(r, meta, lambda f, n, b: r.ray_features(f, n, None, b), 8)
+    assert np.array_equal(rays, rays2)
+    err = np.abs(orc - z["oracle_out"])
+    assert err.max() < 1e-2, err.max()
+    cnt, bins, _ = O.select_adaptive(orc, sc.num_samples, sc.threshold)
+    same = (cnt == z["sel_count"]) & (bins == z["sel_bins"]).all(axis=1)
+    assert same.mean() >= 0.97, "rays with identical bin sets: %.4f" % same.mean()
+    w, h = 160, 120
+    ref = small_frame(cases[name], w, h)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="fp16") as r:
+        r.set_camera(z["pose"], z["rot"])
+        rgb, rgba, st = r.render_numpy()
+    assert st.sampling_overflow == 0
+    p = O.psnr(rgb, ref["rgb"])
+    assert p > 40.0, "PSNR %.2f dB" % p
