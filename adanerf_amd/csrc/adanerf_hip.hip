@@ -483,9 +483,13 @@ int launch_composite(adanerf_ctx* c, const float* d_raw, const float* d_w, const
   if (c->info.num_samples > 32)   // long rays (dense mode): one wave per ray, coalesced
     hipLaunchKernelGGL(composite_wave_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw), d_w,
                        d_off, d_cnt, n_rays, c->mult_mode, d_rgb, reinterpret_cast<uchar4*>(d_rgba8));
-  else
-    hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw), d_w,
-                       d_off, d_cnt, n_rays, c->mult_mode, d_rgb, reinterpret_cast<uchar4*>(d_rgba8));
+  else {
+    // samples of 256 consecutive rays staged in LDS (20 B each) while that fits the default 64 KiB dynamic-LDS limit (N <= 12)
+    const int cap = 256 * c->info.num_samples * 20 <= 65536 ? 256 * c->info.num_samples : 0;
+    hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 255) / 256), dim3(256), static_cast<size_t>(cap) * 20, c->stream,
+                       reinterpret_cast<const float4*>(d_raw), d_w, d_off, d_cnt, n_rays, c->mult_mode, cap, d_rgb,
+                       reinterpret_cast<uchar4*>(d_rgba8));
+  }
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;
 }

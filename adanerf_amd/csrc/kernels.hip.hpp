@@ -1480,24 +1480,53 @@ __global__ __launch_bounds__(256) void composite_classic_kernel(const float4* __
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// one sample of the front-to-back recurrence (src/nerf_raymarch_common.py:91-144): every product and sum rounds
+// to fp32 where the reference's does
+__device__ __forceinline__ void composite_step(const float4 v, float wv, int mult_mode, float& cr, float& cg, float& cb, float& T) {
+  float al = sigmoidf(v.w);
+  if (mult_mode == 1) al = __fmul_rn(al, wv);
+  float wt = __fmul_rn(al, T);
+  if (mult_mode == 2) wt = __fmul_rn(wt, wv);
+  cr = __fadd_rn(cr, __fmul_rn(wt, sigmoidf(v.x)));
+  cg = __fadd_rn(cg, __fmul_rn(wt, sigmoidf(v.y)));
+  cb = __fadd_rn(cb, __fmul_rn(wt, sigmoidf(v.z)));
+  T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, al), 1e-10f));
+}
+
+// Thread per ray, sequential over its samples (the reference's cumprod order, bit for bit).  The samples of the
+// workgroup's 256 consecutive rays are one contiguous range of the compacted arrays, so they are first copied to LDS
+// with coalesced 16-byte loads (`cap` samples of dynamic LDS, 20 B each); a thread striding through global memory
+// instead touches a different 128-byte line per lane and per step (measured 3.6x the algorithmic HBM bytes).
+// Offsets that are not the compactor's (stage API called with a hand-made layout) fall back to direct loads.
 __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict__ raw, const float* __restrict__ sample_w,
                                                         const int32_t* __restrict__ ray_offsets, const int32_t* __restrict__ counts,
-                                                        int n_rays, int mult_mode, float* __restrict__ rgb_out, uchar4* __restrict__ rgba8_out) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+                                                        int n_rays, int mult_mode, int cap, float* __restrict__ rgb_out,
+                                                        uchar4* __restrict__ rgba8_out) {
+  extern __shared__ __attribute__((aligned(16))) char comp_lds[];
+  float4* s_raw = reinterpret_cast<float4*>(comp_lds);
+  float* s_w = reinterpret_cast<float*>(comp_lds + static_cast<size_t>(cap) * sizeof(float4));
+  const int t = threadIdx.x;
+  const int r0 = blockIdx.x * 256;
+  const int r1 = min(r0 + 256, n_rays) - 1;                     // last ray of the workgroup (uniform)
+  const int base = ray_offsets[r0];
+  const int n = ray_offsets[r1] + counts[r1] - base;            // samples of the workgroup if the layout is the compactor's
+  const bool staged = cap > 0 && n >= 0 && n <= cap;            // uniform
+  if (staged) {
+    for (int i = t; i < n; i += 256) {
+      s_raw[i] = raw[base + i];
+      s_w[i] = sample_w[base + i];
+    }
+    __syncthreads();
+  }
+  const int r = r0 + t;
   if (r >= n_rays) return;
   const int o = ray_offsets[r], c = counts[r];
+  const int ol = o - base;
   float cr = 0.f, cg = 0.f, cb = 0.f, T = 1.f;
-  for (int k = 0; k < c; ++k) {
-    const float4 v = raw[o + k];
-    const float wv = sample_w[o + k];
-    float al = sigmoidf(v.w);
-    if (mult_mode == 1) al = __fmul_rn(al, wv);
-    float wt = __fmul_rn(al, T);
-    if (mult_mode == 2) wt = __fmul_rn(wt, wv);
-    cr = __fadd_rn(cr, __fmul_rn(wt, sigmoidf(v.x)));
-    cg = __fadd_rn(cg, __fmul_rn(wt, sigmoidf(v.y)));
-    cb = __fadd_rn(cb, __fmul_rn(wt, sigmoidf(v.z)));
-    T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, al), 1e-10f));
+  if (staged && ol >= 0 && ol + c <= n) {
+    for (int k = 0; k < c; ++k) composite_step(s_raw[ol + k], s_w[ol + k], mult_mode, cr, cg, cb, T);
+  } else {
+    for (int k = 0; k < c; ++k) composite_step(raw[o + k], sample_w[o + k], mult_mode, cr, cg, cb, T);
   }
   if (rgb_out) {
     rgb_out[3 * static_cast<size_t>(r) + 0] = cr;

@@ -307,6 +307,34 @@ def test_composite_matches_reference(cases, name):
     assert (out8 == exp8).mean() > 0.995
 
 
+def test_composite_accepts_any_sample_layout(cases):
+    """adanerf_composite takes (offset, count) per ray: the LDS-staged fast path is only for the compactor's own
+    ray-major layout; a reversed ray order, gaps between rays and a layout wider than the staging buffer must give
+    bit-identical colours through the direct-load path."""
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    count, off, key, sw, sray, sbin = golden_samples(z, sc)
+    n = count.shape[0]
+    raw = z["shade_out"].astype(np.float32)
+    with make(cases["classroom_n8_thr02"]) as r:
+        def run(raw_, sw_, off_, cnt_):
+            rgb = r.empty((n, 3), np.float32)
+            r.composite(r.to_device(raw_), r.to_device(sw_), r.to_device(off_.astype(np.int32)), r.to_device(cnt_.astype(np.int32)), n, rgb, None)
+            return rgb.numpy()
+        ref = run(raw, sw, off, count)
+        # (a) rays listed in reverse order over the same sample arrays
+        got = run(raw, sw, off[::-1].copy(), count[::-1].copy())
+        assert np.array_equal(got, ref[::-1])
+        # (b) every ray padded to 40 sample slots (gaps; 256 rays span 10 240 samples > the 2 048-sample staging buffer)
+        pad = 40
+        raw2 = np.zeros((n * pad, 4), np.float32)
+        sw2 = np.zeros(n * pad, np.float32)
+        for i in range(n):
+            raw2[i * pad:i * pad + count[i]] = raw[off[i]:off[i] + count[i]]
+            sw2[i * pad:i * pad + count[i]] = sw[off[i]:off[i] + count[i]]
+        got = run(raw2, sw2, np.arange(n) * pad, count)
+        assert np.array_equal(got, ref)
+
+
 # ---------------------------------------------------------------------------------------------
 # A8: whole frames
 # ---------------------------------------------------------------------------------------------
