@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 export TMPDIR=/tmp
 cd /tmp && rm -rf /tmp/kst
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o b -- python $R/bench.py --steps ${STEPS:-20} --warmup 5 --no-cpu-baseline "$@" > /tmp/kst.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o b -- python $R/bench.py --steps ${STEPS:-20} --warmup 5 --no-cpu-baseline --no-speed-mode "$@" > /tmp/kst.log 2>&1
 python - <<'PY'
 import csv
 for r in csv.DictReader(open('/tmp/kst/b_kernel_stats.csv')):
