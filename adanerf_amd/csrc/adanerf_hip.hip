@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -484,11 +485,18 @@ int launch_composite(adanerf_ctx* c, const float* d_raw, const float* d_w, const
     hipLaunchKernelGGL(composite_wave_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw), d_w,
                        d_off, d_cnt, n_rays, c->mult_mode, d_rgb, reinterpret_cast<uchar4*>(d_rgba8));
   else {
-    // samples of 256 consecutive rays staged in LDS (20 B each) while that fits the default 64 KiB dynamic-LDS limit (N <= 12)
-    const int cap = 256 * c->info.num_samples * 20 <= 65536 ? 256 * c->info.num_samples : 0;
-    hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 255) / 256), dim3(256), static_cast<size_t>(cap) * 20, c->stream,
-                       reinterpret_cast<const float4*>(d_raw), d_w, d_off, d_cnt, n_rays, c->mult_mode, cap, d_rgb,
-                       reinterpret_cast<uchar4*>(d_rgba8));
+    // samples of RB consecutive rays staged in LDS (20 B each), RB chosen so that RB * N * 20 B <= 48 KB
+    const int N = c->info.num_samples;
+    auto run = [&](auto rb_tag) {
+      constexpr int RB = decltype(rb_tag)::value;
+      const int cap = RB * N;
+      hipLaunchKernelGGL(composite_kernel<RB>, dim3((n_rays + RB - 1) / RB), dim3(RB), static_cast<size_t>(cap) * 20, c->stream,
+                         reinterpret_cast<const float4*>(d_raw), d_w, d_off, d_cnt, n_rays, c->mult_mode, cap, d_rgb,
+                         reinterpret_cast<uchar4*>(d_rgba8));
+    };
+    if (N <= 9) run(std::integral_constant<int, 256>{});
+    else if (N <= 19) run(std::integral_constant<int, 128>{});
+    else run(std::integral_constant<int, 64>{});
   }
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;

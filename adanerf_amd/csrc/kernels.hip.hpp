@@ -1495,24 +1495,26 @@ __device__ __forceinline__ void composite_step(const float4 v, float wv, int mul
 
 // Thread per ray, sequential over its samples (the reference's cumprod order, bit for bit).  The samples of the
 // workgroup's 256 consecutive rays are one contiguous range of the compacted arrays, so they are first copied to LDS
-// with coalesced 16-byte loads (`cap` samples of dynamic LDS, 20 B each); a thread striding through global memory
+// with coalesced 16-byte loads (`cap` samples of dynamic LDS, 20 B each; RB = rays per workgroup is chosen so that
+// RB * N samples stay under 48 KB); a thread striding through global memory
 // instead touches a different 128-byte line per lane and per step (measured 3.6x the algorithmic HBM bytes).
 // Offsets that are not the compactor's (stage API called with a hand-made layout) fall back to direct loads.
-__global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict__ raw, const float* __restrict__ sample_w,
-                                                        const int32_t* __restrict__ ray_offsets, const int32_t* __restrict__ counts,
-                                                        int n_rays, int mult_mode, int cap, float* __restrict__ rgb_out,
-                                                        uchar4* __restrict__ rgba8_out) {
+template <int RB>
+__global__ __launch_bounds__(RB) void composite_kernel(const float4* __restrict__ raw, const float* __restrict__ sample_w,
+                                                       const int32_t* __restrict__ ray_offsets, const int32_t* __restrict__ counts,
+                                                       int n_rays, int mult_mode, int cap, float* __restrict__ rgb_out,
+                                                       uchar4* __restrict__ rgba8_out) {
   extern __shared__ __attribute__((aligned(16))) char comp_lds[];
   float4* s_raw = reinterpret_cast<float4*>(comp_lds);
   float* s_w = reinterpret_cast<float*>(comp_lds + static_cast<size_t>(cap) * sizeof(float4));
   const int t = threadIdx.x;
-  const int r0 = blockIdx.x * 256;
-  const int r1 = min(r0 + 256, n_rays) - 1;                     // last ray of the workgroup (uniform)
+  const int r0 = blockIdx.x * RB;
+  const int r1 = min(r0 + RB, n_rays) - 1;                      // last ray of the workgroup (uniform)
   const int base = ray_offsets[r0];
   const int n = ray_offsets[r1] + counts[r1] - base;            // samples of the workgroup if the layout is the compactor's
   const bool staged = cap > 0 && n >= 0 && n <= cap;            // uniform
   if (staged) {
-    for (int i = t; i < n; i += 256) {
+    for (int i = t; i < n; i += RB) {
       s_raw[i] = raw[base + i];
       s_w[i] = sample_w[base + i];
     }
