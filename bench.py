@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-speed-mode", action="store_true", help="skip the extra fp16-sampling measurement reported under speed_mode")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--orbit", type=int, default=0,
+                    help="K > 0: step i renders pose i %% K of a K-pose orbit inside the view cell (yaw and position vary) instead of "
+                         "the fixed camera; quality / cpu_baseline still refer to pose 0")
     ap.add_argument("--dump-image", default=None, help="rank 0 writes the last frame's RGBA8 image [h,w,4] as .npy (tests)")
     args = ap.parse_args()
 
@@ -217,7 +220,18 @@ def main():
             if rank == 0:
                 r.assemble_strips(gathered[b], image)
 
+    poses = []
+    if args.orbit > 0:
+        size = np.array(scene["view_cell_size"], dtype=np.float32)
+        for i in range(args.orbit):
+            th = 2.0 * np.pi * i / args.orbit
+            ppos = pose + 0.3 * 0.5 * size * np.array([np.cos(th), np.sin(th), 0.0], dtype=np.float32)
+            prot = M.camera_rotation(100.0 + 360.0 * i / args.orbit, 0.0) if tag != "ndc_random_init" else rot
+            poses.append((ppos.astype(np.float32), prot))
+
     def step():
+        if poses:
+            r.set_camera(*poses[state["k"] % len(poses)])
         b = state["k"] & (n_buf - 1)
         state["k"] += 1
         with torch.cuda.stream(tstream):
@@ -325,6 +339,11 @@ def main():
         quality = {}
         if not args.no_cpu_baseline and world == 1:
             cpu, ref, (row0, rows), psnr = cpu_baseline(td, w, h, pose, rot, args.cpu_budget)
+            if poses:                                   # the quality check refers to the fixed pose
+                r.set_camera(pose, rot)
+                with torch.cuda.stream(tstream):
+                    r.render(outs[0], rgb)
+                torch.cuda.synchronize()
             mine = rgb.cpu().numpy()[row0 * w:(row0 + rows) * w]
             cnt = r.buffer(3, np.int32, (r.info.rays_local,))[row0 * w:(row0 + rows) * w] if r.info.batch_rays >= r.info.rays_local else None
             if cnt is not None:
@@ -365,7 +384,8 @@ def main():
                                        {"split": "split-fp16 (3 MFMAs per term)", "fp32": "fp32 MFMA", "fp16": "plain fp16 (opt-in speed mode)"}[args.sampling]),
                           "parallelism": ("image-strip shard x%d (%d-row strips, round-robin) + %s gather overlapped with the next frame" %
                                           (world, strip_rows, "RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
-                          "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame},
+                          "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame,
+                          "camera": ("%d-pose orbit inside the view cell" % args.orbit) if poses else "fixed: view-cell centre, yaw 100 deg"},
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,
                "sampling_mlp_algorithmic_tflops": smp_tflops, "hbm_stages": hbm, "quality": quality, "speed_mode": speed}
         if shard_samples:
