@@ -24,6 +24,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required for RCCL between processes on these hosts
 
 SHADE_FLOP_PER_SAMPLE = 1186816      # 2 x 593408 MAC
 SAMPLE_FLOP_PER_RAY = 898048         # 2 x 449024 MAC
