@@ -71,6 +71,27 @@ def build_cli(force=False, verbose=False):
     return out
 
 
+def build_probes(force=False, verbose=False):
+    """Device-function test helpers (tools/probes/*.hip -> adanerf_amd/bin/<name>); they include the kernel header,
+    so the GPU tests can exercise device functions that have no ABI entry of their own (sin_or_cos)."""
+    pdir = os.path.join(os.path.dirname(HERE), "tools", "probes")
+    outs = []
+    for name in ("sincos_probe",):
+        src = os.path.join(pdir, name + ".hip")
+        out = os.path.join(BINDIR, name)
+        if not os.path.exists(src):
+            continue
+        if force or _stale(out, [src] + [os.path.join(CSRC, d) for d in LIB_DEPS]):
+            os.makedirs(BINDIR, exist_ok=True)
+            cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", src, "-o", out]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+        outs.append(out)
+    return outs
+
+
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
     print(build_cli(force=True, verbose=True))
+    print(build_probes(force=True, verbose=True))

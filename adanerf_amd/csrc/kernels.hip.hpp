@@ -115,8 +115,46 @@ __device__ __forceinline__ void ndc_ray(const RayGenParams& g, const float o[3],
   dn[2] = -2.0f * near / oz;
 }
 
+// sin(a) (h = 0) or cos(a) (h = 1) at libm accuracy (<= 1.6 ulp, max abs error 9.2e-8 for |a| < 1e5, checked against
+// fp64 on 2e7 arguments): three-term FMA Cody-Waite reduction by pi/2, degree-7 / degree-8 minimax polynomials on
+// [-pi/4, pi/4] (Cephes sinf/cosf coefficients); cos(a) = sin(a + pi/2) is applied to the integer quadrant, so it is
+// exact.  ~25 VALU instructions; the device libm's sincosf (Payne-Hanek capable, both results) costs ~5x that, which
+// was 0.14 ms per frame in the sampling kernel.
+__device__ __forceinline__ float sin_or_cos(float a, int h) {
+  float r;
+  int n;
+  if (__builtin_expect(fabsf(a) < 1.0e5f, 1)) {
+    const float j = __builtin_rintf(a * 0.636619747f);             // a * 2/pi
+    r = __builtin_fmaf(j, -1.57079601e+00f, a);                    // pi/2 = 1.57079601 + 3.13916473e-7 + 5.39030253e-15
+    r = __builtin_fmaf(j, -3.13916473e-07f, r);
+    r = __builtin_fmaf(j, -5.39030253e-15f, r);
+    n = static_cast<int>(j) + h;
+  } else {
+    // rare: the same reduction in fp64 (two-term pi/2), exact to ~1e-16 while the quotient fits a double's integers
+    // (|a| < ~1e15).  Beyond that the argument's own fp32 spacing spans > 1e7 periods and the value carries no
+    // information: the reduced argument is clamped so the result stays in [-1, 1], but it is not libm's value.
+    // inf/NaN -> NaN like libm.
+    const double ad = static_cast<double>(a);
+    const double k = __builtin_rint(ad * 0.6366197723675814);
+    double rd = __builtin_fma(k, -1.5707963267948966, ad);
+    rd = __builtin_fma(k, -6.123233995736766e-17, rd);
+    rd = __builtin_fmin(__builtin_fmax(rd, -0.7853981633974483), 0.7853981633974483);   // NaN stays NaN: see below
+    r = (a != a || fabsf(a) == INFINITY) ? __builtin_nanf("") : static_cast<float>(rd);
+    n = static_cast<int>(k - 4.0 * __builtin_floor(k * 0.25)) + h;
+  }
+  const float s = r * r;
+  float t = __builtin_fmaf(s, -1.9515295891e-4f, 8.3321608736e-3f);
+  t = __builtin_fmaf(t, s, -1.6666654611e-1f);
+  const float ps = __builtin_fmaf(t * s, r, r);
+  float u = __builtin_fmaf(s, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  u = __builtin_fmaf(u, s, 4.166664568298827e-2f);
+  const float pc = __builtin_fmaf(u, s * s, __builtin_fmaf(s, -0.5f, 1.0f));
+  const float v = (n & 1) ? pc : ps;
+  return (n & 2) ? -v : v;
+}
+
 // PE slots of lane-half h (layout.hpp): slot q < 3F -> h ? cos : sin of 2^(q/3) * x[q%3];
-// then two identity slots.  ACCURATE: libm-grade sincosf (fp32 parity path);
+// then two identity slots.  ACCURATE: libm-grade sin_or_cos (fp32 parity path);
 // !ACCURATE: one v_sin_f32 per slot (cos = sin shifted by a quarter revolution).
 template <int F, bool ACCURATE>
 __device__ __forceinline__ void pe_eval(const float x[3], int h, float* out) {
@@ -125,9 +163,7 @@ __device__ __forceinline__ void pe_eval(const float x[3], int h, float* out) {
     const int b = q / 3, c = q - 3 * b;
     const float a = x[c] * static_cast<float>(1 << b);
     if (ACCURATE) {
-      float s, co;
-      sincosf(a, &s, &co);
-      out[q] = h ? co : s;
+      out[q] = sin_or_cos(a, h);
     } else {
       out[q] = __builtin_amdgcn_sinf(__builtin_fmaf(a, 0.15915494309189535f, h ? 0.25f : 0.0f));
     }
@@ -627,6 +663,7 @@ struct Fp16 {
 //   4: no bias read (acc starts at 0)                    8: no ReLU/convert epilogue
 //  16: boundary without the DMA issue                   32: boundary without wait + barrier
 //  64: (sampling kernel) no cross-tile software pipeline of bias reads / epilogue
+// 128: (sampling kernels) v_sin_f32 instead of the libm-grade sincosf in the oracle-feature encoding
 // ADN_ABLATE applies to shade_mlp16_kernel, ADN_ABLATE_S to sample_mlp16x3_kernel.
 #ifndef ADN_ABLATE
 #define ADN_ABLATE 0
@@ -1234,8 +1271,8 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
     uint32_t aH[64], aL[64], bH[64], bL[64];
     {
       float t[Q0];
-      pe_eval<FD, true>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
-      pe_eval<FP, true>(p, h, t + QD);
+      pe_eval<FD, !(ADN_ABLATE_S & 128)>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
+      pe_eval<FP, !(ADN_ABLATE_S & 128)>(p, h, t + QD);
 #pragma unroll
       for (int q = 0; q < Q0 / 2; ++q) split_pack(t[2 * q], t[2 * q + 1], &aH[q], &aL[q]);
     }
@@ -1326,8 +1363,8 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
     uint32_t hA[64], hB[64];
     {
       float t[Q0];
-      pe_eval<FD, true>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
-      pe_eval<FP, true>(p, h, t + QD);
+      pe_eval<FD, !(ADN_ABLATE_S & 128)>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
+      pe_eval<FP, !(ADN_ABLATE_S & 128)>(p, h, t + QD);
       uint32_t in0[Q0 / 2];
 #pragma unroll
       for (int q = 0; q < Q0 / 2; ++q) in0[q] = Fp16::pack(t[2 * q], t[2 * q + 1]);

@@ -773,3 +773,35 @@ def test_fp16_sampling_speed_mode(cases, name):
     assert st.sampling_overflow == 0
     p = O.psnr(rgb, ref["rgb"])
     assert p > 40.0, "PSNR %.2f dB" % p
+
+
+@pytest.mark.gpu
+def test_device_sin_or_cos_accuracy(tmp_path):
+    """The positional encodings of the fp32 paths use the library's own sin_or_cos (Cody-Waite + minimax polynomials,
+    fp64 reduction beyond 1e5).  Stated accuracy: <= 2 ulp / 1.2e-7 abs for |a| < 1e5 (measured 1.6 ulp), <= 2e-7 abs up
+    to 1e12, NaN for inf/NaN -- i.e. interchangeable with torch.sin / torch.cos on fp32."""
+    import subprocess
+    from adanerf_amd import build as B
+    exe = [p for p in B.build_probes() if p.endswith("sincos_probe")][0]
+    rng = np.random.default_rng(3)
+    mags = 10.0 ** rng.uniform(-6, 12, 400000)
+    a = (mags * rng.choice([-1.0, 1.0], mags.shape)).astype(np.float32)
+    a = np.concatenate([a, rng.uniform(-5200, 5200, 400000).astype(np.float32),         # the 2^9 band of a 10-unit scene
+                        np.array([0.0, -0.0, 1e5, 99999.99, 100000.01, 3.4e38, np.inf, -np.inf, np.nan], np.float32)])
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    a.tofile(fin)
+    subprocess.run([exe, str(fin), str(fout)], check=True, timeout=120)
+    out = np.fromfile(fout, dtype=np.float32)
+    s, c = out[:a.size], out[a.size:]
+    ok = np.isfinite(a)
+    assert np.isnan(s[~ok]).all() and np.isnan(c[~ok]).all()
+    a64 = a[ok].astype(np.float64)
+    for got, fn in ((s[ok], np.sin), (c[ok], np.cos)):
+        ref = fn(a64)
+        err = np.abs(got.astype(np.float64) - ref)
+        small = np.abs(a64) < 1e5
+        ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+        assert (err[small] <= np.maximum(2.0 * ulp[small], 1.2e-7)).all(), (err[small] / ulp[small]).max()
+        mid = (~small) & (np.abs(a64) < 1e12)
+        assert err[mid].max() <= 2e-7, err[mid].max()
+        assert (np.abs(got) <= 1.0000001).all()
