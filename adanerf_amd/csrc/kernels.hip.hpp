@@ -673,10 +673,6 @@ struct Fp16 {
 #endif
 // Ring geometry.  CF = fragments (KiB) per chunk = MFMAs per wave between barriers; RS = ring slots.
 // At boundary k a wave waits for its own pieces of chunk k+1, so RS-3 further chunks stay in flight.
-// ADN_SGB: pin the MFMA / ds_read interleave with sched_group_barrier (bit 0: shading, bit 1: sampling)
-#ifndef ADN_SGB
-#define ADN_SGB 0
-#endif
 #ifndef ADN_CF
 #define ADN_CF 16
 #endif
@@ -853,55 +849,31 @@ __device__ __forceinline__ void epilogue_quad_16(const f32x16& acc, int m, int g
   out[8 * m + 2 * g + 1] = p1;
 }
 
-#ifndef ADN_PRIO
-#define ADN_PRIO 0     // 1: s_setprio 1 while a tile's MFMA chain issues, 0 during its epilogue; 2: per MFMA
-#endif
-#ifndef ADN_PIPE16
-#define ADN_PIPE16 0   // bit 0: early bias reads, bit 1: epilogue of tile m-1 spread over tile m's MFMAs
-#endif
-
 constexpr int kKeepAllF32 = -2;   // layer_16 KEEP_F32_TILE: every tile's raw accumulator goes to keep[m]
 template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
 __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, const uint32_t* in1, const uint32_t* in2,
                                          uint32_t* out, f32x16* keep = nullptr) {
   constexpr int CF = ADN_CF;
   constexpr int KS = S1 + S2;
-  constexpr bool EARLY_BIAS = (ADN_PIPE16 & 1) && !(ADN_ABLATE & 4);
-  constexpr bool SPREAD = (ADN_PIPE16 & 2) && !(ADN_ABLATE & 8) && KS >= 4;
   // bias_addr: LDS byte address of this layer's bias block for THIS lane-half ([m][h][16] floats)
-  BiasRegs br;
-  f32x16 pacc;
-  if (EARLY_BIAS) lds_bias_issue(bias_addr, br);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 acc;
     if (ADN_ABLATE & 4) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    } else if (EARLY_BIAS) {
-      lds_bias_take(br, &acc);
-      if (m + 1 < MT) lds_bias_issue(bias_addr + (m + 1) * 128, br);
     } else {
       lds_bias16(bias_addr + m * 128, &acc);
     }
-    if (ADN_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int f = (FPOS + m * KS + s) % CF;     // position inside the chunk; compile-time after unrolling
       if (f == 0) ws_boundary<ADN_ABLATE>(st);
       const uint32_t* src = (s < S1) ? (in1 + 4 * s) : (in2 + 4 * (s - S1));
       u32x4 b = {src[0], src[1], src[2], src[3]};
-      if (ADN_PRIO == 2) __builtin_amdgcn_s_setprio(1);
       acc = ET::mfma(st.R[f % kRegFrags], b, acc);
-      if (ADN_PRIO == 2) __builtin_amdgcn_s_setprio(0);
       ws_refill<ADN_ABLATE>(st, f);
-      if (ADN_SGB & 1) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // ... then the re-fill read it freed
-      }
-      if (SPREAD && m > 0 && s < 4 && KEEP_F32_TILE != m - 1) epilogue_quad_16<ET, RELU>(pacc, m - 1, s, out);
     }
-    if (ADN_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     if (KEEP_F32_TILE == kKeepAllF32) {
       keep[m] = acc;
     } else if (KEEP_F32_TILE == m) {
@@ -910,8 +882,6 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
       asm volatile("" ::"v"(acc));
 #pragma unroll
       for (int g = 0; g < 8; ++g) asm volatile("" : "=v"(out[8 * m + g]));
-    } else if (SPREAD && m + 1 < MT) {
-      pacc = acc;
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(acc, m, g, out);
@@ -1199,10 +1169,6 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
       cross = Fp16::mfma(st.R[(f + 1) % kRegFrags], bh, cross);
       ws_refill<ADN_ABLATE_S>(st, f);
       ws_refill<ADN_ABLATE_S>(st, f + 1);
-      if (ADN_SGB & 2) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      }
       if (PIPE && m > 0 && !(ADN_ABLATE_S & 8)) {
         // KS >= 2: spread the 8 pairs over the first k-steps (all 8 in step 0/1 when KS < 8)
         constexpr int PER = (KS >= 8) ? 1 : (8 + KS - 1) / KS;
