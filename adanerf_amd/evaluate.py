@@ -2,7 +2,7 @@
 reference's ``src/evaluate.py`` "images" evaluation (``generate_data`` :164-342: render every test view, MSE /
 PSNR against the ground-truth PNG, mean samples per ray) for an exported model directory.
 
-    python -m adanerf_amd.evaluate <model_dir> <dataset_dir> [--set test] [--out DIR] [--precision bf16]
+    python -m adanerf_amd.evaluate <model_dir> <dataset_dir> [--set test] [--out DIR] [--video out.y4m] [--precision bf16]
 
 Dataset layout (src/datasets.py:146-213, 361-365, 480-542): ``dataset_info.json`` (``resolution``,
 ``camera_angle_x``, ``view_cell_center``, ``view_cell_size`` ...), ``transforms_<set>.json`` with
@@ -36,13 +36,38 @@ def load_dataset(dataset_dir: str, set_name: str = "test"):
     return dict(w=w, h=h, fov=float(info["camera_angle_x"]), info=info), frames
 
 
+class Y4mWriter:
+    """Uncompressed YUV4MPEG2 (4:4:4, BT.601 full range) -- the headless counterpart of the reference's
+    ``imageio.mimwrite(... .mp4, fps=30)`` (src/evaluate.py:289-292); no codec library exists in this image, and any
+    player / ffmpeg reads .y4m."""
+
+    def __init__(self, path: str, w: int, h: int, fps: int = 30):
+        self.f = open(path, "wb")
+        self.f.write(("YUV4MPEG2 W%d H%d F%d:1 Ip A1:1 C444 XCOLORRANGE=FULL\n" % (w, h, fps)).encode())
+        self.w, self.h = w, h
+
+    def add(self, rgb8: np.ndarray):
+        """rgb8: uint8 [h, w, 3]"""
+        c = rgb8.astype(np.float32)
+        y = 0.299 * c[..., 0] + 0.587 * c[..., 1] + 0.114 * c[..., 2]
+        u = -0.168736 * c[..., 0] - 0.331264 * c[..., 1] + 0.5 * c[..., 2] + 128.0
+        v = 0.5 * c[..., 0] - 0.418688 * c[..., 1] - 0.081312 * c[..., 2] + 128.0
+        self.f.write(b"FRAME\n")
+        for p in (y, u, v):
+            self.f.write(np.clip(np.rint(p), 0, 255).astype(np.uint8).tobytes())
+
+    def close(self):
+        self.f.close()
+
+
 def psnr_from_mse(mse: float) -> float:
     """src/evaluate.py:49-54: 10 log10(1 / mse), mse over all 3*h*w values."""
     return float("inf") if mse == 0 else 10.0 * math.log10(1.0 / mse)
 
 
 def evaluate(model_dir: str, dataset_dir: str, set_name: str = "test", out_dir: Optional[str] = None,
-             precision: str = "bf16", batch_size: int = -1, max_frames: int = 0, quiet: bool = False):
+             precision: str = "bf16", batch_size: int = -1, max_frames: int = 0, quiet: bool = False,
+             video: Optional[str] = None, fps: int = 30):
     meta, frames = load_dataset(dataset_dir, set_name)
     if max_frames > 0:
         frames = frames[:max_frames]
@@ -54,6 +79,7 @@ def evaluate(model_dir: str, dataset_dir: str, set_name: str = "test", out_dir: 
                   (meta["fov"], r.info.fov), file=sys.stderr)
         if out_dir:
             os.makedirs(out_dir, exist_ok=True)
+        vid = Y4mWriter(video, w, h, fps) if video else None
         for i, fr in enumerate(frames):
             r.set_camera(fr["pose"], fr["rot"])
             rgb, rgba, st = r.render_numpy()
@@ -67,10 +93,14 @@ def evaluate(model_dir: str, dataset_dir: str, set_name: str = "test", out_dir: 
                 rec.update(mse=mse, psnr=psnr_from_mse(mse))
             if out_dir:
                 write_png(os.path.join(out_dir, "%05d.png" % i), rgba[:, :3].reshape(h, w, 3))
+            if vid:
+                vid.add(rgba[:, :3].reshape(h, w, 3))
             results.append(rec)
             if not quiet:
                 print("frame %d: %s" % (i, ", ".join("%s=%s" % (k, ("%.4f" % v) if isinstance(v, float) else v)
                                                       for k, v in rec.items() if k not in ("frame", "image"))))
+        if vid:
+            vid.close()
     with_gt = [x for x in results if "psnr" in x]
     summary = dict(frames=len(results), mean_samples_per_ray=float(np.mean([x["samples_per_ray"] for x in results])) if results else 0.0,
                    mean_ms=float(np.mean([x["ms"] for x in results])) if results else 0.0)
@@ -88,8 +118,10 @@ def main(argv=None):
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--batch-size", type=int, default=-1)
     ap.add_argument("--max-frames", type=int, default=0)
+    ap.add_argument("--video", default=None, help="also write the rendered frames as an uncompressed .y4m video")
+    ap.add_argument("--fps", type=int, default=30)
     a = ap.parse_args(argv)
-    summary, _ = evaluate(a.model_dir, a.dataset_dir, a.set, a.out, a.precision, a.batch_size, a.max_frames)
+    summary, _ = evaluate(a.model_dir, a.dataset_dir, a.set, a.out, a.precision, a.batch_size, a.max_frames, video=a.video, fps=a.fps)
     print(json.dumps(summary))
 
 

@@ -326,3 +326,22 @@ def test_balanced_strip_rows():
         sr = S.balanced_strip_rows(h, world)
         per = [S.rays_local(64, h, sr, world, k) for k in range(world)]
         assert len(set(per)) == 1 and sum(per) == 64 * h
+
+
+def test_y4m_video_writer(tmp_path):
+    from adanerf_amd.evaluate import Y4mWriter
+    w, h = 6, 4
+    path = str(tmp_path / "v.y4m")
+    v = Y4mWriter(path, w, h, fps=25)
+    grey = np.full((h, w, 3), 100, np.uint8)
+    red = np.zeros((h, w, 3), np.uint8); red[..., 0] = 255
+    v.add(grey); v.add(red); v.close()
+    data = open(path, "rb").read()
+    head, rest = data.split(b"\n", 1)
+    assert head.startswith(b"YUV4MPEG2 W6 H4 F25:1") and b"C444" in head
+    frame = 6 + 3 * w * h
+    assert len(rest) == 2 * frame and rest[:6] == b"FRAME\n" and rest[frame:frame + 6] == b"FRAME\n"
+    y0 = np.frombuffer(rest[6:6 + w * h], np.uint8); u0 = np.frombuffer(rest[6 + w * h:6 + 2 * w * h], np.uint8)
+    assert (y0 == 100).all() and (u0 == 128).all()                       # grey: Y = value, chroma neutral
+    y1 = np.frombuffer(rest[frame + 6:frame + 6 + w * h], np.uint8)
+    assert (y1 == 76).all()                                              # BT.601: 0.299 * 255
