@@ -70,6 +70,8 @@ struct adanerf_ctx {
   DevBuf sample_key, sample_w, raw, sample_z;
   DepthMap dm{};
   int shade_grid[3] = {0, 0, 0};
+  int device = 0;                 // HIP device ordinal this context lives on
+  hipEvent_t peer_event = nullptr;   // adanerf_gather_to: orders the destination stream behind the copy
 };
 
 namespace {
@@ -82,6 +84,10 @@ namespace {
       return ADANERF_EDEVICE;                                                               \
     }                                                                                       \
   } while (0)
+
+// Every entry point that touches the device first makes the context's device current: one host thread may drive
+// several contexts on different GPUs (adanerf_amd/host --gpus N), and a launch on another device's stream fails.
+#define BIND(ctx) HIP_TRY(ctx, hipSetDevice((ctx)->device))
 
 int fail(adanerf_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
@@ -560,6 +566,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     return bail(ADANERF_EDEVICE, std::string("device is ") + prop.gcnArchName + "; this library is built for gfx950 (MI355X) only");
   c->info.compute_units = prop.multiProcessorCount;
+  c->device = opt->device_id;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(ADANERF_EDEVICE, "hipStreamCreate failed");
   c->stream = c->own_stream;
 
@@ -639,6 +646,8 @@ int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precis
 
 int adanerf_destroy(adanerf_ctx* c) {
   if (!c) return ADANERF_OK;
+  (void)hipSetDevice(c->device);
+  if (c->peer_event) (void)hipEventDestroy(c->peer_event);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
   for (int32_t* p : c->pinned_totals) (void)hipHostFree(p);
@@ -667,12 +676,14 @@ int adanerf_set_camera(adanerf_ctx* c, const float pos[3], const float rot[9]) {
 
 int adanerf_sync(adanerf_ctx* c) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ADANERF_OK;
 }
 
 int adanerf_ray_features(adanerf_ctx* c, int32_t first_ray, int32_t n_rays, float* d_feat, float* d_rays) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   if (first_ray < 0 || n_rays < 0 || first_ray + n_rays > c->info.rays_local) return fail(c, ADANERF_EINVAL, "ray range outside this context's rays");
   if (n_rays == 0) return ADANERF_OK;
   dim3 grid((n_rays + 255) / 256), block(256);
@@ -684,6 +695,7 @@ int adanerf_ray_features(adanerf_ctx* c, int32_t first_ray, int32_t n_rays, floa
 
 int adanerf_sample_mlp(adanerf_ctx* c, int32_t first_ray, int32_t n_rays, float* d_oracle, float* d_rays) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   if (first_ray < 0 || n_rays < 0 || first_ray + n_rays > c->info.rays_local) return fail(c, ADANERF_EINVAL, "ray range outside this context's rays");
   return launch_sample_mlp(c, first_ray, n_rays, d_oracle, d_rays);
 }
@@ -691,6 +703,7 @@ int adanerf_sample_mlp(adanerf_ctx* c, int32_t first_ray, int32_t n_rays, float*
 int adanerf_compact(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, int32_t n_max, float thr, int32_t* d_off, int32_t* d_cnt,
                     uint32_t* d_key, float* d_w, int32_t* d_total) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   if (!d_oracle || !d_off || !d_cnt || !d_key || !d_w || !d_total) return fail(c, ADANERF_EINVAL, "NULL buffer");
   if (n_rays < 0 || n_max < 1 || n_max > kBins || thr < 0.f) return fail(c, ADANERF_EINVAL, "n_rays/n_max/thr out of range");
   if (thr == 0.f && n_max != kBins) return fail(c, ADANERF_EINVAL, "dense mode (thr == 0) requires n_max == 128");
@@ -702,6 +715,7 @@ int adanerf_compact(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, int32
 
 int adanerf_shade_features(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, int32_t n_samples, float* d_feat) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   if (!d_rays || !d_key || !d_feat || n_samples < 0) return fail(c, ADANERF_EINVAL, "bad argument");
   if (n_samples == 0) return ADANERF_OK;
   ShadeArgs a{};
@@ -717,6 +731,7 @@ int adanerf_shade_features(adanerf_ctx* c, const float* d_rays, const uint32_t* 
 int adanerf_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, const int32_t* d_total, int32_t max_samples,
                       int32_t precision, float* d_raw) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   if (!d_rays || !d_key || !d_raw || max_samples < 0) return fail(c, ADANERF_EINVAL, "bad argument");
   return launch_shade_mlp(c, d_rays, d_key, d_total, max_samples, precision < 0 ? c->info.precision : precision, d_raw);
 }
@@ -724,6 +739,7 @@ int adanerf_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key
 int adanerf_shade_mlp_z(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, const float* d_z, const int32_t* d_total,
                         int32_t max_samples, int32_t precision, float* d_raw) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   if (!d_rays || !d_key || !d_raw || max_samples < 0) return fail(c, ADANERF_EINVAL, "bad argument");
   return launch_shade_mlp(c, d_rays, d_key, d_total, max_samples, precision < 0 ? c->info.precision : precision, d_raw, d_z);
 }
@@ -731,6 +747,7 @@ int adanerf_shade_mlp_z(adanerf_ctx* c, const float* d_rays, const uint32_t* d_k
 int adanerf_sample_pdf(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, int32_t n, int32_t* d_off, int32_t* d_cnt, uint32_t* d_key,
                        float* d_w, float* d_z, int32_t* d_total) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   if (!d_oracle || !d_off || !d_cnt || !d_key || !d_w || !d_z || !d_total) return fail(c, ADANERF_EINVAL, "NULL buffer");
   if (n_rays < 0 || n < 1 || n > 4096) return fail(c, ADANERF_EINVAL, "n_rays/n out of range");
   if (static_cast<int64_t>(n_rays) * n > 0x7fffffffll || n_rays >= (1 << 25)) return fail(c, ADANERF_EINVAL, "n_rays * n too large");
@@ -740,6 +757,7 @@ int adanerf_sample_pdf(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, in
 int adanerf_composite_classic(adanerf_ctx* c, const float* d_raw, const float* d_z, const float* d_rays, int32_t n_rays, int32_t n,
                               float* d_rgb, void* d_rgba8) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   if (!d_raw || !d_z || !d_rays || n_rays < 0 || n < 1) return fail(c, ADANERF_EINVAL, "bad argument");
   return launch_composite_classic(c, d_raw, d_z, d_rays, n_rays, n, d_rgb, d_rgba8);
 }
@@ -747,6 +765,7 @@ int adanerf_composite_classic(adanerf_ctx* c, const float* d_raw, const float* d
 int adanerf_composite(adanerf_ctx* c, const float* d_raw, const float* d_w, const int32_t* d_off, const int32_t* d_cnt, int32_t n_rays,
                       float* d_rgb, void* d_rgba8) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   if (!d_raw || !d_w || !d_off || !d_cnt || n_rays < 0) return fail(c, ADANERF_EINVAL, "bad argument");
   return launch_composite(c, d_raw, d_w, d_off, d_cnt, n_rays, d_rgb, d_rgba8);
 }
@@ -786,6 +805,7 @@ int sum_stats(adanerf_ctx* c, adanerf_stats* stats) {
 
 int adanerf_copy_result_sampling_network(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, void* d_rgba8) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   if (!d_oracle || !d_rgba8) return fail(c, ADANERF_EINVAL, "NULL buffer");
   if (n_rays < 0) return fail(c, ADANERF_EINVAL, "n_rays out of range");
   if (n_rays == 0) return ADANERF_OK;
@@ -796,6 +816,7 @@ int adanerf_copy_result_sampling_network(adanerf_ctx* c, const float* d_oracle, 
 
 int adanerf_render_oracle(adanerf_ctx* c, void* d_rgba8) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   if (!d_rgba8) return fail(c, ADANERF_EINVAL, "NULL buffer");
   const int R = c->info.rays_local, B = c->info.batch_rays;
   int rc = ensure_batch_buffers(c, std::min(B, std::max(R, 1)), c->info.num_samples);
@@ -812,6 +833,7 @@ int adanerf_render_oracle(adanerf_ctx* c, void* d_rgba8) {
 
 int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* stats) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   const int R = c->info.rays_local, B = c->info.batch_rays, N = c->info.num_samples;
   const float thr = c->info.threshold;
   const int n_batches = R > 0 ? (R + B - 1) / B : 0;
@@ -890,6 +912,7 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
 
 int adanerf_set_stream(adanerf_ctx* c, void* hip_stream) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
   return ADANERF_OK;
@@ -897,6 +920,7 @@ int adanerf_set_stream(adanerf_ctx* c, void* hip_stream) {
 
 int adanerf_set_profiling(adanerf_ctx* c, int32_t enabled) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->profiling = enabled != 0;
   c->events_used = 0;
@@ -906,6 +930,7 @@ int adanerf_set_profiling(adanerf_ctx* c, int32_t enabled) {
 
 int adanerf_collect_stats(adanerf_ctx* c, adanerf_stats* stats, int32_t* frames) {
   if (!c || !stats) return ADANERF_EINVAL;
+  BIND(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   int rc = sum_stats(c, stats);
   if (rc) return rc;
@@ -918,6 +943,7 @@ int adanerf_collect_stats(adanerf_ctx* c, adanerf_stats* stats, int32_t* frames)
 
 int adanerf_assemble_strips(adanerf_ctx* c, const void* d_gathered, void* d_image) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   if (!d_gathered || !d_image) return fail(c, ADANERF_EINVAL, "NULL buffer");
   const int n = c->info.width * c->info.height;
   hipLaunchKernelGGL(assemble_strips_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const uchar4*>(d_gathered),
@@ -926,25 +952,55 @@ int adanerf_assemble_strips(adanerf_ctx* c, const void* d_gathered, void* d_imag
   return ADANERF_OK;
 }
 
+int adanerf_gather_to(adanerf_ctx* dst, void* d_dst, adanerf_ctx* src, const void* d_src, size_t bytes) {
+  if (!dst || !src) return ADANERF_EINVAL;
+  if (!d_dst || !d_src) return fail(dst, ADANERF_EINVAL, "NULL buffer");
+  if (bytes == 0) return ADANERF_OK;
+  adanerf_ctx* c = src;
+  BIND(src);
+  if (src->device != dst->device) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, src->device, dst->device) == hipSuccess && can) {
+      const hipError_t e = hipDeviceEnablePeerAccess(dst->device, 0);      // direct xGMI stores; harmless if already on
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+      else (void)hipGetLastError();
+    }
+    HIP_TRY(c, hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, src->stream));
+  } else {
+    HIP_TRY(c, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, src->stream));
+  }
+  if (src == dst || src->stream == dst->stream) return ADANERF_OK;
+  if (!src->peer_event) HIP_TRY(c, hipEventCreateWithFlags(&src->peer_event, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(src->peer_event, src->stream));
+  c = dst;
+  BIND(dst);
+  HIP_TRY(c, hipStreamWaitEvent(dst->stream, src->peer_event, 0));
+  return ADANERF_OK;
+}
+
 int adanerf_malloc(adanerf_ctx* c, size_t bytes, void** d_out) {
   if (!c || !d_out) return ADANERF_EINVAL;
+  BIND(c);
   HIP_TRY(c, hipMalloc(d_out, bytes ? bytes : 1));
   return ADANERF_OK;
 }
 int adanerf_free(adanerf_ctx* c, void* d_ptr) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipFree(d_ptr));
   return ADANERF_OK;
 }
 int adanerf_memcpy_h2d(adanerf_ctx* c, void* d_dst, const void* src, size_t bytes) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   HIP_TRY(c, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ADANERF_OK;
 }
 int adanerf_memcpy_d2h(adanerf_ctx* c, void* dst, const void* d_src, size_t bytes) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   HIP_TRY(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ADANERF_OK;

@@ -6,7 +6,14 @@
 #include <iostream>
 
 NeuralRenderer::~NeuralRenderer() {
+  for (size_t i = 0; i < peers.size(); ++i) {
+    if (peers[i]) {
+      if (i + 1 < d_payload.size() && d_payload[i + 1]) adanerf_free(peers[i], d_payload[i + 1]);
+      adanerf_destroy(peers[i]);
+    }
+  }
   if (ctx) {
+    if (d_gathered) adanerf_free(ctx, d_gathered);
     if (d_frame) adanerf_free(ctx, d_frame);
     adanerf_destroy(ctx);
   }
@@ -23,19 +30,56 @@ bool NeuralRenderer::init() {
   opt.precision = settings.precision == "fp32" ? ADANERF_PREC_FP32 : (settings.precision == "fp16" ? ADANERF_PREC_FP16 : ADANERF_PREC_BF16);
   opt.num_samples = settings.num_samples;
   opt.threshold = settings.threshold;
-  opt.shard_rank = 0;
-  opt.shard_world = 1;
-  opt.strip_rows = 8;
-  if (adanerf_create(settings.model_path.c_str(), &opt, &ctx) != ADANERF_OK) {
-    err = adanerf_last_error(nullptr);
+  // --gpus N: rows are cut into strips, strip s belongs to GPU s % N; largest strip height <= 8 rows that
+  // gives every GPU the same number of strips
+  const int world = settings.gpus;
+  if (world > 1 && settings.render_oracle) {
+    err = "--oracle renders one context's rays; use it with --gpus 1";
     return false;
   }
+  int strip_rows = 8;
+  for (int sr = 8; sr >= 1; --sr)
+    if (opt.height % sr == 0 && (opt.height / sr) % world == 0) {
+      strip_rows = sr;
+      break;
+    }
+  opt.shard_world = world;
+  opt.strip_rows = strip_rows;
+  for (int rank = 0; rank < world; ++rank) {
+    opt.shard_rank = rank;
+    opt.device_id = settings.same_device ? 0 : rank;
+    adanerf_ctx* c = nullptr;
+    if (adanerf_create(settings.model_path.c_str(), &opt, &c) != ADANERF_OK) {
+      err = adanerf_last_error(nullptr);
+      return false;
+    }
+    if (rank == 0) ctx = c;
+    else peers.push_back(c);
+  }
   adanerf_get_info(ctx, &info_);
-  if (adanerf_malloc(ctx, static_cast<size_t>(info_.rays_local) * 4, &d_frame) != ADANERF_OK) {
+  if (adanerf_malloc(ctx, static_cast<size_t>(info_.width) * info_.height * 4, &d_frame) != ADANERF_OK) {
     err = adanerf_last_error(ctx);
     return false;
   }
+  if (world > 1) {
+    const size_t payload = static_cast<size_t>(info_.rays_local_max) * 4;
+    if (adanerf_malloc(ctx, payload * world, &d_gathered) != ADANERF_OK) {
+      err = adanerf_last_error(ctx);
+      return false;
+    }
+    d_payload.assign(world, nullptr);
+    d_payload[0] = d_gathered;     // rank 0 renders straight into its slot
+    for (int rank = 1; rank < world; ++rank)
+      if (adanerf_malloc(peers[rank - 1], payload, &d_payload[rank]) != ADANERF_OK) {
+        err = adanerf_last_error(peers[rank - 1]);
+        return false;
+      }
+  }
   camera.setPosition(info_.view_cell_center);   // Camera::init: pos = view-cell centre (camera.cpp:49)
+  if (world > 1 && adanerf_set_profiling(ctx, 1) != ADANERF_OK) {
+    err = adanerf_last_error(ctx);
+    return false;
+  }
   render_oracle = settings.render_oracle;
   return true;
 }
@@ -56,6 +100,43 @@ bool NeuralRenderer::render() {
     return settings.write_images ? writeImageToFile() : true;
   }
   adanerf_stats st;
+  std::memset(&st, 0, sizeof(st));
+  if (!peers.empty()) {
+    // every GPU renders its strips (launches are asynchronous: the GPUs run concurrently), each payload is copied to
+    // the display GPU over xGMI behind its render, and rank 0 de-interleaves; one host sync at the end of the frame.
+    // Rank 0 is enqueued first so that its stream does not wait for the peers before it starts.
+    const size_t payload = static_cast<size_t>(info_.rays_local_max) * 4;
+    if (adanerf_render(ctx, d_payload[0], nullptr, nullptr) != ADANERF_OK) {
+      err = adanerf_last_error(ctx);
+      return false;
+    }
+    for (size_t i = 0; i < peers.size(); ++i) {
+      if (adanerf_set_camera(peers[i], camera.getPosition(), rot) != ADANERF_OK ||
+          adanerf_render(peers[i], d_payload[i + 1], nullptr, nullptr) != ADANERF_OK ||
+          adanerf_gather_to(ctx, static_cast<char*>(d_gathered) + (i + 1) * payload, peers[i], d_payload[i + 1], payload) != ADANERF_OK) {
+        err = adanerf_last_error(peers[i]);
+        return false;
+      }
+    }
+    if (adanerf_assemble_strips(ctx, d_gathered, d_frame) != ADANERF_OK || adanerf_sync(ctx) != ADANERF_OK) {
+      err = adanerf_last_error(ctx);
+      return false;
+    }
+    sample_count++;
+    if (sample_count % logging_interval == 0) {
+      // rank 0's share, accumulated on its stream by the profiling API (no per-frame sync); samples scaled to the frame
+      int32_t frames = 0;
+      if (adanerf_collect_stats(ctx, &st, &frames) == ADANERF_OK && frames > 0) {
+        const double f = frames, world = static_cast<double>(peers.size() + 1);
+        std::cout << "Inference 1:" << st.ms_sample_mlp / f << ", 2:" << st.ms_shade_mlp / f << " | fc1: 0"
+                  << ", fc2: " << st.ms_compact / f << ", rm: " << st.ms_composite / f
+                  << ", avg samples ppx: " << st.total_samples * world / f / settings.total_size
+                  << " (total: " << static_cast<long long>(st.total_samples * world / f) << ")"
+                  << ", frames: " << sample_count << ", gpus: " << peers.size() + 1 << " (stage times: GPU 0's share)" << std::endl;
+      }
+    }
+    return settings.write_images ? writeImageToFile() : true;
+  }
   if (adanerf_render(ctx, d_frame, nullptr, &st) != ADANERF_OK) {
     err = adanerf_last_error(ctx);
     return false;

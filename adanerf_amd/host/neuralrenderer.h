@@ -24,7 +24,10 @@ class NeuralRenderer {
  private:
   Settings& settings;
   Camera& camera;
-  adanerf_ctx* ctx = nullptr;
+  adanerf_ctx* ctx = nullptr;        // rank 0: display GPU, owns the frame
+  std::vector<adanerf_ctx*> peers;   // ranks 1 .. N-1 (--gpus N), one per GPU, same process
+  std::vector<void*> d_payload;      // per rank: uchar4 [rays_local_max] on that rank's GPU
+  void* d_gathered = nullptr;        // rank 0: uchar4 [N][rays_local_max]
   adanerf_info info_{};
   void* d_frame = nullptr;           // uchar4 [h*w]
   std::string err;

@@ -9,7 +9,8 @@ const char* Settings::usage() {
   return "Usage: adanerf [modelPath] [-s|--size W H] [-ws|--windowSize W H] [-bs|--batchSize N]\n"
          "               [-nb|--numberOfBatches N] [-w|--writeImages] [-d|--debug]\n"
          "               [--frames N] [--precision bf16|fp16|fp32] [--yaw DEG] [--pitch DEG]\n"
-         "               [--samples N] [--threshold T] [--oracle]\n";
+         "               [--samples N] [--threshold T] [--oracle]\n"
+         "               [--gpus N] [--same-device]\n";
 }
 
 bool Settings::init(int argc, char** argv, std::string* err) {
@@ -65,6 +66,11 @@ bool Settings::init(int argc, char** argv, std::string* err) {
     } else if (a == "--threshold") {
       if (!need(i, 1)) return false;
       threshold = static_cast<float>(std::atof(argv[++i]));
+    } else if (a == "--gpus") {
+      if (!need(i, 1)) return false;
+      gpus = std::max(1, std::atoi(argv[++i]));
+    } else if (a == "--same-device") {
+      same_device = true;
     } else if (a == "--oracle") {
       render_oracle = true;
     } else if (a == "-h" || a == "--help") {

@@ -17,6 +17,8 @@ class Settings {
   float yaw = -80.f, pitch = 0.f;   // Camera::init defaults (camera.cpp:90-91)
   int num_samples = 0;
   float threshold = -1.f;
+  int gpus = 1;                 // --gpus N: one context per GPU in this process, strips exchanged with peer copies over xGMI
+  bool same_device = false;     // --same-device: all N contexts on device 0 (exercises the N-GPU path on a 1-GPU box)
   bool render_oracle = false;   // --oracle: the viewer's 'O' key (inputhandler.cpp:76), sampling-network debug view
 
   // returns false and fills err on a malformed command line

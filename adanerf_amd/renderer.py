@@ -57,7 +57,7 @@ EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_las
            "adanerf_collect_stats", "adanerf_ray_features", "adanerf_sample_mlp",
            "adanerf_compact", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_shade_mlp_z", "adanerf_sample_pdf",
            "adanerf_composite", "adanerf_composite_classic", "adanerf_copy_result_sampling_network",
-           "adanerf_render_oracle", "adanerf_malloc",
+           "adanerf_render_oracle", "adanerf_gather_to", "adanerf_malloc",
            "adanerf_free", "adanerf_memcpy_h2d", "adanerf_memcpy_d2h", "adanerf_get_buffer"]
 
 _lib = None
@@ -96,6 +96,7 @@ def load_library(path: Optional[str] = None):
     lib.adanerf_composite_classic.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     lib.adanerf_copy_result_sampling_network.argtypes = [vp, vp, i32, vp]
     lib.adanerf_render_oracle.argtypes = [vp, vp]
+    lib.adanerf_gather_to.argtypes = [vp, vp, vp, vp, C.c_size_t]
     lib.adanerf_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.adanerf_free.argtypes = [vp, vp]
     lib.adanerf_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -254,6 +255,11 @@ class NeuralRenderer:
         if stats:
             self.last_stats = st
         return st
+
+    def gather_from(self, dst, src_renderer: "NeuralRenderer", src, nbytes: int):
+        """Stream-ordered copy of ``nbytes`` from ``src`` (on ``src_renderer``'s device / stream) into ``dst`` on this
+        renderer's device; this renderer's stream waits for it (single-process multi-GPU strip exchange)."""
+        self._check(self.lib.adanerf_gather_to(self.handle, _ptr(dst), src_renderer.handle, _ptr(src), nbytes))
 
     def render_oracle(self, rgba8_out):
         """Sampling-network debug view of this rank's rays (the viewer's 'O' key): [rays_local] uchar4."""

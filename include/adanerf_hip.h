@@ -164,6 +164,12 @@ int adanerf_render(adanerf_ctx* ctx, void* d_rgba8_out, float* d_rgb_f32_out, ad
  * into the full row-major image [h*w] uchar4. */
 int adanerf_assemble_strips(adanerf_ctx* ctx, const void* d_gathered, void* d_image_out);
 
+/* Single-process multi-GPU exchange (the counterpart of the RCCL gather for a host that owns all N contexts, e.g. the
+ * `adanerf` CLI with --gpus N): copies `bytes` from d_src (a buffer of src's device, produced on src's stream) to d_dst
+ * on dst's device -- hipMemcpyPeerAsync over xGMI, peer access enabled on first use -- ordered behind src's stream, and
+ * makes dst's stream wait for it.  No host synchronisation.  src == dst or same device: a device-to-device copy. */
+int adanerf_gather_to(adanerf_ctx* dst, void* d_dst, adanerf_ctx* src, const void* d_src, size_t bytes);
+
 int adanerf_sync(adanerf_ctx* ctx);
 
 /* Makes the context enqueue on a caller-owned HIP stream (hipStream_t, e.g. PyTorch's current stream)

@@ -805,3 +805,51 @@ def test_device_sin_or_cos_accuracy(tmp_path):
         mid = (~small) & (np.abs(a64) < 1e12)
         assert err[mid].max() <= 2e-7, err[mid].max()
         assert (np.abs(got) <= 1.0000001).all()
+
+
+@pytest.mark.gpu
+def test_single_process_multi_context_gather(cases, tmp_path):
+    """adanerf_gather_to + adanerf_assemble_strips: the exchange a single-process host (adanerf --gpus N) uses instead
+    of RCCL.  Three contexts on this box's one GPU stand in for three GPUs; the assembled frame must equal the
+    unsharded frame byte for byte, through the Python host and through the C++ CLI."""
+    import subprocess
+    from adanerf_amd import build as B
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    w, h = 96, 72
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16") as r:
+        r.set_camera(z["pose"], z["rot"])
+        _, ref8, _ = r.render_numpy()
+    world = 3
+    rs = [adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", shard_rank=k, shard_world=world, strip_rows=8)
+          for k in range(world)]
+    try:
+        for r in rs:
+            r.init()
+            r.set_camera(z["pose"], z["rot"])
+        root = rs[0]
+        stride = root.info.rays_local_max * 4
+        gathered = root.empty((world, root.info.rays_local_max, 4), np.uint8)
+        image = root.empty((w * h, 4), np.uint8)
+        payloads = [None] + [r.empty((r.info.rays_local_max, 4), np.uint8) for r in rs[1:]]
+        root.render(gathered.ptr, None)                       # rank 0 renders straight into slot 0
+        for k in range(1, world):
+            rs[k].render(payloads[k], None)
+            root.gather_from(gathered.ptr + k * stride, rs[k], payloads[k], stride)
+        root.assemble_strips(gathered, image)
+        root.sync()
+        assert np.array_equal(image.numpy(), ref8)
+    finally:
+        for r in rs:
+            r.close()
+    # the C++ host
+    exe = B.build_cli()
+    md = str(tmp_path / "model")
+    O.write_model_dir(md, sc, wts)
+    imgs = []
+    for extra in ([], ["--gpus", "3", "--same-device"]):
+        out = subprocess.run([exe, md, "-s", str(w), str(h), "-w", "--frames", "100", "--yaw", "100", "--pitch", "0"] + extra,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "avg samples ppx" in out.stdout
+        imgs.append(open(os.path.join(md, "out.bmp"), "rb").read())
+    assert imgs[0] == imgs[1]
