@@ -72,6 +72,7 @@ struct adanerf_ctx {
   int shade_grid[3] = {0, 0, 0};
   int device = 0;                 // HIP device ordinal this context lives on
   hipEvent_t peer_event = nullptr;   // adanerf_gather_to: orders the destination stream behind the copy
+  uint64_t peer_tried = 0;           // bit d: peer access to device d has been requested once
 };
 
 namespace {
@@ -959,11 +960,12 @@ int adanerf_gather_to(adanerf_ctx* dst, void* d_dst, adanerf_ctx* src, const voi
   adanerf_ctx* c = src;
   BIND(src);
   if (src->device != dst->device) {
-    int can = 0;
-    if (hipDeviceCanAccessPeer(&can, src->device, dst->device) == hipSuccess && can) {
-      const hipError_t e = hipDeviceEnablePeerAccess(dst->device, 0);      // direct xGMI stores; harmless if already on
-      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-      else (void)hipGetLastError();
+    if (dst->device < 64 && !((src->peer_tried >> dst->device) & 1)) {
+      src->peer_tried |= 1ull << dst->device;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, src->device, dst->device) == hipSuccess && can)
+        (void)hipDeviceEnablePeerAccess(dst->device, 0);      // direct xGMI stores; "already enabled" is fine
+      (void)hipGetLastError();                                // without peer access the copy is staged by the runtime
     }
     HIP_TRY(c, hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, src->stream));
   } else {
