@@ -853,3 +853,12 @@ def test_single_process_multi_context_gather(cases, tmp_path):
         assert "avg samples ppx" in out.stdout
         imgs.append(open(os.path.join(md, "out.bmp"), "rb").read())
     assert imgs[0] == imgs[1]
+
+
+@pytest.mark.gpu
+def test_randomised_frames_against_oracle():
+    """A short run of tests/fuzz_parity.py (random frame sizes, cameras, N, thresholds, batch sizes, weight sets; fp32 and
+    bf16 against the oracle).  300 cases are logged in profiles/r01_fuzz_parity_300cases.log."""
+    import fuzz_parity
+    rng = np.random.default_rng(2024)
+    assert all(fuzz_parity.one_case(rng, i) for i in range(12))
