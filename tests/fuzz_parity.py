@@ -59,6 +59,8 @@ def one_case(rng, idx):
     pose = (centre + rng.uniform(-0.5, 0.5, 3).astype(np.float32) * size).astype(np.float32)
     rot = O.camera_rotation(float(rng.uniform(0, 360)), float(rng.uniform(-40, 40))) if kind != "ndc" else z["rot"]
     batch = int(rng.choice([-1, -1, 1, 7, 64, 1000, 4096]))
+    shard_world = int(rng.choice([1, 1, 2, 3, 5, 8]))
+    shard_rows = int(rng.choice([1, 3, 5, 8]))
     only = os.environ.get("FUZZ_ONLY")
     if only is not None and int(only) != idx:
         return True
@@ -106,6 +108,30 @@ def one_case(rng, idx):
     e16 = worst(rgb16, ref["rgb"])
     if e16 > 0.12:
         ok = False; msg.append("bf16 rgb err %.3f" % e16)
+    # sharded render of the same frame (random world size / strip height, all contexts on this GPU): byte-identical
+    if shard_world > 1:
+        rs = [adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=batch), precision="bf16", shard_rank=k,
+                                         shard_world=shard_world, strip_rows=shard_rows) for k in range(shard_world)]
+        try:
+            for q in rs:
+                q.init()
+                q.set_camera(pose, rot)
+            root = rs[0]
+            stride = root.info.rays_local_max * 4
+            gathered = root.empty((shard_world, max(root.info.rays_local_max, 1), 4), np.uint8)
+            image = root.empty((w * h, 4), np.uint8)
+            pay = [None] + [q.empty((max(q.info.rays_local_max, 1), 4), np.uint8) for q in rs[1:]]
+            root.render(gathered.ptr, None)
+            for k in range(1, shard_world):
+                rs[k].render(pay[k], None)
+                root.gather_from(gathered.ptr + k * stride, rs[k], pay[k], stride)
+            root.assemble_strips(gathered, image)
+            root.sync()
+            if not np.array_equal(image.numpy(), out["bf16"][1]):
+                ok = False; msg.append("sharded frame (world %d, %d-row strips) differs" % (shard_world, shard_rows))
+        finally:
+            for q in rs:
+                q.close()
     exp8 = O.to_rgba8(rgb)
     d8 = np.abs(rgba.astype(np.int16) - exp8.astype(np.int16))
     if not ((rgba[:, 3] == 255).all() and (d8[:, :3] <= 1).all()):
