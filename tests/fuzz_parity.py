@@ -37,20 +37,24 @@ def bins_of(r, n_rays, n_max):
 
 
 def one_case(rng, idx):
-    kind = rng.choice(["classroom", "barbershop", "random", "ndc"], p=[0.4, 0.2, 0.25, 0.15])
+    kind = rng.choice(["classroom", "barbershop", "random", "ndc", "pdf"], p=[0.35, 0.2, 0.2, 0.15, 0.1])
     if kind == "classroom":
         z, meta, sc = load_case("classroom_n8_thr02"); wts = case_weights(meta)
     elif kind == "barbershop":
         z, meta, sc = load_case("barbershop_n4_thr015"); wts = case_weights(meta)
     elif kind == "ndc":
         z, meta, sc = load_case("ndc_synthetic_n8"); wts = case_weights(meta)
+    elif kind == "pdf":                              # DONeRF inverse-CDF sampler + classic compositing
+        z, meta, sc = load_case("classroom_pdf_n8"); wts = case_weights(meta)
     else:
         z, meta, sc = load_case("synthetic_fixed8")
         wts = O.synthetic_weights(int(rng.integers(1 << 30)), oracle_bias=float(rng.uniform(-0.3, 0.5)), oracle_scale=float(rng.uniform(0.2, 1.0)))
     n_max = int(rng.choice([1, 2, 3, 4, 8, 8, 8, 12, 16, 24, 32]))
     thr = float(rng.choice([0.02, 0.05, 0.1, 0.15, 0.2, 0.3, 0.5, 0.9]))
-    if rng.random() < 0.08 and kind != "ndc":
+    if rng.random() < 0.08 and kind not in ("ndc", "pdf"):
         n_max, thr = 128, 0.0                     # dense mode
+    if kind == "pdf":
+        n_max, thr = int(rng.choice([2, 4, 8, 16, 32])), sc.threshold
     sc = dataclasses.replace(sc, num_samples=n_max, threshold=thr)
     w = int(rng.integers(1, 97)); h = int(rng.integers(1, 65))
     if n_max == 128:
