@@ -9,7 +9,9 @@ HOST = os.path.join(HERE, "host")
 LIBDIR = os.path.join(HERE, "lib")
 BINDIR = os.path.join(HERE, "bin")
 LIB_SOURCES = ["adanerf_hip.hip", "format.cpp", "pack.cpp"]
-LIB_DEPS = LIB_SOURCES + ["kernels.hip.hpp", "layout.hpp", "format.hpp", "pack.hpp", os.path.join("..", "..", "include", "adanerf_hip.h")]
+KERNEL_HEADERS = ["kernels.hip.hpp", "k_common.hip.hpp", "k_mlp_f32.hip.hpp", "k_compact.hip.hpp", "k_mlp16.hip.hpp",
+                  "k_sampling16.hip.hpp", "k_donerf.hip.hpp", "k_composite.hip.hpp"]
+LIB_DEPS = LIB_SOURCES + KERNEL_HEADERS + ["layout.hpp", "format.hpp", "pack.hpp", os.path.join("..", "..", "include", "adanerf_hip.h")]
 ARCH = "gfx950"
 
 

@@ -1,0 +1,262 @@
+// A4: adaptive selection + deterministic compaction (select_kernel / scan_blocks_kernel / expand_kernel), the dense-mode
+// expansion and the sampling-network debug view.
+// Device code only (gfx950, wave64); part of kernels.hip.hpp.
+#pragma once
+#include "k_common.hip.hpp"
+
+namespace adanerf {
+
+// ------------------------------------------------------------------------------------------
+// A4: adaptive selection + deterministic compaction
+// ------------------------------------------------------------------------------------------
+
+// Rays per workgroup of select_kernel (4 waves x kSelRaysPerBlock/4 rays, one ray at a time per wave) = rays per
+// entry of the block-total scan.  Small on purpose: a wave's serial loop over its rays is the critical path of a
+// small batch (an 83 200-ray shard of an 8-GPU frame), and more, shorter waves also schedule better on a whole
+// frame (measured 0.207 ms at 256 rays, 0.167 ms at 64 for 640 000 rays).
+#ifndef ADN_SEL_RPB
+#define ADN_SEL_RPB 64
+#endif
+constexpr int kSelRaysPerBlock = ADN_SEL_RPB;
+static_assert(kSelRaysPerBlock == 16 || kSelRaysPerBlock == 32 || kSelRaysPerBlock == 64, "segment must fit one wave");
+
+// Selection rule (src/nerf_raymarch_common.py:699-757 as a set rule):
+// keep the n_max largest values (ties: lower bin first) that are >= thr; if none is >= thr keep the
+// arg-max alone.  One wave per ray: lane holds bins (lane, lane + 64); the kept set lives in two
+// 64-bit ballot masks, so ascending-bin output order is a popcount.
+__device__ __forceinline__ void select_ray(float v0, float v1, int lane, int n_max, float thr, uint64_t* s0, uint64_t* s1) {
+  const uint64_t b0 = __ballot(v0 >= thr), b1 = __ballot(v1 >= thr);
+  const int c = __popcll(b0) + __popcll(b1);
+  uint64_t sel0, sel1;
+  if (c <= n_max && c > 0) {
+    sel0 = b0;
+    sel1 = b1;
+  } else {
+    const float m = wave_max_f32(fmaxf(v0, v1));
+    const uint64_t e0 = __ballot(v0 == m), e1 = __ballot(v1 == m);
+    if (c == 0) {
+      // nothing clears the threshold: keep the arg-max alone (lowest bin among equal maxima)
+      sel0 = e0 & (~e0 + 1);
+      sel1 = e0 ? 0 : (e1 & (~e1 + 1));
+      if ((sel0 | sel1) == 0) sel0 = 1;   // all-NaN row: keep bin 0 (undefined in the reference)
+    } else {
+      // More than n_max candidates: bisect a value threshold t in [thr, max] until exactly n_max values
+      // are >= t (v_cmp yields the lane mask directly, ~10 instructions per step, ~log2(range / gap)
+      // steps).  If the interval closes on a tie that straddles the cut-off, keep everything above the
+      // tie value plus the lowest-index members of the tie (the set rule's "lower bin first").
+      float lo = thr, hi = m;                    // count(v >= lo) = c > n_max
+      uint64_t g0 = e0, g1 = e1;                 // {v >= hi}
+      int ch = __popcll(e0) + __popcll(e1);
+      uint64_t t0 = b0, t1 = b1;                 // {v >= lo}
+      while (ch < n_max) {
+        const float mid = lo + (hi - lo) * 0.5f;
+        if (!(mid > lo) || !(mid < hi)) break;   // lo and hi are adjacent floats
+        const uint64_t m0 = __ballot(v0 >= mid), m1 = __ballot(v1 >= mid);
+        const int cm = __popcll(m0) + __popcll(m1);
+        if (cm > n_max) {
+          lo = mid;
+          t0 = m0;
+          t1 = m1;
+        } else {
+          hi = mid;
+          g0 = m0;
+          g1 = m1;
+          ch = cm;
+        }
+      }
+      if (ch >= n_max) {
+        // ch == n_max: {v >= hi} is the answer; ch > n_max only when more than n_max values equal the
+        // maximum (then lo..hi never moved): fall through to the tie rule with an empty "above" set
+        if (ch == n_max) {
+          sel0 = g0;
+          sel1 = g1;
+        } else {
+          g0 = 0;
+          g1 = 0;
+          ch = 0;
+          t0 = e0;
+          t1 = e1;
+          goto tie;
+        }
+      } else {
+      tie:
+        // every value in {v >= lo} \ {v >= hi} equals lo: take the first (n_max - ch) of them by bin index
+        const uint64_t q0 = t0 & ~g0, q1 = t1 & ~g1;
+        const int need = n_max - ch;
+        const int r0 = mbcnt64(q0), r1 = __popcll(q0) + mbcnt64(q1);
+        const uint64_t k0 = __ballot(((q0 >> lane) & 1) && r0 < need), k1 = __ballot(((q1 >> lane) & 1) && r1 < need);
+        sel0 = g0 | k0;
+        sel1 = g1 | k1;
+      }
+    }
+  }
+  *s0 = sel0;
+  *s1 = sel1;
+}
+
+__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ oracle, int n_rays, int n_max, float thr,
+                                                     int32_t* __restrict__ counts, uint8_t* __restrict__ selbin,
+                                                     float* __restrict__ selw, int32_t* __restrict__ block_total) {
+  __shared__ int wave_tot[4];
+  constexpr int RPW = kSelRaysPerBlock / 4;   // rays per wave
+  const int lane = lane_id();
+  const int wave = static_cast<int>(threadIdx.x) >> 6;
+  const int base = blockIdx.x * kSelRaysPerBlock + wave * RPW;
+  int total = 0;
+  // rows of the next group of 4 rays are requested before the current group is processed, so each wave keeps
+  // 8 row loads in flight while it computes (the kernel is bound by latency x bytes in flight, not by issue)
+  float n0[4], n1[4];
+  auto fetch = [&](int i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = base + i + u;
+      const float* row = oracle + static_cast<size_t>(r < n_rays ? r : 0) * kBins;
+      n0[u] = row[lane];
+      n1[u] = row[64 + lane];
+    }
+  };
+  fetch(0);
+#pragma unroll
+  for (int i = 0; i < RPW; i += 4) {
+    float v0[4], v1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v0[u] = n0[u];
+      v1[u] = n1[u];
+    }
+    if (i + 4 < RPW) fetch(i + 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = base + i + u;
+      if (r >= n_rays) break;     // wave-uniform
+      uint64_t s0, s1;
+      select_ray(v0[u], v1[u], lane, n_max, thr, &s0, &s1);
+      const int c0 = __popcll(s0);
+      const int cnt = c0 + __popcll(s1);
+      const size_t o = static_cast<size_t>(r) * n_max;
+      if ((s0 >> lane) & 1) {
+        const int rank = mbcnt64(s0);
+        selbin[o + rank] = static_cast<uint8_t>(lane);
+        selw[o + rank] = v0[u];
+      }
+      if ((s1 >> lane) & 1) {
+        const int rank = c0 + mbcnt64(s1);
+        selbin[o + rank] = static_cast<uint8_t>(64 + lane);
+        selw[o + rank] = v1[u];
+      }
+      if (lane == 0) counts[r] = cnt;
+      total += cnt;
+    }
+  }
+  if (lane == 0) wave_tot[wave] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) block_total[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+// exclusive scan of the per-block totals by one workgroup; writes S to *total
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(const int32_t* __restrict__ block_total, int n_blocks,
+                                                           int32_t* __restrict__ block_offset, int32_t* __restrict__ total) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (n_blocks + 1023) / 1024;
+  const int lo = t * per;
+  int s = 0;
+  for (int i = 0; i < per; ++i) {
+    const int k = lo + i;
+    if (k < n_blocks) s += block_total[k];
+  }
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;   // exclusive prefix of this thread's chunk
+  for (int i = 0; i < per; ++i) {
+    const int k = lo + i;
+    if (k < n_blocks) {
+      block_offset[k] = run;
+      run += block_total[k];
+    }
+  }
+  if (t == 1023) *total = part[1023];
+}
+
+// ray offsets + compacted (key, weight) arrays, ray-major / bins ascending
+// One thread per ray; the rays of one select_kernel workgroup are one wave segment, so the in-segment prefix is a
+// width-limited shuffle scan (no LDS, no barrier).
+__global__ __launch_bounds__(256) void expand_kernel(const int32_t* __restrict__ counts, const uint8_t* __restrict__ selbin,
+                                                     const float* __restrict__ selw, const int32_t* __restrict__ block_offset,
+                                                     int n_rays, int n_max, int32_t* __restrict__ ray_offsets,
+                                                     uint32_t* __restrict__ sample_key, float* __restrict__ sample_w) {
+  const int r = blockIdx.x * 256 + static_cast<int>(threadIdx.x);
+  const int c = (r < n_rays) ? counts[r] : 0;
+  const int seg_lane = r & (kSelRaysPerBlock - 1);
+  int x = c;
+#pragma unroll
+  for (int off = 1; off < kSelRaysPerBlock; off <<= 1) {
+    const int y = __shfl_up(x, off, kSelRaysPerBlock);
+    if (seg_lane >= off) x += y;
+  }
+  if (r >= n_rays) return;
+  const int o = block_offset[r / kSelRaysPerBlock] + x - c;
+  ray_offsets[r] = o;
+  const size_t src = static_cast<size_t>(r) * n_max;
+  for (int k = 0; k < c; ++k) {
+    sample_key[o + k] = (static_cast<uint32_t>(r) << 7) | selbin[src + k];
+    sample_w[o + k] = selw[src + k];
+  }
+}
+
+// Debug view of the sampling network (viewer 'O' key: copyResultSamplingNetwork -> samplesToImage,
+// adanerf_real_time_viewer/src/cuda/base_cuda_kernels.cu:487-528): pixel = ((0.5 + bin) / 128) of the three largest
+// outputs of the ray, largest first, in R, G, B.  The viewer sorts with a stable block radix sort, so equal values
+// rank lower bin first.  One wave per ray, three arg-max rounds.
+__global__ __launch_bounds__(256) void oracle_view_kernel(const float* __restrict__ oracle, int n_rays, uchar4* __restrict__ rgba8) {
+  const int lane = lane_id();
+  const int r = blockIdx.x * 4 + (static_cast<int>(threadIdx.x) >> 6);
+  if (r >= n_rays) return;   // wave-uniform
+  const float* row = oracle + static_cast<size_t>(r) * kBins;
+  float v0 = row[lane], v1 = row[64 + lane];
+  int bin[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float m = wave_max_f32(fmaxf(v0, v1));
+    const uint64_t e0 = __ballot(v0 == m), e1 = __ballot(v1 == m);
+    int b = k;   // all-NaN row: undefined in the reference
+    if (e0) b = __builtin_ctzll(e0);
+    else if (e1) b = 64 + __builtin_ctzll(e1);
+    bin[k] = b;
+    if (b == lane) v0 = -INFINITY;
+    if (b == 64 + lane) v1 = -INFINITY;
+  }
+  if (lane == 0) {
+    uchar4 px;
+    px.x = static_cast<unsigned char>((0.5f + static_cast<float>(bin[0])) / 128.0f * 255.0f);
+    px.y = static_cast<unsigned char>((0.5f + static_cast<float>(bin[1])) / 128.0f * 255.0f);
+    px.z = static_cast<unsigned char>((0.5f + static_cast<float>(bin[2])) / 128.0f * 255.0f);
+    px.w = 255;
+    rgba8[r] = px;
+  }
+}
+
+// thr == 0: every bin of every ray (src/nerf_raymarch_common.py:708-720); keys are implicit
+__global__ __launch_bounds__(256) void dense_expand_kernel(const float* __restrict__ oracle, int n_rays, int32_t* __restrict__ ray_offsets,
+                                                           int32_t* __restrict__ counts, uint32_t* __restrict__ sample_key,
+                                                           float* __restrict__ sample_w, int32_t* __restrict__ total) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t n = static_cast<size_t>(n_rays) * kBins;
+  if (i == 0) *total = static_cast<int32_t>(n);
+  if (i >= n) return;
+  sample_key[i] = static_cast<uint32_t>(i);
+  sample_w[i] = oracle[i];
+  if ((i & (kBins - 1)) == 0) {
+    const int r = static_cast<int>(i >> 7);
+    ray_offsets[r] = static_cast<int32_t>(i);
+    counts[r] = kBins;
+  }
+}
+
+}  // namespace adanerf

@@ -1,0 +1,125 @@
+// DONeRF inverse-CDF sampler (pdf_sample_kernel) and classic sigma/delta compositing.
+// Device code only (gfx950, wave64); part of kernels.hip.hpp.
+#pragma once
+#include "k_common.hip.hpp"
+
+namespace adanerf {
+
+// ------------------------------------------------------------------------------------------
+// DONeRF inverse-CDF sampler (FromClassifiedDepth) + classic sigma/delta compositing
+// ------------------------------------------------------------------------------------------
+
+struct DepthMap {          // warped depth t in [0,1] -> world depth (src/util/depth_transformations.py:37-58)
+  float d0, d1;
+  int32_t log_transform;   // 1: (d1-d0+1)^t - 1 + d0, 0: t (d1-d0) + d0
+};
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ float wave_incl_scan_f32(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float t = __shfl_up(v, off);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+// FromClassifiedDepth.generate + nerf_sample_pdf(det=True) (src/nerf_raymarch_common.py:606-660, 160-192):
+// sigmoid(oracle) + 1e-5 -> pdf -> cdf over the 129 bin edges -> invert at u = k/(n+1), k = 1..n.
+// One wave per ray; the cdf goes through a wave-private LDS row and every lane inverts its own u.
+__global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict__ oracle, int n_rays, int n, DepthMap dm,
+                                                         int32_t* __restrict__ ray_offsets, int32_t* __restrict__ counts,
+                                                         uint32_t* __restrict__ sample_key, float* __restrict__ sample_w,
+                                                         float* __restrict__ sample_z, int32_t* __restrict__ total) {
+  __shared__ float cdf_s[4][kBins + 1 + 3];
+  const int lane = lane_id();
+  const int wave = static_cast<int>(threadIdx.x) >> 6;
+  float* cdf = cdf_s[wave];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *total = n_rays * n;
+  for (int r = (blockIdx.x * 4 + wave); r < n_rays; r += gridDim.x * 4) {
+    const float* row = oracle + static_cast<size_t>(r) * kBins;
+    const float w0 = sigmoidf_dev(row[lane]) + 1e-5f, w1 = sigmoidf_dev(row[64 + lane]) + 1e-5f;
+    const float tot = wave_sum_f32(w0 + w1);
+    const float p0 = w0 / tot, p1 = w1 / tot;
+    const float cA = wave_incl_scan_f32(p0, lane);
+    const float totA = __shfl(cA, 63);
+    const float cB = totA + wave_incl_scan_f32(p1, lane);
+    if (lane == 0) cdf[0] = 0.f;
+    cdf[1 + lane] = cA;
+    cdf[65 + lane] = cB;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      ray_offsets[r] = r * n;
+      counts[r] = n;
+    }
+    for (int k = lane; k < n; k += 64) {
+      const float u = static_cast<float>(k + 1) / static_cast<float>(n + 1);     // linspace(0,1,n+2)[k+1]
+      int lo = 0, hi = kBins + 1;                                                 // searchsorted(cdf, u, right=True)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid + 1;
+        else hi = mid;
+      }
+      const int below = max(lo - 1, 0), above = min(lo, kBins);
+      const float c0 = cdf[below], c1 = cdf[above];
+      float denom = c1 - c0;
+      denom = denom < 1e-5f ? 1.0f : denom;
+      const float t = (u - c0) / denom;
+      const float b0 = static_cast<float>(below) * (1.0f / kBins), b1 = static_cast<float>(above) * (1.0f / kBins);
+      const float zw = __fadd_rn(b0, __fmul_rn(t, b1 - b0));
+      float z;
+      if (dm.log_transform) z = powf(static_cast<float>(static_cast<double>(dm.d1) - dm.d0 + 1.0), zw) - 1.0f + dm.d0;
+      else z = zw * (dm.d1 - dm.d0) + dm.d0;
+      const size_t o = static_cast<size_t>(r) * n + k;
+      sample_z[o] = z;
+      sample_key[o] = (static_cast<uint32_t>(r) << 7) | static_cast<uint32_t>(min(below, kBins - 1));
+      sample_w[o] = 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// nerf_raw2outputs (src/nerf_raymarch_common.py:19-68): alpha = 1 - exp(-relu(raw_a) * (z[k+1]-z[k]) * |d|),
+// last interval 1e10; rgb = sigmoid(raw); front-to-back with the 1e-10 transmittance floor.
+__global__ __launch_bounds__(256) void composite_classic_kernel(const float4* __restrict__ raw, const float* __restrict__ sample_z,
+                                                                const float* __restrict__ rays, int n_rays, int n,
+                                                                float* __restrict__ rgb_out, uchar4* __restrict__ rgba8_out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  const float4 d4 = reinterpret_cast<const float4*>(rays + static_cast<size_t>(r) * 8)[1];
+  const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d4.x, d4.x), __fmul_rn(d4.y, d4.y)), __fmul_rn(d4.z, d4.z)));
+  const size_t o = static_cast<size_t>(r) * n;
+  float cr = 0.f, cg = 0.f, cb = 0.f, T = 1.f;
+  float zk = sample_z[o];
+  for (int k = 0; k < n; ++k) {
+    const float4 v = raw[o + k];
+    const float zn = (k + 1 < n) ? sample_z[o + k + 1] : 0.f;
+    const float dist = __fmul_rn((k + 1 < n) ? __fsub_rn(zn, zk) : 1e10f, dn);
+    const float al = __fsub_rn(1.0f, expf(-__fmul_rn(fmaxf(v.w, 0.f), dist)));
+    const float wt = __fmul_rn(al, T);
+    cr = __fadd_rn(cr, __fmul_rn(wt, sigmoidf_dev(v.x)));
+    cg = __fadd_rn(cg, __fmul_rn(wt, sigmoidf_dev(v.y)));
+    cb = __fadd_rn(cb, __fmul_rn(wt, sigmoidf_dev(v.z)));
+    T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, al), 1e-10f));
+    zk = zn;
+  }
+  if (rgb_out) {
+    rgb_out[3 * static_cast<size_t>(r) + 0] = cr;
+    rgb_out[3 * static_cast<size_t>(r) + 1] = cg;
+    rgb_out[3 * static_cast<size_t>(r) + 2] = cb;
+  }
+  if (rgba8_out) {
+    uchar4 px;
+    px.x = static_cast<unsigned char>(fminf(fmaxf(cr, 0.f), 1.f) * 255.0f);
+    px.y = static_cast<unsigned char>(fminf(fmaxf(cg, 0.f), 1.f) * 255.0f);
+    px.z = static_cast<unsigned char>(fminf(fmaxf(cb, 0.f), 1.f) * 255.0f);
+    px.w = 255;
+    rgba8_out[r] = px;
+  }
+}
+
+}  // namespace adanerf

@@ -1,0 +1,500 @@
+// A5 + A6: 16-bit MFMA engine (LDS weight ring, layer_16), the fused PE + shading MLP kernels shade_mlp16_kernel /
+// shade_mlp32_kernel and the debug kernel shade_features_kernel.
+// Device code only (gfx950, wave64); part of kernels.hip.hpp.
+#pragma once
+#include "k_common.hip.hpp"
+#include "k_mlp_f32.hip.hpp"
+
+namespace adanerf {
+
+// ------------------------------------------------------------------------------------------
+// A5 + A6: fused PE + shading MLP
+// ------------------------------------------------------------------------------------------
+
+struct ShadeArgs {
+  ShadeParams sp;
+  NetParams net;
+  const float* rays;          // [*,8]
+  const uint32_t* sample_key; // [S]
+  const float* sample_z;      // [S] world depth per sample (inverse-CDF sampler); null -> ztab[bin]
+  const int32_t* total;       // device S (may be null -> max_samples)
+  int32_t max_samples;
+  float* raw_out;             // [S,4]
+};
+
+struct Bf16 {
+  typedef bf16x8 vec8;
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  }
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+struct Fp16 {
+  typedef f16x8 vec8;
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+  }
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// ---- weight streaming through LDS -------------------------------------------------------------
+// The packed 16-bit shading net is one linear stream of 1 KiB A fragments in consumption order
+// (layer, tile m, k-step s).  All waves of a workgroup consume it in lockstep, so it is staged ONCE
+// per workgroup: 8 KiB chunks (8 fragments; each of the 8 waves DMA-copies one fragment with
+// global_load_lds_dwordx4, LDS image lane-linear = fragment order, so ds_read_b128 is conflict
+// free) into a 4-slot ring.  One s_barrier per chunk; counted vmcnt keeps 2-3 chunks in flight
+// across the barrier (never vmcnt(0) in the loop).  Each wave keeps the current chunk's 8
+// fragments in registers and re-fills fragment i from the NEXT chunk right after the MFMA that
+// consumed it, so LDS latency hides behind the other 7 MFMAs.
+// Timing-ablation switches for tools/ablate.sh (results become WRONG; never defined in the shipped build):
+//   1: no chunk boundary (no wait, no barrier, no DMA)   2: no LDS re-fill of the fragment registers
+//   4: no bias read (acc starts at 0)                    8: no ReLU/convert epilogue
+//  16: boundary without the DMA issue                   32: boundary without wait + barrier
+//  64: (sampling kernel) no cross-tile software pipeline of bias reads / epilogue
+// 128: (sampling kernels) v_sin_f32 instead of the libm-grade sincosf in the oracle-feature encoding
+// ADN_ABLATE applies to shade_mlp16_kernel, ADN_ABLATE_S to sample_mlp16x3_kernel.
+#ifndef ADN_ABLATE
+#define ADN_ABLATE 0
+#endif
+#ifndef ADN_ABLATE_S
+#define ADN_ABLATE_S 0
+#endif
+// Ring geometry.  CF = fragments (KiB) per chunk = MFMAs per wave between barriers; RS = ring slots.
+// At boundary k a wave waits for its own pieces of chunk k+1, so RS-3 further chunks stay in flight.
+#ifndef ADN_CF
+#define ADN_CF 16
+#endif
+#ifndef ADN_RS
+#define ADN_RS 4
+#endif
+#ifndef ADN_CF_S
+#define ADN_CF_S 16
+#endif
+#ifndef ADN_RS_S
+#define ADN_RS_S 6
+#endif
+constexpr int kRegFrags = 4;     // fragments held in registers per wave (re-fill distance in MFMAs)
+constexpr int kShadeFrags16 = 32 + 4 * 128 + 160 + 2 * 128 + 144 + 72 + 8;   // 1184 per pass (FP=10, FD=4)
+constexpr int kShadeBiasFloats = 8 * 256 + 288 + 128 + 32;                     // 2496
+
+// CF / RS / LPW (fragments each wave DMA-copies per chunk = CF / waves) are compile-time; the slot a
+// chunk lives in is a run-time counter, so any tile length that is a multiple of CF works.
+template <int CF, int RS, int LPW>
+struct WStream {
+  static constexpr int kChunkBytes = CF * 1024;
+  const char* gbase;     // stream start (global)
+  uint32_t gbytes;       // stream length in bytes (multiple of kChunkBytes)
+  uint32_t goff;         // byte offset of the next chunk to issue
+  uint32_t lane_off;     // lane * 16
+  uint32_t wave_off;     // byte offset of this wave's first fragment inside a chunk
+  uint32_t slot_cur;     // ring slot of the chunk being consumed (wave-uniform)
+  uint32_t rd_cur;       // LDS byte address of (current chunk, this lane)
+  uint32_t rd_next;      // LDS byte address of (next chunk, this lane)
+  uint32_t lds_base;     // LDS byte address of the ring
+  u32x4 R[kRegFrags];    // register ring: fragment p (position inside the chunk) lives in R[p % kRegFrags]
+};
+
+__device__ __forceinline__ u32x4 lds_read128(uint32_t byte_addr) {
+  typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
+  return *((lds_u32x4_ptr)(uintptr_t)byte_addr);
+}
+
+template <int CF, int RS, int LPW>
+__device__ __forceinline__ void ws_issue(WStream<CF, RS, LPW>& st, uint32_t slot) {
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) {
+    const char* src = st.gbase + st.goff + st.wave_off + i * 1024 + st.lane_off;
+    const uint32_t dst = st.lds_base + slot * (CF * 1024) + st.wave_off + i * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)static_cast<uintptr_t>(dst), 16, 0, 0);
+  }
+  st.goff += CF * 1024;
+  if (st.goff >= st.gbytes) st.goff = 0;
+}
+
+// chunk boundary k: own pieces of chunk k+1 have landed (<= (RS-3) LPW younger DMAs outstanding); barrier =>
+// chunk k+1 complete in LDS for every wave and every wave has consumed chunk k-1 (its MFMAs were
+// issued before the barrier, so its ds_reads returned) => refill the slot of chunk k-1 with chunk k+RS-1.
+template <int ABL, int CF, int RS, int LPW>
+__device__ __forceinline__ void ws_boundary(WStream<CF, RS, LPW>& st) {
+  static_assert(RS >= 3 && (RS - 2) * LPW < 64, "vmcnt is a 6-bit counter");
+  if (ABL & 1) return;
+  if (!(ABL & 32)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 3) * LPW) : "memory");   // 32: no wait/barrier
+  const uint32_t old = st.slot_cur;
+  st.slot_cur = (old + 1 == RS) ? 0 : old + 1;
+  const uint32_t nxt = (st.slot_cur + 1 == RS) ? 0 : st.slot_cur + 1;
+  if (!(ABL & 16)) ws_issue(st, old);                                                                       // 16: no DMA
+  st.rd_cur = st.rd_next;
+  st.rd_next = st.lds_base + nxt * (CF * 1024) + st.lane_off;
+}
+
+// fragment position p inside the current chunk has just been consumed: re-fill its register with fragment
+// p + kRegFrags (same chunk, or the next chunk -- already landed: see ws_boundary)
+template <int ABL, int CF, int RS, int LPW>
+__device__ __forceinline__ void ws_refill(WStream<CF, RS, LPW>& st, int p) {
+  if (ABL & 2) {
+    asm volatile("" : "+v"(st.R[p % kRegFrags]));
+    return;
+  }
+  const int q = p + kRegFrags;
+  st.R[p % kRegFrags] = (q < CF) ? lds_read128(st.rd_cur + q * 1024) : lds_read128(st.rd_next + (q - CF) * 1024);
+}
+
+template <int CF, int RS, int LPW>
+__device__ __forceinline__ void ws_start(WStream<CF, RS, LPW>& st, const void* gbase, uint32_t gbytes, char* lds, int wave, int lane) {
+  st.gbase = reinterpret_cast<const char*>(gbase);
+  st.gbytes = gbytes;
+  st.goff = 0;
+  st.lane_off = lane * 16;
+  st.wave_off = wave * LPW * 1024;
+  st.lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds));
+#pragma unroll
+  for (int k = 0; k < RS - 1; ++k) ws_issue(st, k);
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 2) * LPW) : "memory");
+  st.slot_cur = RS - 1;                       // the first boundary moves to slot 0 = chunk 0
+  st.rd_cur = st.lds_base + st.lane_off;      // unused until then
+  st.rd_next = st.lds_base + st.lane_off;     // chunk 0
+#pragma unroll
+  for (int i = 0; i < kRegFrags; ++i) st.R[i] = lds_read128(st.rd_next + i * 1024);
+}
+
+// ReLU on the raw bits: max(int(x), 0) is +0.0 for every negative float and the identity for positive
+// ones -- one v_max_i32, no canonicalising v_max_f32 pair.
+__device__ __forceinline__ float relu_bits(float x) {
+  int i = __builtin_bit_cast(int, x);
+  i = i > 0 ? i : 0;
+  return __builtin_bit_cast(float, i);
+}
+
+template <class ET, int F>
+__device__ __forceinline__ void pe_pack(const float x[3], int h, uint32_t* out) {
+  float t[pe_slots(F)];
+  pe_eval<F, false>(x, h, t);
+#pragma unroll
+  for (int q = 0; q < pe_slots(F) / 2; ++q) out[q] = ET::pack(t[2 * q], t[2 * q + 1]);
+}
+
+// Bias block [m][h][16] for this lane-half from LDS with hand-issued reads: hipcc cannot see an asm
+// ds_read, so it neither assumes aliasing with the LDS-DMA ring (which costs an s_waitcnt vmcnt(0) drain
+// per tile) nor needs the 3-VALU-per-value SGPR select that scalar loads cost.  The wait statement names
+// every destination "+v" so no consumer is scheduled above it (cdna_hip_programming.md 5.7 form ii).
+struct BiasRegs {
+  f32x4 b0, b1, b2, b3;
+};
+// issue now, consume later: the reads stay in flight behind the MFMAs of the current tile
+__device__ __forceinline__ void lds_bias_issue(uint32_t byte_addr, BiasRegs& r) {
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+               : "=&v"(r.b0), "=&v"(r.b1), "=&v"(r.b2), "=&v"(r.b3)
+               : "v"(byte_addr));
+}
+__device__ __forceinline__ void lds_bias_take(BiasRegs& r, f32x16* acc) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.b0), "+v"(r.b1), "+v"(r.b2), "+v"(r.b3));
+  f32x16 a;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = r.b0[e];
+    a[4 + e] = r.b1[e];
+    a[8 + e] = r.b2[e];
+    a[12 + e] = r.b3[e];
+  }
+  *acc = a;
+}
+
+__device__ __forceinline__ void lds_bias16(uint32_t byte_addr, f32x16* acc) {
+  f32x4 b0, b1, b2, b3;
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+               : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+               : "v"(byte_addr));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+  f32x16 a;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = b0[e];
+    a[4 + e] = b1[e];
+    a[8 + e] = b2[e];
+    a[12 + e] = b3[e];
+  }
+  *acc = a;
+}
+
+// One 16-bit layer for one 32-sample column block.  Input = two register segments (S1 then S2
+// k-steps of 8 slots = 4 packed dwords each); output tile m lands in out[8m .. 8m+7] (packed pairs).
+// FPOS = position of the layer's first fragment in the stream modulo the chunk size.
+// KEEP_F32_TILE >= 0: that tile's raw accumulator is returned in *keep instead (alpha / rgb rows);
+// kKeepAllF32: all of them, in keep[0 .. MT-1] (the sampling net's 128 raw outputs).
+// epilogue of one accumulator quad g (values 4g..4g+3 of tile m): convert, ReLU on the packed pairs
+template <class ET, bool RELU>
+__device__ __forceinline__ void epilogue_quad_16(const f32x16& acc, int m, int g, uint32_t* out) {
+  // convert first, then ReLU on the packed pair: max(int16, 0) clears every negative bf16/f16
+  // (one v_cvt_pk + one v_pk_max_i16 per two values)
+  uint32_t p0 = ET::pack(acc[4 * g + 0], acc[4 * g + 1]), p1 = ET::pack(acc[4 * g + 2], acc[4 * g + 3]);
+  if (RELU) {
+    const s16x2 z = {0, 0};
+    p0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p0), z));
+    p1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p1), z));
+  }
+  out[8 * m + 2 * g + 0] = p0;
+  out[8 * m + 2 * g + 1] = p1;
+}
+
+constexpr int kKeepAllF32 = -2;   // layer_16 KEEP_F32_TILE: every tile's raw accumulator goes to keep[m]
+template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
+__device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, const uint32_t* in1, const uint32_t* in2,
+                                         uint32_t* out, f32x16* keep = nullptr) {
+  constexpr int CF = ADN_CF;
+  constexpr int KS = S1 + S2;
+  // bias_addr: LDS byte address of this layer's bias block for THIS lane-half ([m][h][16] floats)
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    f32x16 acc;
+    if (ADN_ABLATE & 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    } else {
+      lds_bias16(bias_addr + m * 128, &acc);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int f = (FPOS + m * KS + s) % CF;     // position inside the chunk; compile-time after unrolling
+      if (f == 0) ws_boundary<ADN_ABLATE>(st);
+      const uint32_t* src = (s < S1) ? (in1 + 4 * s) : (in2 + 4 * (s - S1));
+      u32x4 b = {src[0], src[1], src[2], src[3]};
+      acc = ET::mfma(st.R[f % kRegFrags], b, acc);
+      ws_refill<ADN_ABLATE>(st, f);
+    }
+    if (KEEP_F32_TILE == kKeepAllF32) {
+      keep[m] = acc;
+    } else if (KEEP_F32_TILE == m) {
+      *keep = acc;
+    } else if (ADN_ABLATE & 8) {
+      asm volatile("" ::"v"(acc));
+#pragma unroll
+      for (int g = 0; g < 8; ++g) asm volatile("" : "=v"(out[8 * m + g]));
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(acc, m, g, out);
+    }
+  }
+}
+
+// Loads the sample's ray record and evaluates position (+ optional unit direction).
+__device__ __forceinline__ void load_sample(const ShadeArgs& a, int s, int total, float x[3], float dpe[3]) {
+  const int si = (s < total) ? s : (total > 0 ? total - 1 : 0);
+  const uint32_t key = a.sample_key[si];
+  const uint32_t ray = key >> 7;
+  const int bin = static_cast<int>(key & 127u);
+  const float4* rr = reinterpret_cast<const float4*>(a.rays + static_cast<size_t>(ray) * 8);
+  const float4 o4 = rr[0], d4 = rr[1];
+  const float o[3] = {o4.x, o4.y, o4.z}, d[3] = {d4.x, d4.y, d4.z};
+  sample_position(a.sp, o, d, a.sample_z ? a.sample_z[si] : a.sp.ztab[bin], x);
+  if (a.sp.unit_dir) unit3(d, dpe);
+  else {
+    dpe[0] = d[0];
+    dpe[1] = d[1];
+    dpe[2] = d[2];
+  }
+}
+
+// Wave-private LDS stash for packed PE slots (hand-issued so hipcc neither orders them against the LDS-DMA
+// ring with vmcnt(0) nor keeps 24 VGPRs alive across the layer stack).  Layout [dword group of 4][lane]:
+// b128 accesses are lane-linear, hence conflict-free.
+template <int NQ>   // NQ = number of b128 groups
+__device__ __forceinline__ void lds_stash_write(uint32_t byte_addr, const uint32_t* v) {
+#pragma unroll
+  for (int g = 0; g < NQ; ++g) {
+    const u32x4 t = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+    asm volatile("ds_write_b128 %0, %1" ::"v"(byte_addr + g * 1024), "v"(t) : "memory");
+  }
+}
+template <int NQ>
+__device__ __forceinline__ void lds_stash_read(uint32_t byte_addr, uint32_t* v) {
+  u32x4 t[NQ];
+#pragma unroll
+  for (int g = 0; g < NQ; ++g) asm volatile("ds_read_b128 %0, %1" : "=&v"(t[g]) : "v"(byte_addr + g * 1024));
+  if (NQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[NQ > 3 ? 3 : 0]));
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[NQ > 1 ? 1 : 0]));
+#pragma unroll
+  for (int g = 0; g < NQ; ++g) {
+    v[4 * g] = t[g][0];
+    v[4 * g + 1] = t[g][1];
+    v[4 * g + 2] = t[g][2];
+    v[4 * g + 3] = t[g][3];
+  }
+}
+
+// A5+A6, 16-bit MFMA path.  Workgroup = WAVES waves x 32 samples; persistent over tiles; the weight
+// stream is cyclic so DMA prefetch runs across tile boundaries.  WAVES = 4 with two workgroups per CU
+// (two waves per SIMD from DIFFERENT workgroups): each workgroup has its own ring and barriers, so the
+// two waves sharing a SIMD are not in lockstep and one computes while the other waits at its barrier.
+template <class ET, int FP, int FD, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_kernel(ShadeArgs a) {
+  static_assert(FP == 10 && FD == 4, "fragment positions below assume the 10-4 shading encoding");
+  static_assert(WAVES == 4 || WAVES == 8, "chunk = 8 fragments");
+  constexpr int QP = pe_slots(FP), QD = pe_slots(FD);
+  constexpr int TILE = WAVES * 32, CF = ADN_CF, RS = ADN_RS, LPW = CF / WAVES;
+  constexpr int kRingBytes = CF * RS * 1024;
+  static_assert(CF % WAVES == 0 && CF % kRegFrags == 0 && kShadeFrags16 % CF == 0 && CF % 8 == 0 && CF <= 32, "chunk geometry");
+  typedef WStream<CF, RS, LPW> WS;
+#ifndef ADN_STASH
+#define ADN_STASH 1   // 1: PE slots computed once per tile and parked in LDS; 0: sample re-loaded at layers 5 / view
+#endif
+  constexpr int kStashBytes = ADN_STASH ? WAVES * (QP / 8 + QD / 8) * 1024 : 0;
+  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kShadeBiasFloats * 4 + kStashBytes];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const uint32_t stash = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + kShadeBiasFloats * 4 +
+                         wave * (QP / 8 + QD / 8) * 1024 + lane * 16;
+  int total = a.total ? *a.total : a.max_samples;
+  if (total > a.max_samples) total = a.max_samples;
+  const int ntiles = (total + TILE - 1) / TILE;
+  if (static_cast<int>(blockIdx.x) >= ntiles) return;    // workgroup-uniform
+
+  {
+    float* lds_bias = reinterpret_cast<float*>(lds + kRingBytes);
+    for (int i = threadIdx.x; i < kShadeBiasFloats; i += blockDim.x) lds_bias[i] = a.net.bias[i];
+  }
+  __syncthreads();
+  WS st;
+  ws_start(st, a.net.w, kShadeFrags16 * 1024, lds, wave, lane);
+
+  // LDS byte address of the bias blocks of this lane-half
+  const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
+  const uint32_t* bo = a.net.b_off;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int s = tile * TILE + wave * 32 + j;
+    uint32_t hA[64], hB[64];
+    {
+      float x[3], dpe[3];
+      load_sample(a, s, total, x, dpe);
+      uint32_t pts[QP / 2];
+      pe_pack<ET, FP>(x, h, pts);
+      if (ADN_STASH) {
+        uint32_t dirs[QD / 2];
+        pe_pack<ET, FD>(dpe, h, dirs);
+        lds_stash_write<QP / 8>(stash, pts);
+        lds_stash_write<QD / 8>(stash + (QP / 8) * 1024, dirs);
+      }
+      layer_16<ET, WS, QP / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, lane, pts, pts, hA);
+    }
+#pragma unroll 1
+    for (int l = 1; l <= 3; l += 2) {
+      layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l] * 4, lane, hA, hA, hB);
+      layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l + 1] * 4, lane, hB, hB, hA);
+    }
+    {
+      // the skip connection re-loads the sample and re-evaluates the 32 position slots instead of
+      // holding 16 (+6) VGPRs across layers 1-4 (30 v_sin per lane vs ~600 MFMA issue slots)
+      uint32_t pts[QP / 2];
+      if (ADN_STASH) {
+        lds_stash_read<QP / 8>(stash, pts);
+      } else {
+        float x[3], dpe[3];
+        load_sample(a, s, total, x, dpe);
+        pe_pack<ET, FP>(x, h, pts);
+      }
+      layer_16<ET, WS, QP / 8, 16, 8, true, 0>(st, bias0 + bo[5] * 4, lane, pts, hA, hB);   // cat([pts, h])
+    }
+    layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[6] * 4, lane, hB, hB, hA);
+    layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[7] * 4, lane, hA, hA, hB);
+    f32x16 alpha_tile;
+    layer_16<ET, WS, 16, 0, 9, false, 0, 8>(st, bias0 + bo[8] * 4, lane, hB, hB, hA, &alpha_tile);      // feature (+alpha row)
+    const float alpha = alpha_tile[0];
+    {
+      uint32_t dirs[QD / 2];
+      if (ADN_STASH) {
+        lds_stash_read<QD / 8>(stash + (QP / 8) * 1024, dirs);
+      } else {
+        float x[3], dpe[3];
+        load_sample(a, s, total, x, dpe);
+        pe_pack<ET, FD>(dpe, h, dirs);
+      }
+      layer_16<ET, WS, 16, QD / 8, 4, true, (32 + 4 * 128 + 160 + 2 * 128 + 144) % CF>(st, bias0 + bo[9] * 4, lane, hA, dirs, hB);             // cat([feature, dir])
+    }
+    f32x16 rgb_tile;
+    layer_16<ET, WS, 8, 0, 1, false, (32 + 4 * 128 + 160 + 2 * 128 + 144 + 72) % CF, 0>(st, bias0 + bo[10] * 4, lane, hB, hB, hA, &rgb_tile);
+    if (h == 0 && s < total)
+      *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(rgb_tile[0], rgb_tile[1], rgb_tile[2], alpha);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+// fp32 parity mode of the shading net: same structure on the fp32 MFMA engine, accurate sincos.
+template <int FP, int FD>
+__global__ __launch_bounds__(256) void shade_mlp32_kernel(ShadeArgs a) {
+  constexpr int QP = pe_slots(FP), QD = pe_slots(FD);
+  constexpr int TILE = 4 * 32;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  int total = a.total ? *a.total : a.max_samples;
+  if (total > a.max_samples) total = a.max_samples;
+  const u32x4* w = a.net.w;
+  const float* b = a.net.bias;
+
+  for (int tile = blockIdx.x; tile * TILE < total; tile += gridDim.x) {
+    const int s = tile * TILE + wave * 32 + j;
+    if (tile * TILE + wave * 32 >= total) continue;
+    // the weight addresses do not depend on the tile: without this the compiler hoists every A-fragment
+    // load out of the tile loop (loop-invariant code motion) and spills thousands of registers
+    asm volatile("" : "+v"(w), "+v"(b));
+    float x[3], dpe[3];
+    load_sample(a, s, total, x, dpe);
+    float pts[QP], dirs[QD], hA[144], hB[128];      // hA also receives the 9-tile feature(+alpha) layer
+    pe_eval<FP, true>(x, h, pts);
+    pe_eval<FD, true>(dpe, h, dirs);
+    layer_f32<QP, 0, 8, true>(w + a.net.w_off[0], b + a.net.b_off[0], lane, pts, pts, hA);
+#pragma unroll 1
+    for (int l = 1; l <= 3; l += 2) {
+      layer_f32<128, 0, 8, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, hA, hA, hB);
+      layer_f32<128, 0, 8, true>(w + a.net.w_off[l + 1], b + a.net.b_off[l + 1], lane, hB, hB, hA);
+    }
+    layer_f32<QP, 128, 8, true>(w + a.net.w_off[5], b + a.net.b_off[5], lane, pts, hA, hB);       // cat([pts, h])
+    layer_f32<128, 0, 8, true>(w + a.net.w_off[6], b + a.net.b_off[6], lane, hB, hB, hA);
+    layer_f32<128, 0, 8, true>(w + a.net.w_off[7], b + a.net.b_off[7], lane, hA, hA, hB);
+    layer_f32<128, 0, 9, false>(w + a.net.w_off[8], b + a.net.b_off[8], lane, hB, hB, hA);         // feature (+alpha row)
+    const float alpha = hA[128];
+    layer_f32<128, QD, 4, true>(w + a.net.w_off[9], b + a.net.b_off[9], lane, hA, dirs, hB);       // cat([feature, dir])
+    float rgb[16];
+    layer_f32<64, 0, 1, false>(w + a.net.w_off[10], b + a.net.b_off[10], lane, hB, hB, rgb);
+    if (h == 0 && s < total)
+      *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(rgb[0], rgb[1], rgb[2], alpha);
+  }
+}
+
+// Debug/parity: explicit shading-net input features in the reference's column order.
+template <int FP, int FD>
+__global__ __launch_bounds__(256) void shade_features_kernel(ShadeArgs a, float* feat) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.max_samples) return;
+  float x[3], dpe[3];
+  load_sample(a, s, a.max_samples, x, dpe);
+  constexpr int NP = 3 + 6 * FP, ND = 3 + 6 * FD;
+  float* f = feat + static_cast<size_t>(s) * (NP + ND);
+  for (int c = 0; c < 3; ++c) {
+    f[c] = x[c];
+    f[NP + c] = dpe[c];
+  }
+  for (int b = 0; b < FP; ++b)
+    for (int c = 0; c < 3; ++c) {
+      float sn, co;
+      sincosf(x[c] * static_cast<float>(1 << b), &sn, &co);
+      f[3 + 6 * b + c] = sn;
+      f[3 + 6 * b + 3 + c] = co;
+    }
+  for (int b = 0; b < FD; ++b)
+    for (int c = 0; c < 3; ++c) {
+      float sn, co;
+      sincosf(dpe[c] * static_cast<float>(1 << b), &sn, &co);
+      f[NP + 3 + 6 * b + c] = sn;
+      f[NP + 3 + 6 * b + 3 + c] = co;
+    }
+}
+
+}  // namespace adanerf

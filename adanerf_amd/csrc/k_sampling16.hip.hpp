@@ -1,0 +1,266 @@
+// A1+A2+A3 on the 16-bit MFMA pipe: the split-precision sampling kernel sample_mlp16x3_kernel (default) and the
+// opt-in plain-fp16 kernel sample_mlp16_kernel.
+// Device code only (gfx950, wave64); part of kernels.hip.hpp.
+#pragma once
+#include "k_mlp16.hip.hpp"
+
+namespace adanerf {
+
+// ---- split-precision sampling MLP: fp16 hi + 2^-11 * fp16 lo', three MFMAs per term --------------
+// x ~= hi + lo' / 2048 with hi = fp16(x), lo' = fp16((x - hi) * 2048): 22 significant bits and no
+// dependence on fp16 subnormals.  W.x = Whi.xhi + (Whi.xlo' + Wlo'.xhi) / 2048 (the lo'.lo' term is
+// 2^-22 relative and dropped).  Main and cross products accumulate in separate fp32 accumulators.
+// Measured against an fp64 reference on the shipped weights: max error 1.9e-6 (numpy sgemm: 2.4e-6),
+// identical selections on 100 % of rays -- at 3/16 of the fp32-MFMA cycle count.
+// kSplitScale (2^11) is defined in pack.hpp
+
+__device__ __forceinline__ void split_pack(float v0, float v1, uint32_t* hi, uint32_t* lo) {
+  f32x2 v = {v0, v1};
+  f16x2 h = __builtin_convertvector(v, f16x2);
+  f32x2 hf = __builtin_convertvector(h, f32x2);
+  f32x2 r = (v - hf) * kSplitScale;
+  *hi = __builtin_bit_cast(uint32_t, h);
+  *lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+}
+
+// One layer, fragments arrive as (hi, lo') pairs per k-step.  FPOS: first fragment position mod the chunk size.
+// epilogue of one accumulator pair (values 2*pi, 2*pi+1 of tile m): v = acc + cross / 2048, then either
+// the fp32 output (last layer) or ReLU + hi/lo' split for the next layer
+template <bool LAST>
+__device__ __forceinline__ void epilogue_pair_16x3(const f32x16& acc, const f32x16& cross, int m, int pi, uint32_t* out_hi,
+                                                   uint32_t* out_lo, float* out_f32) {
+  float v0 = __builtin_fmaf(cross[2 * pi], 1.0f / kSplitScale, acc[2 * pi]);
+  float v1 = __builtin_fmaf(cross[2 * pi + 1], 1.0f / kSplitScale, acc[2 * pi + 1]);
+  if (LAST) {
+    out_f32[16 * m + 2 * pi] = v0;
+    out_f32[16 * m + 2 * pi + 1] = v1;
+  } else {
+    split_pack(relu_bits(v0), relu_bits(v1), &out_hi[8 * m + pi], &out_lo[8 * m + pi]);
+  }
+}
+
+template <class WS, int KS, int MT, bool LAST, int FPOS>
+__device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane, const uint32_t* in_hi,
+                                           const uint32_t* in_lo, uint32_t* out_hi, uint32_t* out_lo, float* out_f32) {
+  // Software pipeline across output tiles (one wave per SIMD: nothing else hides these latencies):
+  //  - the bias block of tile m+1 is requested right after tile m's accumulators are initialised,
+  //  - the epilogue of tile m-1 is spread, one accumulator pair per k-step, over tile m's MFMAs.
+  constexpr bool PIPE = !(ADN_ABLATE_S & 64);
+  BiasRegs br;
+  f32x16 pacc, pcross;   // previous tile's accumulators (PIPE)
+  if (!(ADN_ABLATE_S & 4)) lds_bias_issue(bias_addr, br);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    f32x16 acc, cross;
+    if (ADN_ABLATE_S & 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    } else {
+      lds_bias_take(br, &acc);
+      if (m + 1 < MT) lds_bias_issue(bias_addr + (m + 1) * 128, br);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cross[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int f = (FPOS + 2 * (m * KS + s)) % ADN_CF_S;   // compile-time after unrolling; always even
+      if (f == 0) ws_boundary<ADN_ABLATE_S>(st);
+      const u32x4 bh = {in_hi[4 * s], in_hi[4 * s + 1], in_hi[4 * s + 2], in_hi[4 * s + 3]};
+      const u32x4 bl = {in_lo[4 * s], in_lo[4 * s + 1], in_lo[4 * s + 2], in_lo[4 * s + 3]};
+      acc = Fp16::mfma(st.R[f % kRegFrags], bh, acc);
+      cross = Fp16::mfma(st.R[f % kRegFrags], bl, cross);
+      cross = Fp16::mfma(st.R[(f + 1) % kRegFrags], bh, cross);
+      ws_refill<ADN_ABLATE_S>(st, f);
+      ws_refill<ADN_ABLATE_S>(st, f + 1);
+      if (PIPE && m > 0 && !(ADN_ABLATE_S & 8)) {
+        // KS >= 2: spread the 8 pairs over the first k-steps (all 8 in step 0/1 when KS < 8)
+        constexpr int PER = (KS >= 8) ? 1 : (8 + KS - 1) / KS;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+          const int pi = s * PER + k;
+          if (pi < 8) epilogue_pair_16x3<LAST>(pacc, pcross, m - 1, pi, out_hi, out_lo, out_f32);
+        }
+      }
+    }
+    if ((ADN_ABLATE_S & 8) && !LAST) {
+      asm volatile("" ::"v"(acc), "v"(cross));
+#pragma unroll
+      for (int g = 0; g < 8; ++g) asm volatile("" : "=v"(out_hi[8 * m + g]), "=v"(out_lo[8 * m + g]));
+      continue;
+    }
+    if (PIPE && m + 1 < MT) {
+      pacc = acc;
+      pcross = cross;
+    } else {
+#pragma unroll
+      for (int pi = 0; pi < 8; ++pi) epilogue_pair_16x3<LAST>(acc, cross, m, pi, out_hi, out_lo, out_f32);
+    }
+  }
+}
+
+// A1+A2+A3 on the split-precision engine.  Workgroup = 4 waves (one per SIMD, <= 512 registers:
+// 2 x (hi, lo') activation sets of 64 VGPRs + 2 accumulators) x 32 rays = 128-ray tile; persistent
+// over tiles; weights streamed once per workgroup through the LDS ring like the shading kernel.
+template <int FP, int FD>
+__global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
+  constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP;
+  constexpr int WAVES = 4, CF = ADN_CF_S, RS = ADN_RS_S, LPW = CF / WAVES, TILE = WAVES * 32;
+  constexpr int F0 = 2 * (Q0 / 8) * 8;                  // layer-0 fragments (hi + lo')
+  constexpr int FRAGS = F0 + 6 * 256 + 128;
+  static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % WAVES == 0 && CF % kRegFrags == 0 && CF <= 32, "chunk geometry");
+  typedef WStream<CF, RS, LPW> WS;
+  constexpr int kRingBytes = CF * RS * 1024, kBiasFloats = 7 * 256 + 128;
+  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kBiasFloats * 4];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int ntiles = (a.n_rays + TILE - 1) / TILE;
+  if (static_cast<int>(blockIdx.x) >= ntiles) return;
+
+  {
+    float* lds_bias = reinterpret_cast<float*>(lds + kRingBytes);
+    for (int i = threadIdx.x; i < kBiasFloats; i += blockDim.x) lds_bias[i] = a.net16.bias[i];
+  }
+  __syncthreads();
+  WS st;
+  ws_start(st, a.net16.w, FRAGS * 1024, lds, wave, lane);
+  const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
+  const uint32_t* bo = a.net16.b_off;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int local = tile * TILE + wave * 32 + j;
+    const bool valid = local < a.n_rays;
+    const int ray = a.first_ray + (valid ? local : a.n_rays - 1);
+    int col, row;
+    ray_pixel(a.g, ray, &col, &row);
+    float nds[3], p[3], u[3];
+    gen_ray(a.g, col, row, nds, p);
+    unit3(nds, u);
+
+    uint32_t aH[64], aL[64], bH[64], bL[64];
+    {
+      float t[Q0];
+      pe_eval<FD, !(ADN_ABLATE_S & 128)>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
+      pe_eval<FP, !(ADN_ABLATE_S & 128)>(p, h, t + QD);
+#pragma unroll
+      for (int q = 0; q < Q0 / 2; ++q) split_pack(t[2 * q], t[2 * q + 1], &aH[q], &aL[q]);
+    }
+    layer_16x3<WS, Q0 / 8, 8, false, 0>(st, bias0 + bo[0] * 4, lane, aH, aL, bH, bL, nullptr);
+#pragma unroll 1
+    for (int l = 1; l <= 5; l += 2) {
+      layer_16x3<WS, 16, 8, false, 0>(st, bias0 + bo[l] * 4, lane, bH, bL, aH, aL, nullptr);
+      layer_16x3<WS, 16, 8, false, 0>(st, bias0 + bo[l + 1] * 4, lane, aH, aL, bH, bL, nullptr);
+    }
+    float out[64];
+    layer_16x3<WS, 16, 4, true, 0>(st, bias0 + bo[7] * 4, lane, bH, bL, nullptr, nullptr, out);
+
+    if (valid) {
+      if (a.oracle_out) {
+        float* o = a.oracle_out + static_cast<size_t>(local) * kBins;
+        bool bad = false;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float4 v = make_float4(out[16 * m + 4 * g], out[16 * m + 4 * g + 1], out[16 * m + 4 * g + 2], out[16 * m + 4 * g + 3]);
+            bad |= !(fabsf(v.x) < 3.0e38f) | !(fabsf(v.y) < 3.0e38f) | !(fabsf(v.z) < 3.0e38f) | !(fabsf(v.w) < 3.0e38f);
+            *reinterpret_cast<float4*>(o + 32 * m + 8 * g + 4 * h) = v;
+          }
+        // an activation beyond the fp16 range (65504) shows up as inf/NaN here
+        if (bad && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
+      }
+      if (a.rays_out) {
+        float ro[3] = {p[0], p[1], p[2]}, rd[3] = {nds[0], nds[1], nds[2]};
+        if (a.g.use_ndc) ndc_ray(a.g, p, nds, ro, rd);
+        float4* r = reinterpret_cast<float4*>(a.rays_out + static_cast<size_t>(local) * 8);
+        if (h == 0) r[0] = make_float4(ro[0], ro[1], ro[2], 0.f);
+        else r[1] = make_float4(rd[0], rd[1], rd[2], 0.f);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// A1+A2+A3 in plain fp16 (ADANERF_SAMPLING_FP16): one MFMA per term, fp32 accumulate -- the arithmetic the
+// reference VIEWER runs its sampling network in (TensorRT kFP16, adanerf_real_time_viewer/src/imagegenerator.cpp:155-156).
+// 11-bit operands move a few outputs across the threshold / the N-th rank (raw error <= 3e-3), so the selected bins
+// differ from the fp32 PyTorch path on 0.3-1.5 % of rays: an opt-in speed mode, never the default.  Same engine as the shading
+// kernel (8 waves x 32 rays per workgroup, activations in registers, weights through the LDS ring).
+template <int FP, int FD>
+constexpr int sample16_frags() { return ((pe_slots(FD) + pe_slots(FP)) / 8) * 8 + 6 * 128 + 64; }
+
+template <int FP, int FD>
+__global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
+  constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP;
+  constexpr int WAVES = 8, CF = ADN_CF, RS = ADN_RS, LPW = CF / WAVES, TILE = WAVES * 32;
+  constexpr int F0 = (Q0 / 8) * 8, FRAGS = sample16_frags<FP, FD>();
+  static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % WAVES == 0 && CF % kRegFrags == 0 && CF <= 32, "chunk geometry");
+  typedef WStream<CF, RS, LPW> WS;
+  constexpr int kRingBytes = CF * RS * 1024, kBiasFloats = 7 * 256 + 128;
+  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kBiasFloats * 4];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int ntiles = (a.n_rays + TILE - 1) / TILE;
+  if (static_cast<int>(blockIdx.x) >= ntiles) return;
+  {
+    float* lds_bias = reinterpret_cast<float*>(lds + kRingBytes);
+    for (int i = threadIdx.x; i < kBiasFloats; i += blockDim.x) lds_bias[i] = a.net16.bias[i];
+  }
+  __syncthreads();
+  WS st;
+  ws_start(st, a.net16.w, FRAGS * 1024, lds, wave, lane);
+  const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
+  const uint32_t* bo = a.net16.b_off;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int local = tile * TILE + wave * 32 + j;
+    const bool valid = local < a.n_rays;
+    const int ray = a.first_ray + (valid ? local : a.n_rays - 1);
+    int col, row;
+    ray_pixel(a.g, ray, &col, &row);
+    float nds[3], p[3], u[3];
+    gen_ray(a.g, col, row, nds, p);
+    unit3(nds, u);
+    if (valid && a.rays_out) {
+      float ro[3] = {p[0], p[1], p[2]}, rd[3] = {nds[0], nds[1], nds[2]};
+      if (a.g.use_ndc) ndc_ray(a.g, p, nds, ro, rd);
+      float4* r = reinterpret_cast<float4*>(a.rays_out + static_cast<size_t>(local) * 8);
+      if (h == 0) r[0] = make_float4(ro[0], ro[1], ro[2], 0.f);
+      else r[1] = make_float4(rd[0], rd[1], rd[2], 0.f);
+    }
+    uint32_t hA[64], hB[64];
+    {
+      float t[Q0];
+      pe_eval<FD, !(ADN_ABLATE_S & 128)>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
+      pe_eval<FP, !(ADN_ABLATE_S & 128)>(p, h, t + QD);
+      uint32_t in0[Q0 / 2];
+#pragma unroll
+      for (int q = 0; q < Q0 / 2; ++q) in0[q] = Fp16::pack(t[2 * q], t[2 * q + 1]);
+      layer_16<Fp16, WS, Q0 / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, lane, in0, in0, hA);
+    }
+#pragma unroll 1
+    for (int l = 1; l <= 5; l += 2) {
+      layer_16<Fp16, WS, 16, 0, 8, true, F0 % CF>(st, bias0 + bo[l] * 4, lane, hA, hA, hB);
+      layer_16<Fp16, WS, 16, 0, 8, true, F0 % CF>(st, bias0 + bo[l + 1] * 4, lane, hB, hB, hA);
+    }
+    f32x16 out[4];
+    layer_16<Fp16, WS, 16, 0, 4, false, F0 % CF, kKeepAllF32>(st, bias0 + bo[7] * 4, lane, hA, hA, hB, out);
+    if (valid && a.oracle_out) {
+      float* o = a.oracle_out + static_cast<size_t>(local) * kBins;
+      bool bad = false;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = make_float4(out[m][4 * g], out[m][4 * g + 1], out[m][4 * g + 2], out[m][4 * g + 3]);
+          bad |= !(fabsf(v.x) < 3.0e38f) | !(fabsf(v.y) < 3.0e38f) | !(fabsf(v.z) < 3.0e38f) | !(fabsf(v.w) < 3.0e38f);
+          *reinterpret_cast<float4*>(o + 32 * m + 8 * g + 4 * h) = v;
+        }
+      if (bad && a.overflow_flag) atomicAdd(a.overflow_flag, 1);   // an activation left the fp16 range
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace adanerf

@@ -2,7 +2,7 @@
 
 Rows are cut into strips of ``strip_rows`` rows; strip ``s`` belongs to rank ``s % world``.  A rank's
 local ray list is its strips in ascending order, rows then columns.  The same mapping lives in the
-device ray generator (``ray_pixel`` in csrc/kernels.hip.hpp) and in ``assemble_strips_kernel``; this
+device ray generator (``ray_pixel`` in csrc/k_common.hip.hpp) and in ``assemble_strips_kernel``; this
 module is what the host uses to size gather payloads and what the CPU tests check the protocol with.
 """
 import numpy as np

@@ -154,7 +154,7 @@ def test_packed_shading_net_reproduces_oracle(lib, tmp_path, precision, tol):
     G = 4 if precision == 2 else 8
     assert sum(int(l[2]) // G * int(l[3]) for l in lay) * 1024 == w.size
     if precision != 2:
-        assert w.size == 1184 * 1024          # kShadeFrags16 in kernels.hip.hpp
+        assert w.size == 1184 * 1024          # kShadeFrags16 in k_mlp16.hip.hpp
         assert b.size == 2496                 # kShadeBiasFloats
     # a few real samples: positions/dirs from the golden case
     count = z["sel_count"].astype(np.int32)
