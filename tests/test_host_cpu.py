@@ -345,3 +345,55 @@ def test_y4m_video_writer(tmp_path):
     assert (y0 == 100).all() and (u0 == 128).all()                       # grey: Y = value, chroma neutral
     y1 = np.frombuffer(rest[frame + 6:frame + 6 + w * h], np.uint8)
     assert (y1 == 76).all()                                              # BT.601: 0.299 * 255
+
+
+def test_corrupt_model_files_never_crash(tmp_path):
+    """The ONNX-initializer reader and the key=value parser are hand-rolled (format.cpp): truncated, bit-flipped and
+    garbage files must come back as an error code (or parse), never as a crash or a hang.  Runs in a child process so
+    that a segfault fails the test instead of the test run."""
+    import subprocess
+    import sys
+    from conftest import case_weights, load_case
+    z, meta, sc = load_case("classroom_n8_thr02")
+    d, _, _ = _model_dir(tmp_path, sc, case_weights(meta))
+    script = r"""
+import ctypes as C, os, shutil, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from adanerf_amd import renderer as R
+lib = R.load_library()
+src, work = sys.argv[2], sys.argv[3]
+f = lib.adanerf_host_pack_weights
+f.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_int32)]
+lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+rng = np.random.default_rng(0)
+codes = {}
+for it in range(240):
+    if os.path.exists(work): shutil.rmtree(work)
+    shutil.copytree(src, work)
+    name = ["model0.onnx", "model1.onnx", "config.ini", "dataset_info.txt"][it % 4]
+    path = os.path.join(work, name)
+    b = bytearray(open(path, "rb").read())
+    mode = (it // 4) % 4
+    if mode == 0: b = b[:int(rng.integers(0, len(b)))]                                   # truncation
+    elif mode == 1:
+        for _ in range(int(rng.integers(1, 40))): b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))   # byte flips
+    elif mode == 2: b = bytearray(rng.integers(0, 256, int(rng.integers(0, 5000)), dtype=np.uint8).tobytes())   # garbage
+    else:                                                                                 # flips confined to the first 4 KiB (headers)
+        for _ in range(int(rng.integers(1, 20))): b[int(rng.integers(0, min(len(b), 4096)))] = int(rng.integers(0, 256))
+    open(path, "wb").write(bytes(b))
+    o = R._Options(width=32, height=24, batch_rays=-1, precision=0, threshold=-1.0, shard_world=1)
+    info = R.Info()
+    rc1 = lib.adanerf_host_parse_model(work.encode(), C.byref(o), C.byref(info))
+    wb, bf, nl = C.c_size_t(0), C.c_size_t(0), C.c_int32(0)
+    rc2 = f(work.encode(), it % 2, 0, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl))
+    if rc2 == 0 and wb.value < (1 << 28):
+        w = np.empty(wb.value, np.uint8); bb = np.empty(bf.value, np.float32); lay = np.empty((nl.value, 4), np.int32)
+        rc2 = f(work.encode(), it % 2, 0, w.ctypes.data, C.byref(wb), bb.ctypes.data, C.byref(bf), lay.ctypes.data, C.byref(nl))
+    codes[(rc1, rc2)] = codes.get((rc1, rc2), 0) + 1
+    assert rc1 in (0, -1, -2, -4) and rc2 in (0, -1, -2, -4), (name, mode, rc1, rc2)
+print("OK", sorted(codes.items()))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", script, root, d, str(tmp_path / "work")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), (out.returncode, out.stdout[-500:], out.stderr[-2000:])
+    assert "(-2," in out.stdout or ", -2)" in out.stdout      # corruption was actually detected in some cases
