@@ -862,3 +862,59 @@ def test_randomised_frames_against_oracle():
     import fuzz_parity
     rng = np.random.default_rng(2024)
     assert all(fuzz_parity.one_case(rng, i) for i in range(12))
+
+
+@pytest.mark.gpu
+def test_stage_kernels_stay_inside_their_output_buffers(cases):
+    """Every stage entry point with ragged sizes writes only [0, n) of its outputs: each output sits between two 4 KiB
+    canary regions that must come back untouched (out-of-bounds stores into a neighbouring allocation would otherwise
+    go unnoticed)."""
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    PAD = 4096
+
+    class Guarded:
+        def __init__(self, r, nbytes):
+            self.r, self.n = r, nbytes
+            self.buf = r.empty((PAD + nbytes + PAD,), np.uint8)
+            self.buf.upload(np.full(PAD + nbytes + PAD, 0xA5, np.uint8))
+            self.ptr = self.buf.ptr + PAD
+
+        def check(self, what):
+            a = self.buf.numpy()
+            assert (a[:PAD] == 0xA5).all(), what + ": wrote before the buffer"
+            assert (a[PAD + self.n:] == 0xA5).all(), what + ": wrote past the buffer"
+            return a[PAD:PAD + self.n]
+
+    for w, h, n_rays in ((37, 29, 1001), (64, 33, 64 * 33), (5, 3, 15)):
+        for prec in ("bf16", "fp32"):
+            with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision=prec) as r:
+                r.set_camera(z["pose"], z["rot"])
+                N = sc.num_samples
+                orc, rays = Guarded(r, n_rays * 512), Guarded(r, n_rays * 32)
+                r.sample_mlp(0, n_rays, orc.ptr, rays.ptr)
+                feat = Guarded(r, n_rays * sc.n_in0 * 4)
+                r.ray_features(0, n_rays, feat.ptr, None)
+                off, cnt = Guarded(r, n_rays * 4), Guarded(r, n_rays * 4)
+                key, sw, tot = Guarded(r, n_rays * N * 4), Guarded(r, n_rays * N * 4), Guarded(r, 4)
+                r.compact(orc.ptr, n_rays, N, sc.threshold, off.ptr, cnt.ptr, key.ptr, sw.ptr, tot.ptr)
+                r.sync()
+                total = int(tot.check("total").view(np.int32)[0])
+                c = cnt.check("counts").view(np.int32)
+                assert total == int(c.sum()) and 0 < total <= n_rays * N
+                # exact-size buffers for the sample arrays of the second half: S is ragged (not a multiple of 256)
+                key2, sw2 = Guarded(r, total * 4), Guarded(r, total * 4)
+                r.compact(orc.ptr, n_rays, N, sc.threshold, off.ptr, cnt.ptr, key2.ptr, sw2.ptr, tot.ptr)
+                raw = Guarded(r, total * 16)
+                r.shade_mlp(rays.ptr, key2.ptr, tot.ptr, total, raw.ptr)
+                sfeat = Guarded(r, total * sc.n_in1 * 4)
+                r.shade_features(rays.ptr, key2.ptr, total, sfeat.ptr)
+                rgb, rgba = Guarded(r, n_rays * 12), Guarded(r, n_rays * 4)
+                r.composite(raw.ptr, sw2.ptr, off.ptr, cnt.ptr, n_rays, rgb.ptr, rgba.ptr)
+                view = Guarded(r, n_rays * 4)
+                r.copy_result_sampling_network(orc.ptr, n_rays, view.ptr)
+                r.sync()
+                for g, name in ((orc, "oracle"), (rays, "rays"), (feat, "ray features"), (off, "offsets"), (key, "keys"), (sw, "weights"),
+                                (key2, "keys (exact)"), (sw2, "weights (exact)"), (raw, "raw"), (sfeat, "shade features"),
+                                (rgb, "rgb"), (rgba, "rgba8"), (view, "oracle view")):
+                    g.check("%s %dx%d %s" % (name, w, h, prec))
+                assert np.isfinite(rgb.check("rgb").view(np.float32)).all()
