@@ -8,11 +8,17 @@ CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
 LIBDIR = os.path.join(HERE, "lib")
 BINDIR = os.path.join(HERE, "bin")
-LIB_SOURCES = ["adanerf_hip.hip", "format.cpp", "pack.cpp"]
+LIB_SOURCES = ["adanerf_hip.hip", "launch_f32.hip", "format.cpp", "pack.cpp"]
 KERNEL_HEADERS = ["kernels.hip.hpp", "k_common.hip.hpp", "k_mlp_f32.hip.hpp", "k_compact.hip.hpp", "k_mlp16.hip.hpp",
-                  "k_sampling16.hip.hpp", "k_donerf.hip.hpp", "k_composite.hip.hpp"]
+                  "k_sampling16.hip.hpp", "k_donerf.hip.hpp", "k_composite.hip.hpp", "launch_f32.hpp"]
 LIB_DEPS = LIB_SOURCES + KERNEL_HEADERS + ["layout.hpp", "format.hpp", "pack.hpp", os.path.join("..", "..", "include", "adanerf_hip.h")]
 ARCH = "gfx950"
+# -ffp-contract=off: the fused and the debug kernels must generate bit-identical rays.
+HIPCC_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off"]
+# Per translation unit: the main one keeps MFMA accumulators in architectural VGPRs, so the VALU epilogues of the 16-bit
+# kernels read them without v_accvgpr_read copies (split-precision sampling kernel 1.48 -> 1.35 ms); the fp32-MFMA
+# kernels (launch_f32.hip) are slower that way and keep the compiler's default (AGPR accumulators).
+TU_FLAGS = {"adanerf_hip.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def library_path():
@@ -37,17 +43,32 @@ def _stale(target, deps):
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -shared -> adanerf_amd/lib/libadanerf_hip.so (cross-compiles without a GPU)."""
-    out = library_path()
+def build_library(force=False, verbose=False, out=None, extra_flags=()):
+    """hipcc --offload-arch=gfx950: one object per translation unit (TU_FLAGS), then -shared ->
+    adanerf_amd/lib/libadanerf_hip.so (cross-compiles without a GPU).  ``out`` / ``extra_flags``: experiment variants
+    (tools/ablate.sh)."""
+    variant = out is not None
+    out = out or library_path()
     deps = [os.path.join(CSRC, d) for d in LIB_DEPS]
-    if os.environ.get("ADANERF_LIB"):
+    if not variant and os.environ.get("ADANERF_LIB"):
         return os.environ["ADANERF_LIB"]      # pre-built variant selected by the caller
-    if not force and not _stale(out, deps):
+    if not force and not variant and not _stale(out, deps):
         return out
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"] + \
-          [os.path.join(CSRC, s) for s in LIB_SOURCES] + ["-o", out]
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj" if not variant else "obj_" + os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for src in LIB_SOURCES:
+        obj = os.path.join(objdir, src + ".o")
+        cmd = [_hipcc()] + HIPCC_FLAGS + TU_FLAGS.get(src, []) + list(extra_flags) + ["-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared"] + objs + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
@@ -85,7 +106,7 @@ def build_probes(force=False, verbose=False):
             continue
         if force or _stale(out, [src] + [os.path.join(CSRC, d) for d in LIB_DEPS]):
             os.makedirs(BINDIR, exist_ok=True)
-            cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", src, "-o", out]
+            cmd = [_hipcc()] + HIPCC_FLAGS + [src, "-o", out]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
@@ -94,6 +115,14 @@ def build_probes(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
-    print(build_cli(force=True, verbose=True))
-    print(build_probes(force=True, verbose=True))
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--out", default=None, help="build an experiment variant of the library to this path instead")
+    ap.add_argument("--flags", default="", help="extra hipcc flags for every translation unit (quoted string)")
+    a = ap.parse_args()
+    if a.out:
+        print(build_library(force=True, verbose=True, out=os.path.abspath(a.out), extra_flags=a.flags.split()))
+    else:
+        print(build_library(force=True, verbose=True, extra_flags=a.flags.split()))
+        print(build_cli(force=True, verbose=True))
+        print(build_probes(force=True, verbose=True))

@@ -14,6 +14,7 @@
 
 #include "format.hpp"
 #include "kernels.hip.hpp"
+#include "launch_f32.hpp"
 #include "pack.hpp"
 
 using namespace adanerf;
@@ -369,8 +370,7 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
   dim3 grid((n_rays + 127) / 128), block(256);
   const bool full = c->fp0 == 10 && c->fd0 == 4;
   if (c->sampling_mode == 1) {
-    if (full) hipLaunchKernelGGL((sample_mlp_kernel<10, 4>), grid, block, 0, c->stream, a);
-    else hipLaunchKernelGGL((sample_mlp_kernel<2, 2>), grid, block, 0, c->stream, a);
+    HIP_TRY(c, launch_sample_mlp_f32(a, full, grid.x, c->stream));
   } else if (c->sampling_mode == 2) {
     if (!c->net0_f16.w.p) {
       PackedNet pn;
@@ -447,9 +447,9 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
   a.raw_out = d_raw;
   if (c->fp1 != 10 || c->fd1 != 4) return fail(c, ADANERF_EUNSUPPORTED, "shading net posEncArgs must be 10-4");
   if (prec == ADANERF_PREC_FP32) {
-    if (!c->shade_grid[2] && (rc = occupancy_grid(c, shade_mlp32_kernel<10, 4>, 256, &c->shade_grid[2]))) return rc;
+    if (!c->shade_grid[2]) HIP_TRY(c, shade_mlp_f32_grid(c->info.compute_units, &c->shade_grid[2]));
     const int tiles = (max_samples + 127) / 128;
-    hipLaunchKernelGGL((shade_mlp32_kernel<10, 4>), dim3(std::min(tiles, c->shade_grid[2])), dim3(256), 0, c->stream, a);
+    HIP_TRY(c, launch_shade_mlp_f32(a, std::min(tiles, c->shade_grid[2]), c->stream));
   } else {
     const int tile = kShadeWaves * 32;
     const int tiles = (max_samples + tile - 1) / tile;

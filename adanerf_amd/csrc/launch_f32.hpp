@@ -1,0 +1,18 @@
+// Launchers of the two kernels that run on the fp32 MFMA engine (v_mfma_f32_32x32x2_f32).  They live in their own
+// translation unit (launch_f32.hip) because the rest of the library is compiled with -mllvm -amdgpu-mfma-vgpr-form=1
+// (MFMA accumulators in architectural VGPRs: good for the 16-bit kernels' VALU epilogues, 1.48 -> 1.35 ms in the
+// split-precision sampling kernel) and that option slows these two down (fp32 sampling 5.3 -> 9.6 ms, fp32 shading
+// 60 -> 67 ms): their accumulators belong in AGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace adanerf {
+struct SampleArgs;
+struct ShadeArgs;
+
+// sample_mlp_kernel<10,4> (full = true) or <2,2>; grid = ceil(n_rays / 128) workgroups of 256 threads
+hipError_t launch_sample_mlp_f32(const SampleArgs& a, bool full, unsigned grid, hipStream_t stream);
+// persistent grid of shade_mlp32_kernel<10,4> for a device with `compute_units` CUs
+hipError_t shade_mlp_f32_grid(int compute_units, int* grid);
+hipError_t launch_shade_mlp_f32(const ShadeArgs& a, int grid, hipStream_t stream);
+}  // namespace adanerf

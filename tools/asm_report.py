@@ -4,8 +4,15 @@ histogram and where scratch (spill) traffic sits relative to the MFMA stream."""
 import bisect, collections, os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = "/tmp/adanerf_all.s"
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
-                os.path.join(root, "adanerf_amd/csrc/adanerf_hip.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
+sys.path.insert(0, root)
+from adanerf_amd import build as B
+parts = []
+for src in ("adanerf_hip.hip", "launch_f32.hip"):          # same per-translation-unit flags as the shipped build
+    tmp = "/tmp/adanerf_%s.s" % src
+    subprocess.run(["hipcc"] + B.HIPCC_FLAGS + B.TU_FLAGS.get(src, []) + ["-S", "--cuda-device-only", os.path.join(root, "adanerf_amd/csrc", src), "-o", tmp],
+                   check=True, stderr=subprocess.DEVNULL)
+    parts.append(open(tmp).read())
+open(out, "w").write("\n".join(parts))
 pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else ".")
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 18
 for f in re.split(r"\n\s*\.globl\s+", open(out).read()):
