@@ -85,8 +85,9 @@ constexpr int kShadeBiasFloats = 8 * 256 + 288 + 128 + 32;                     /
 
 // CF / RS / LPW (fragments each wave DMA-copies per chunk = CF / waves) are compile-time; the slot a
 // chunk lives in is a run-time counter, so any tile length that is a multiple of CF works.
-template <int CF, int RS, int LPW>
+template <int CF, int RS, int LPW, int NR = kRegFrags>
 struct WStream {
+  static constexpr int kRegs = NR;   // fragments held in registers = re-fill distance
   static constexpr int kChunkBytes = CF * 1024;
   const char* gbase;     // stream start (global)
   uint32_t gbytes;       // stream length in bytes (multiple of kChunkBytes)
@@ -97,7 +98,7 @@ struct WStream {
   uint32_t rd_cur;       // LDS byte address of (current chunk, this lane)
   uint32_t rd_next;      // LDS byte address of (next chunk, this lane)
   uint32_t lds_base;     // LDS byte address of the ring
-  u32x4 R[kRegFrags];    // register ring: fragment p (position inside the chunk) lives in R[p % kRegFrags]
+  u32x4 R[NR];           // register ring: fragment p (position inside the chunk) lives in R[p % NR]
 };
 
 __device__ __forceinline__ u32x4 lds_read128(uint32_t byte_addr) {
@@ -105,8 +106,8 @@ __device__ __forceinline__ u32x4 lds_read128(uint32_t byte_addr) {
   return *((lds_u32x4_ptr)(uintptr_t)byte_addr);
 }
 
-template <int CF, int RS, int LPW>
-__device__ __forceinline__ void ws_issue(WStream<CF, RS, LPW>& st, uint32_t slot) {
+template <int CF, int RS, int LPW, int NR>
+__device__ __forceinline__ void ws_issue(WStream<CF, RS, LPW, NR>& st, uint32_t slot) {
 #pragma unroll
   for (int i = 0; i < LPW; ++i) {
     const char* src = st.gbase + st.goff + st.wave_off + i * 1024 + st.lane_off;
@@ -121,8 +122,8 @@ __device__ __forceinline__ void ws_issue(WStream<CF, RS, LPW>& st, uint32_t slot
 // chunk boundary k: own pieces of chunk k+1 have landed (<= (RS-3) LPW younger DMAs outstanding); barrier =>
 // chunk k+1 complete in LDS for every wave and every wave has consumed chunk k-1 (its MFMAs were
 // issued before the barrier, so its ds_reads returned) => refill the slot of chunk k-1 with chunk k+RS-1.
-template <int ABL, int CF, int RS, int LPW>
-__device__ __forceinline__ void ws_boundary(WStream<CF, RS, LPW>& st) {
+template <int ABL, int CF, int RS, int LPW, int NR>
+__device__ __forceinline__ void ws_boundary(WStream<CF, RS, LPW, NR>& st) {
   static_assert(RS >= 3 && (RS - 2) * LPW < 64, "vmcnt is a 6-bit counter");
   if (ABL & 1) return;
   if (!(ABL & 32)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 3) * LPW) : "memory");   // 32: no wait/barrier
@@ -136,18 +137,18 @@ __device__ __forceinline__ void ws_boundary(WStream<CF, RS, LPW>& st) {
 
 // fragment position p inside the current chunk has just been consumed: re-fill its register with fragment
 // p + kRegFrags (same chunk, or the next chunk -- already landed: see ws_boundary)
-template <int ABL, int CF, int RS, int LPW>
-__device__ __forceinline__ void ws_refill(WStream<CF, RS, LPW>& st, int p) {
+template <int ABL, int CF, int RS, int LPW, int NR>
+__device__ __forceinline__ void ws_refill(WStream<CF, RS, LPW, NR>& st, int p) {
   if (ABL & 2) {
-    asm volatile("" : "+v"(st.R[p % kRegFrags]));
+    asm volatile("" : "+v"(st.R[p % NR]));
     return;
   }
-  const int q = p + kRegFrags;
-  st.R[p % kRegFrags] = (q < CF) ? lds_read128(st.rd_cur + q * 1024) : lds_read128(st.rd_next + (q - CF) * 1024);
+  const int q = p + NR;
+  st.R[p % NR] = (q < CF) ? lds_read128(st.rd_cur + q * 1024) : lds_read128(st.rd_next + (q - CF) * 1024);
 }
 
-template <int CF, int RS, int LPW>
-__device__ __forceinline__ void ws_start(WStream<CF, RS, LPW>& st, const void* gbase, uint32_t gbytes, char* lds, int wave, int lane) {
+template <int CF, int RS, int LPW, int NR>
+__device__ __forceinline__ void ws_start(WStream<CF, RS, LPW, NR>& st, const void* gbase, uint32_t gbytes, char* lds, int wave, int lane) {
   st.gbase = reinterpret_cast<const char*>(gbase);
   st.gbytes = gbytes;
   st.goff = 0;
@@ -161,7 +162,7 @@ __device__ __forceinline__ void ws_start(WStream<CF, RS, LPW>& st, const void* g
   st.rd_cur = st.lds_base + st.lane_off;      // unused until then
   st.rd_next = st.lds_base + st.lane_off;     // chunk 0
 #pragma unroll
-  for (int i = 0; i < kRegFrags; ++i) st.R[i] = lds_read128(st.rd_next + i * 1024);
+  for (int i = 0; i < NR; ++i) st.R[i] = lds_read128(st.rd_next + i * 1024);
 }
 
 // ReLU on the raw bits: max(int(x), 0) is +0.0 for every negative float and the identity for positive
@@ -265,7 +266,7 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
       if (f == 0) ws_boundary<ADN_ABLATE>(st);
       const uint32_t* src = (s < S1) ? (in1 + 4 * s) : (in2 + 4 * (s - S1));
       u32x4 b = {src[0], src[1], src[2], src[3]};
-      acc = ET::mfma(st.R[f % kRegFrags], b, acc);
+      acc = ET::mfma(st.R[f % WS::kRegs], b, acc);
       ws_refill<ADN_ABLATE>(st, f);
     }
     if (KEEP_F32_TILE == kKeepAllF32) {

@@ -14,6 +14,10 @@ namespace adanerf {
 // identical selections on 100 % of rays -- at 3/16 of the fp32-MFMA cycle count.
 // kSplitScale (2^11) is defined in pack.hpp
 
+#ifndef ADN_NR_S
+#define ADN_NR_S 16  // fragment registers of the split sampling kernel = a whole chunk (measured 4: 1.42, 8: 1.37, 16: 1.32 ms)
+#endif
+
 __device__ __forceinline__ void split_pack(float v0, float v1, uint32_t* hi, uint32_t* lo) {
   f32x2 v = {v0, v1};
   f16x2 h = __builtin_convertvector(v, f16x2);
@@ -67,9 +71,9 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
       if (f == 0) ws_boundary<ADN_ABLATE_S>(st);
       const u32x4 bh = {in_hi[4 * s], in_hi[4 * s + 1], in_hi[4 * s + 2], in_hi[4 * s + 3]};
       const u32x4 bl = {in_lo[4 * s], in_lo[4 * s + 1], in_lo[4 * s + 2], in_lo[4 * s + 3]};
-      acc = Fp16::mfma(st.R[f % kRegFrags], bh, acc);
-      cross = Fp16::mfma(st.R[f % kRegFrags], bl, cross);
-      cross = Fp16::mfma(st.R[(f + 1) % kRegFrags], bh, cross);
+      acc = Fp16::mfma(st.R[f % WS::kRegs], bh, acc);
+      cross = Fp16::mfma(st.R[f % WS::kRegs], bl, cross);
+      cross = Fp16::mfma(st.R[(f + 1) % WS::kRegs], bh, cross);
       ws_refill<ADN_ABLATE_S>(st, f);
       ws_refill<ADN_ABLATE_S>(st, f + 1);
       if (PIPE && m > 0 && !(ADN_ABLATE_S & 8)) {
@@ -107,8 +111,8 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
   constexpr int WAVES = 4, CF = ADN_CF_S, RS = ADN_RS_S, LPW = CF / WAVES, TILE = WAVES * 32;
   constexpr int F0 = 2 * (Q0 / 8) * 8;                  // layer-0 fragments (hi + lo')
   constexpr int FRAGS = F0 + 6 * 256 + 128;
-  static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % WAVES == 0 && CF % kRegFrags == 0 && CF <= 32, "chunk geometry");
-  typedef WStream<CF, RS, LPW> WS;
+  static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % WAVES == 0 && CF % ADN_NR_S == 0 && CF <= 32, "chunk geometry");
+  typedef WStream<CF, RS, LPW, ADN_NR_S> WS;
   constexpr int kRingBytes = CF * RS * 1024, kBiasFloats = 7 * 256 + 128;
   __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kBiasFloats * 4];
   const int lane = lane_id();
