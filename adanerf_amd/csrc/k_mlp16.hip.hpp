@@ -79,7 +79,13 @@ struct Fp16 {
 #ifndef ADN_RS_S
 #define ADN_RS_S 6
 #endif
-constexpr int kRegFrags = 4;     // fragments held in registers per wave (re-fill distance in MFMAs)
+// Fragments held in registers per wave (= re-fill distance in MFMAs) in the 2-waves-per-SIMD kernels, which live at the
+// 256-register cap: 2 leaves the shading kernel spill-free (4: 6 spilled dwords, 3.77 vs 3.73 ms; 8: 4.43 ms).  The
+// one-wave-per-SIMD split sampling kernel keeps a whole chunk (ADN_NR_S).
+#ifndef ADN_NR
+#define ADN_NR 2
+#endif
+constexpr int kRegFrags = ADN_NR;
 constexpr int kShadeFrags16 = 32 + 4 * 128 + 160 + 2 * 128 + 144 + 72 + 8;   // 1184 per pass (FP=10, FD=4)
 constexpr int kShadeBiasFloats = 8 * 256 + 288 + 128 + 32;                     // 2496
 
