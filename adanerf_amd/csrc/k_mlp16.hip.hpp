@@ -94,6 +94,7 @@ constexpr int kShadeBiasFloats = 8 * 256 + 288 + 128 + 32;                     /
 template <int CF, int RS, int LPW, int NR = kRegFrags>
 struct WStream {
   static constexpr int kRegs = NR;   // fragments held in registers = re-fill distance
+  static constexpr int kChunk = CF;  // fragments per chunk
   static constexpr int kChunkBytes = CF * 1024;
   const char* gbase;     // stream start (global)
   uint32_t gbytes;       // stream length in bytes (multiple of kChunkBytes)
@@ -254,7 +255,7 @@ constexpr int kKeepAllF32 = -2;   // layer_16 KEEP_F32_TILE: every tile's raw ac
 template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
 __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, const uint32_t* in1, const uint32_t* in2,
                                          uint32_t* out, f32x16* keep = nullptr) {
-  constexpr int CF = ADN_CF;
+  constexpr int CF = WS::kChunk;
   constexpr int KS = S1 + S2;
   // bias_addr: LDS byte address of this layer's bias block for THIS lane-half ([m][h][16] floats)
 #pragma unroll

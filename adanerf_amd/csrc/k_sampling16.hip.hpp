@@ -196,7 +196,7 @@ constexpr int sample16_frags() { return ((pe_slots(FD) + pe_slots(FP)) / 8) * 8 
 template <int FP, int FD>
 __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
   constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP;
-  constexpr int WAVES = 8, CF = ADN_CF, RS = ADN_RS, LPW = CF / WAVES, TILE = WAVES * 32;
+  constexpr int WAVES = 8, CF = 16, RS = 4, LPW = CF / WAVES, TILE = WAVES * 32;   // 880 fragments = 55 chunks of 16
   constexpr int F0 = (Q0 / 8) * 8, FRAGS = sample16_frags<FP, FD>();
   static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % WAVES == 0 && CF % kRegFrags == 0 && CF <= 32, "chunk geometry");
   typedef WStream<CF, RS, LPW> WS;
