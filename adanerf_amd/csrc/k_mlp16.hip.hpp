@@ -67,6 +67,10 @@ struct Fp16 {
 #endif
 // Ring geometry.  CF = fragments (KiB) per chunk = MFMAs per wave between barriers; RS = ring slots.
 // At boundary k a wave waits for its own pieces of chunk k+1, so RS-3 further chunks stay in flight.
+#ifndef ADN_BUFDMA
+#define ADN_BUFDMA 1   // LDS-DMA through buffer_load ... lds (descriptor + scalar byte offset, lane * 16 as the only VGPR
+                       // operand) instead of global_load_lds with a 64-bit VALU address per piece: shading 3.82 -> 3.77 ms
+#endif
 #ifndef ADN_CF
 #define ADN_CF 16
 #endif
@@ -96,6 +100,9 @@ struct WStream {
   static constexpr int kRegs = NR;   // fragments held in registers = re-fill distance
   static constexpr int kChunk = CF;  // fragments per chunk
   static constexpr int kChunkBytes = CF * 1024;
+#if ADN_BUFDMA && defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t rsrc;   // raw buffer descriptor of the stream
+#endif
   const char* gbase;     // stream start (global)
   uint32_t gbytes;       // stream length in bytes (multiple of kChunkBytes)
   uint32_t goff;         // byte offset of the next chunk to issue
@@ -117,10 +124,17 @@ template <int CF, int RS, int LPW, int NR>
 __device__ __forceinline__ void ws_issue(WStream<CF, RS, LPW, NR>& st, uint32_t slot) {
 #pragma unroll
   for (int i = 0; i < LPW; ++i) {
-    const char* src = st.gbase + st.goff + st.wave_off + i * 1024 + st.lane_off;
     const uint32_t dst = st.lds_base + slot * (CF * 1024) + st.wave_off + i * 1024;
+#if ADN_BUFDMA && defined(__HIP_DEVICE_COMPILE__)
+    // buffer form: descriptor + wave-uniform byte offset in SGPRs, lane * 16 as the only VGPR operand (no 64-bit VALU
+    // address per piece)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (__attribute__((address_space(3))) void*)static_cast<uintptr_t>(dst), 16,
+                                             static_cast<int>(st.lane_off), static_cast<int>(st.goff + st.wave_off + i * 1024), 0, 0);
+#else
+    const char* src = st.gbase + st.goff + st.wave_off + i * 1024 + st.lane_off;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)static_cast<uintptr_t>(dst), 16, 0, 0);
+#endif
   }
   st.goff += CF * 1024;
   if (st.goff >= st.gbytes) st.goff = 0;
@@ -158,6 +172,9 @@ template <int CF, int RS, int LPW, int NR>
 __device__ __forceinline__ void ws_start(WStream<CF, RS, LPW, NR>& st, const void* gbase, uint32_t gbytes, char* lds, int wave, int lane) {
   st.gbase = reinterpret_cast<const char*>(gbase);
   st.gbytes = gbytes;
+#if ADN_BUFDMA && defined(__HIP_DEVICE_COMPILE__)
+  st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gbase), 0, static_cast<int>(gbytes), 0x00020000);
+#endif
   st.goff = 0;
   st.lane_off = lane * 16;
   st.wave_off = wave * LPW * 1024;
