@@ -110,7 +110,7 @@ def one_case(rng, idx):
         ok = False; msg.append("fp32 rgb err %.2e" % err32)
     rgb16 = out["bf16"][0]
     if kind == "pdf":
-        # classic compositing gives the LAST sample of a ray the distance 1e10 (src/nerf_raymarch_common.py:27-28): its alpha
+        # classic compositing gives the LAST sample of a ray the distance 1e10 (src/nerf_raymarch_common.py:36): its alpha
         # is a step function of the sign of its density, so a bf16-sized error on a density near zero turns a transparent
         # ray opaque.  The bound is therefore on the 97th percentile of the per-ray error in this mode.
         e = np.abs(rgb16 - ref["rgb"]).max(axis=1) / np.maximum(1.0, np.abs(ref["rgb"]).max(axis=1))
