@@ -403,6 +403,9 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
   return ADANERF_OK;
 }
 
+// above this many select workgroups (64 rays each) the block totals are scanned by their own kernel
+constexpr int kInlineScanMaxBlocks = 16384;
+
 int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max, float thr, int32_t* d_off, int32_t* d_cnt,
                    uint32_t* d_key, float* d_w, int32_t* d_total) {
   if (n_rays <= 0) return ADANERF_OK;
@@ -417,11 +420,19 @@ int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max,
   hipLaunchKernelGGL(select_kernel, dim3(nblk), dim3(256), 0, c->stream, d_oracle, n_rays, n_max, thr, d_cnt,
                      reinterpret_cast<uint8_t*>(c->selbin.p), reinterpret_cast<float*>(c->selw.p),
                      reinterpret_cast<int32_t*>(c->block_total.p));
-  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, c->stream, reinterpret_cast<const int32_t*>(c->block_total.p), nblk,
-                     reinterpret_cast<int32_t*>(c->block_offset.p), d_total);
-  hipLaunchKernelGGL(expand_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const int32_t*>(d_cnt),
-                     reinterpret_cast<const uint8_t*>(c->selbin.p), reinterpret_cast<const float*>(c->selw.p),
-                     reinterpret_cast<const int32_t*>(c->block_offset.p), n_rays, n_max, d_off, d_key, d_w);
+  const int32_t* bt = reinterpret_cast<const int32_t*>(c->block_total.p);
+  int32_t* bo = reinterpret_cast<int32_t*>(c->block_offset.p);
+  const dim3 egrid((n_rays + 255) / 256);
+  if (nblk <= kInlineScanMaxBlocks) {
+    hipLaunchKernelGGL(expand_kernel<true>, egrid, dim3(256), 0, c->stream, reinterpret_cast<const int32_t*>(d_cnt),
+                       reinterpret_cast<const uint8_t*>(c->selbin.p), reinterpret_cast<const float*>(c->selw.p), bo, bt, nblk, n_rays, n_max,
+                       d_off, d_key, d_w, d_total);
+  } else {
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, c->stream, bt, nblk, bo, d_total);
+    hipLaunchKernelGGL(expand_kernel<false>, egrid, dim3(256), 0, c->stream, reinterpret_cast<const int32_t*>(d_cnt),
+                       reinterpret_cast<const uint8_t*>(c->selbin.p), reinterpret_cast<const float*>(c->selw.p), bo, bt, nblk, n_rays, n_max,
+                       d_off, d_key, d_w, d_total);
+  }
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;
 }

@@ -186,12 +186,20 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const int32_t* __rest
 
 // ray offsets + compacted (key, weight) arrays, ray-major / bins ascending
 // One thread per ray; the rays of one select_kernel workgroup are one wave segment, so the in-segment prefix is a
-// width-limited shuffle scan (no LDS, no barrier).
+// width-limited shuffle scan (no LDS, no barrier).  INLINE_SCAN: the workgroup also derives its own base offset by
+// summing the block totals in front of it (a cooperative reduction over <= 16 384 ints from L2) instead of reading the
+// output of scan_blocks_kernel -- one launch and its ~10 us of single-workgroup latency less per batch; the host keeps
+// the separate scan for larger batches, where every workgroup re-reading the totals would be quadratic.
+template <bool INLINE_SCAN>
 __global__ __launch_bounds__(256) void expand_kernel(const int32_t* __restrict__ counts, const uint8_t* __restrict__ selbin,
                                                      const float* __restrict__ selw, const int32_t* __restrict__ block_offset,
-                                                     int n_rays, int n_max, int32_t* __restrict__ ray_offsets,
-                                                     uint32_t* __restrict__ sample_key, float* __restrict__ sample_w) {
-  const int r = blockIdx.x * 256 + static_cast<int>(threadIdx.x);
+                                                     const int32_t* __restrict__ block_total, int n_blocks, int n_rays, int n_max,
+                                                     int32_t* __restrict__ ray_offsets, uint32_t* __restrict__ sample_key,
+                                                     float* __restrict__ sample_w, int32_t* __restrict__ total) {
+  static_assert(kSelRaysPerBlock <= 64 && 256 % kSelRaysPerBlock == 0, "one segment per wave or less");
+  constexpr int SEGS = 256 / kSelRaysPerBlock;                 // select workgroups covered by this workgroup
+  const int t = static_cast<int>(threadIdx.x);
+  const int r = blockIdx.x * 256 + t;
   const int c = (r < n_rays) ? counts[r] : 0;
   const int seg_lane = r & (kSelRaysPerBlock - 1);
   int x = c;
@@ -200,8 +208,29 @@ __global__ __launch_bounds__(256) void expand_kernel(const int32_t* __restrict__
     const int y = __shfl_up(x, off, kSelRaysPerBlock);
     if (seg_lane >= off) x += y;
   }
+  const int seg = r / kSelRaysPerBlock;                        // select workgroup of this ray
+  int seg_base;
+  if (INLINE_SCAN) {
+    __shared__ int part[4];
+    const int b0 = blockIdx.x * SEGS;                          // first select workgroup of this workgroup
+    int s = 0;
+    for (int i = t; i < b0; i += 256) s += block_total[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((t & 63) == 0) part[t >> 6] = s;
+    __syncthreads();
+    seg_base = part[0] + part[1] + part[2] + part[3];
+    for (int i = b0; i < seg && i < n_blocks; ++i) seg_base += block_total[i];
+    if (blockIdx.x == gridDim.x - 1 && t == 0) {               // the last workgroup knows the grand total
+      int tot = part[0] + part[1] + part[2] + part[3];
+      for (int i = b0; i < n_blocks; ++i) tot += block_total[i];
+      *total = tot;
+    }
+  } else {
+    seg_base = (seg < n_blocks) ? block_offset[seg] : 0;
+  }
   if (r >= n_rays) return;
-  const int o = block_offset[r / kSelRaysPerBlock] + x - c;
+  const int o = seg_base + x - c;
   ray_offsets[r] = o;
   const size_t src = static_cast<size_t>(r) * n_max;
   for (int k = 0; k < c; ++k) {
