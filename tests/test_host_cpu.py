@@ -178,11 +178,14 @@ def test_packed_sampling_net_reproduces_oracle(lib, tmp_path):
         n = 64
         nds = z["nds"][:n]
         u = (nds / np.sqrt(np.sum(nds * nds, -1, keepdims=True))).astype(np.float32)
-        for precision in (2, 3):     # exact fp32 fragments, and the fp16 hi/lo' split pairs
+        # exact fp32 fragments, the fp16 hi/lo' split pairs, and the plain fp16 fragments of the opt-in speed mode
+        for precision, atol in ((2, 5e-5), (3, 5e-5), (1, 1e-2)):
             w, b, lay = pack_weights(lib, d, 0, precision)
             assert w.size == sum(int(l[2]) // (4 if precision == 2 else 8) * int(l[3]) for l in lay) * 1024 * (2 if precision == 3 else 1)
+            if precision == 1 and fp == 10:
+                assert w.size == 880 * 1024          # sample16_frags<10, 4>() in k_sampling16.hip.hpp
             orc = run_sampling_net(PackedNet(w, b, lay, precision), u, z["p"][:n], fp, fd)
-            np.testing.assert_allclose(orc, z["oracle_out"][:n], rtol=0, atol=5e-5)
+            np.testing.assert_allclose(orc, z["oracle_out"][:n], rtol=0, atol=atol)
 
 
 def test_product_path_fails_loudly_without_gpu(lib, tmp_path):
