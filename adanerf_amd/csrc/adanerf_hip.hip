@@ -47,6 +47,7 @@ struct adanerf_ctx {
   bool profiling = false;
   int prof_frames = 0;
   std::vector<int32_t*> pinned_totals;   // one pinned int32 per recorded batch
+  adanerf_stats folded{};                // profiling record folded out of a full event pool (see adanerf_render)
 
   RayGenParams rg{};
   ShadeParams sp{};
@@ -203,6 +204,15 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   if (cf.accumulationMult == "alpha") ms->mult_mode = 1;
   else if (cf.accumulationMult == "weights") ms->mult_mode = 2;
   else ms->mult_mode = 0;
+  if (!pdf_mode && !cf.losses.empty()) {
+    // losses[0] drives two things on the adaptive path (src/nerf_raymarch_common.py:686-690, src/features.py:503):
+    // the transform applied to the oracle outputs before the threshold test (sigmoid / softmax for the BCE / CE losses)
+    // and whether the kept oracle values reach compositing at all (only under NeRFWeightMultiplicationLoss).
+    const std::string& l0 = cf.losses[0];
+    if (l0 == "BCEWithLogitsLoss" || l0 == "CrossEntropyLoss" || l0 == "CrossEntropyLossWeighted")
+      return bad(ADANERF_EUNSUPPORTED, "losses[0] = " + l0 + " (sigmoid / softmax oracle transform) is not supported on the adaptive path");
+    if (l0 != "NeRFWeightMultiplicationLoss") ms->mult_mode = 0;   // no oracle weights in compositing
+  }
 
   int n_max = opt->num_samples > 0 ? opt->num_samples : cf.numRaymarchSamples.back();
   float thr = opt->threshold >= 0.f ? opt->threshold : cf.adaptiveSamplingThreshold;
@@ -229,6 +239,9 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   const int R = I.rays_local;
   if (static_cast<int64_t>(w) * h >= (1ll << 25)) return bad(ADANERF_EINVAL, "width*height must be < 2^25");
   I.batch_rays = (opt->batch_rays <= 0) ? std::max(R, 1) : std::min(opt->batch_rays, std::max(R, 1));
+  // sample offsets, keys and totals are int32 on the device
+  if (static_cast<int64_t>(I.batch_rays) * n_max > 0x7fffffffll)
+    return bad(ADANERF_EINVAL, "batch_rays * num_samples exceeds 2^31 - 1; use a smaller batch (-bs)");
   I.n_in0 = 6 + 6 * (ms->fp0 + ms->fd0);
   I.n_in1 = 6 + 6 * (ms->fp1 + ms->fd1);
   I.num_samples = n_max;
@@ -325,7 +338,7 @@ int ensure_batch_buffers(adanerf_ctx* c, int n_rays, int n_max) {
   n_rays = std::max(n_rays, c->cap_rays);
   n_max = std::max(n_max, c->cap_nmax);
   const size_t R = static_cast<size_t>(n_rays), S = R * static_cast<size_t>(n_max);
-  const size_t nblk = (R + kSelRaysPerBlock - 1) / kSelRaysPerBlock;
+  const size_t nblk = (R + 31) / 32;     // segment totals: per 64 rays (select_kernel) or per 32 (pair selection)
   int rc;
   if ((rc = dev_alloc(c, &c->rays, R * 8 * sizeof(float)))) return rc;
   if ((rc = dev_alloc(c, &c->oracle, R * kBins * sizeof(float)))) return rc;
@@ -345,6 +358,23 @@ int ensure_batch_buffers(adanerf_ctx* c, int n_rays, int n_max) {
   return ADANERF_OK;
 }
 
+// Scratch of the selection / compaction stage only.  The stage entry point adanerf_compact must not re-allocate the
+// per-batch buffers: a caller may hold pointers from adanerf_get_buffer (e.g. pass the context's own oracle buffer).
+int ensure_compact_scratch(adanerf_ctx* c, int n_rays, int n_max) {
+  const size_t R = static_cast<size_t>(std::max(n_rays, 1)), S = R * static_cast<size_t>(n_max);
+  const size_t nblk = (R + 31) / 32;
+  int rc;
+  if (c->selbin.bytes < S || c->selw.bytes < S * sizeof(float) || c->block_total.bytes < nblk * sizeof(int32_t) ||
+      c->block_offset.bytes < nblk * sizeof(int32_t)) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // a previous launch may still use the old scratch
+    if ((rc = dev_alloc(c, &c->selbin, S))) return rc;
+    if ((rc = dev_alloc(c, &c->selw, S * sizeof(float)))) return rc;
+    if ((rc = dev_alloc(c, &c->block_total, nblk * sizeof(int32_t)))) return rc;
+    if ((rc = dev_alloc(c, &c->block_offset, nblk * sizeof(int32_t)))) return rc;
+  }
+  return ADANERF_OK;
+}
+
 // ---- launches ------------------------------------------------------------------------------
 
 template <typename K>
@@ -356,9 +386,14 @@ int occupancy_grid(adanerf_ctx* c, K kernel, int threads, int* out) {
   return ADANERF_OK;
 }
 
-int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle, float* d_rays) {
+// sel != nullptr: the adaptive selection runs in the kernel's epilogue (k_select_pair.hip.hpp) and d_oracle may be null
+int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle, float* d_rays, const SelectOut* sel = nullptr) {
   if (n_rays <= 0) return ADANERF_OK;
   SampleArgs a{};
+  if (sel) {
+    a.sel = *sel;
+    a.fused_select = 1;
+  }
   a.g = c->rg;
   a.net = c->net0.params;
   a.net16 = c->net0_split.params;
@@ -403,8 +438,42 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
   return ADANERF_OK;
 }
 
-// above this many select workgroups (64 rays each) the block totals are scanned by their own kernel
-constexpr int kInlineScanMaxBlocks = 16384;
+// above this many segment totals (one per 32 or 64 rays) they are scanned by their own kernel
+constexpr int kInlineScanMaxBlocks = 65536;
+
+SelectOut select_out(adanerf_ctx* c, int n_max, float thr, int32_t* d_cnt) {
+  SelectOut so{};
+  so.counts = d_cnt;
+  so.selbin = reinterpret_cast<uint8_t*>(c->selbin.p);
+  so.selw = reinterpret_cast<float*>(c->selw.p);
+  so.seg_total = reinterpret_cast<int32_t*>(c->block_total.p);
+  so.n_max = n_max;
+  so.thr = thr;
+  return so;
+}
+
+// the selection (counts, selbin, selw, segment totals per 2^seg_shift rays) is in place: offsets + compacted arrays
+int launch_expand(adanerf_ctx* c, int n_rays, int n_max, int seg_shift, int32_t* d_off, const int32_t* d_cnt, uint32_t* d_key, float* d_w,
+                  int32_t* d_total) {
+  const int nblk = (n_rays + (1 << seg_shift) - 1) >> seg_shift;
+  const int32_t* bt = reinterpret_cast<const int32_t*>(c->block_total.p);
+  int32_t* bo = reinterpret_cast<int32_t*>(c->block_offset.p);
+  const dim3 egrid((n_rays + 255) / 256);
+  if (nblk <= kInlineScanMaxBlocks) {
+    hipLaunchKernelGGL(expand_kernel<true>, egrid, dim3(256), 0, c->stream, d_cnt, reinterpret_cast<const uint8_t*>(c->selbin.p),
+                       reinterpret_cast<const float*>(c->selw.p), bo, bt, nblk, n_rays, n_max, seg_shift, d_off, d_key, d_w, d_total);
+  } else {
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, c->stream, bt, nblk, bo, d_total);
+    hipLaunchKernelGGL(expand_kernel<false>, egrid, dim3(256), 0, c->stream, d_cnt, reinterpret_cast<const uint8_t*>(c->selbin.p),
+                       reinterpret_cast<const float*>(c->selw.p), bo, bt, nblk, n_rays, n_max, seg_shift, d_off, d_key, d_w, d_total);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+// the pair selection keeps its sorted candidate lists in registers: n_max <= kPairMaxN; ADANERF_FLAG_WAVE_SELECT forces the
+// wave-per-ray select_kernel (any n_max)
+bool use_pair_select(const adanerf_ctx* c, int n_max) { return n_max <= kPairMaxN && !(c->opt.flags & ADANERF_FLAG_WAVE_SELECT); }
 
 int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max, float thr, int32_t* d_off, int32_t* d_cnt,
                    uint32_t* d_key, float* d_w, int32_t* d_total) {
@@ -416,25 +485,15 @@ int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max,
     HIP_TRY(c, hipGetLastError());
     return ADANERF_OK;
   }
+  if (use_pair_select(c, n_max)) {
+    hipLaunchKernelGGL(select_rows_kernel, dim3((n_rays + 127) / 128), dim3(256), 0, c->stream, d_oracle, n_rays, select_out(c, n_max, thr, d_cnt));
+    return launch_expand(c, n_rays, n_max, kPairSegShift, d_off, d_cnt, d_key, d_w, d_total);
+  }
   const int nblk = (n_rays + kSelRaysPerBlock - 1) / kSelRaysPerBlock;
   hipLaunchKernelGGL(select_kernel, dim3(nblk), dim3(256), 0, c->stream, d_oracle, n_rays, n_max, thr, d_cnt,
                      reinterpret_cast<uint8_t*>(c->selbin.p), reinterpret_cast<float*>(c->selw.p),
                      reinterpret_cast<int32_t*>(c->block_total.p));
-  const int32_t* bt = reinterpret_cast<const int32_t*>(c->block_total.p);
-  int32_t* bo = reinterpret_cast<int32_t*>(c->block_offset.p);
-  const dim3 egrid((n_rays + 255) / 256);
-  if (nblk <= kInlineScanMaxBlocks) {
-    hipLaunchKernelGGL(expand_kernel<true>, egrid, dim3(256), 0, c->stream, reinterpret_cast<const int32_t*>(d_cnt),
-                       reinterpret_cast<const uint8_t*>(c->selbin.p), reinterpret_cast<const float*>(c->selw.p), bo, bt, nblk, n_rays, n_max,
-                       d_off, d_key, d_w, d_total);
-  } else {
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, c->stream, bt, nblk, bo, d_total);
-    hipLaunchKernelGGL(expand_kernel<false>, egrid, dim3(256), 0, c->stream, reinterpret_cast<const int32_t*>(d_cnt),
-                       reinterpret_cast<const uint8_t*>(c->selbin.p), reinterpret_cast<const float*>(c->selw.p), bo, bt, nblk, n_rays, n_max,
-                       d_off, d_key, d_w, d_total);
-  }
-  HIP_TRY(c, hipGetLastError());
-  return ADANERF_OK;
+  return launch_expand(c, n_rays, n_max, kSelSegShift, d_off, d_cnt, d_key, d_w, d_total);
 }
 
 #ifndef ADN_SHADE_WAVES
@@ -720,7 +779,8 @@ int adanerf_compact(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, int32
   if (n_rays < 0 || n_max < 1 || n_max > kBins || thr < 0.f) return fail(c, ADANERF_EINVAL, "n_rays/n_max/thr out of range");
   if (thr == 0.f && n_max != kBins) return fail(c, ADANERF_EINVAL, "dense mode (thr == 0) requires n_max == 128");
   if (static_cast<int64_t>(n_rays) >= (1ll << 25)) return fail(c, ADANERF_EINVAL, "n_rays must be < 2^25 per batch");
-  int rc = ensure_batch_buffers(c, n_rays, n_max);
+  if (static_cast<int64_t>(n_rays) * n_max > 0x7fffffffll) return fail(c, ADANERF_EINVAL, "n_rays * n_max exceeds 2^31 - 1");
+  int rc = ensure_compact_scratch(c, n_rays, n_max);
   if (rc) return rc;
   return launch_compact(c, d_oracle, n_rays, n_max, thr, d_off, d_cnt, d_key, d_w, d_total);
 }
@@ -810,6 +870,17 @@ int sum_stats(adanerf_ctx* c, adanerf_stats* stats) {
   stats->batches = static_cast<int32_t>(nb);
   stats->shade_launches = static_cast<int32_t>(nb);
   stats->sample_launches = static_cast<int32_t>(nb);
+  // plus whatever an earlier, full event pool was folded into
+  const adanerf_stats& f = c->folded;
+  stats->total_samples += f.total_samples;
+  stats->ms_total += f.ms_total;
+  stats->ms_sample_mlp += f.ms_sample_mlp;
+  stats->ms_compact += f.ms_compact;
+  stats->ms_shade_mlp += f.ms_shade_mlp;
+  stats->ms_composite += f.ms_composite;
+  stats->batches += f.batches;
+  stats->shade_launches += f.shade_launches;
+  stats->sample_launches += f.sample_launches;
   return ADANERF_OK;
 }
 
@@ -855,9 +926,17 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->events_used = 0;
     c->prof_frames = 0;
+    c->folded = adanerf_stats{};
   }
-  bool record = stats || c->profiling;
-  if (record && c->events_used / 5 + n_batches > kMaxProfiledBatches) record = stats != nullptr;
+  const bool record = stats || c->profiling;
+  if (record && c->events_used && c->events_used / 5 + n_batches > kMaxProfiledBatches) {
+    // the event pool is full: fold what it holds into the running record (one synchronisation per 65 536 batches)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    adanerf_stats part;
+    if ((rc = sum_stats(c, &part))) return rc;
+    c->folded = part;
+    c->events_used = 0;
+  }
   if (record) {
     const size_t need = c->events_used + static_cast<size_t>(n_batches) * 5;
     while (c->events.size() < need) {
@@ -884,16 +963,24 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     const int first = b * B, n = std::min(B, R - first);
     hipEvent_t* ev = record ? &c->events[c->events_used] : nullptr;
     if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    if ((rc = launch_sample_mlp(c, first, n, oracle, rays))) return rc;
+    const bool pdf = c->info.sampler_mode == ADANERF_SAMPLER_PDF;
+    // adaptive selection in the epilogue of the sampling kernel: the [R,128] oracle values never reach HBM
+    const bool fused = !pdf && thr > 0.f && use_pair_select(c, N) && c->sampling_mode != 1 && !(c->opt.flags & ADANERF_FLAG_KEEP_ORACLE);
+    if (fused) {
+      const SelectOut so = select_out(c, N, thr, cnt);
+      rc = launch_sample_mlp(c, first, n, nullptr, rays, &so);
+    } else {
+      rc = launch_sample_mlp(c, first, n, oracle, rays);
+    }
+    if (rc) return rc;
     if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     float* sz = reinterpret_cast<float*>(c->sample_z.p);
-    const bool pdf = c->info.sampler_mode == ADANERF_SAMPLER_PDF;
     if (pdf) rc = launch_sample_pdf(c, oracle, n, N, off, cnt, key, sw, sz, total);
+    else if (fused) rc = launch_expand(c, n, N, kPairSegShift, off, cnt, key, sw, total);
     else rc = launch_compact(c, oracle, n, N, thr, off, cnt, key, sw, total);
     if (rc) return rc;
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
-    const int64_t max_s = static_cast<int64_t>(n) * N;
-    if (max_s > 0x7fffffffll) return fail(c, ADANERF_EINVAL, "batch_rays * num_samples exceeds 2^31; use a smaller batch");
+    const int64_t max_s = static_cast<int64_t>(n) * N;   // <= INT32_MAX: checked by setup_model
     if ((rc = launch_shade_mlp(c, rays, key, total, static_cast<int>(max_s), c->info.precision, raw, pdf ? sz : nullptr))) return rc;
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     float* rgb_b = d_rgb ? d_rgb + static_cast<size_t>(first) * 3 : nullptr;
@@ -918,6 +1005,7 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     }
     c->events_used = 0;
     c->prof_frames = 0;
+    c->folded = adanerf_stats{};
   }
   return ADANERF_OK;
 }
@@ -937,6 +1025,7 @@ int adanerf_set_profiling(adanerf_ctx* c, int32_t enabled) {
   c->profiling = enabled != 0;
   c->events_used = 0;
   c->prof_frames = 0;
+  c->folded = adanerf_stats{};
   return ADANERF_OK;
 }
 
@@ -950,6 +1039,7 @@ int adanerf_collect_stats(adanerf_ctx* c, adanerf_stats* stats, int32_t* frames)
   if (frames) *frames = c->prof_frames;
   c->events_used = 0;
   c->prof_frames = 0;
+  c->folded = adanerf_stats{};
   return ADANERF_OK;
 }
 

@@ -3,6 +3,7 @@
 // Device code only (gfx950, wave64); part of kernels.hip.hpp.
 #pragma once
 #include "k_common.hip.hpp"
+#include "k_select_pair.hip.hpp"
 
 namespace adanerf {
 
@@ -18,7 +19,8 @@ namespace adanerf {
 #define ADN_SEL_RPB 64
 #endif
 constexpr int kSelRaysPerBlock = ADN_SEL_RPB;
-static_assert(kSelRaysPerBlock == 16 || kSelRaysPerBlock == 32 || kSelRaysPerBlock == 64, "segment must fit one wave");
+static_assert(kSelRaysPerBlock == 32 || kSelRaysPerBlock == 64, "segment must fit one wave");
+constexpr int kSelSegShift = kSelRaysPerBlock == 64 ? 6 : 5;
 
 // Selection rule (src/nerf_raymarch_common.py:699-757 as a set rule):
 // keep the n_max largest values (ties: lower bin first) that are >= thr; if none is >= thr keep the
@@ -153,6 +155,32 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ o
   if (threadIdx.x == 0) block_total[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
 }
 
+// Lane-pair selection (k_select_pair.hip.hpp), standalone form: rows of [R,128] fp32 in global memory (stage API / parity tests).  4 waves x 32 rays per workgroup.
+__global__ __launch_bounds__(256) void select_rows_kernel(const float* __restrict__ oracle, int n_rays, SelectOut so) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * kPairLdsBytesPerWave];
+  const int lane = lane_id();
+  const int wave = static_cast<int>(threadIdx.x) >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int first = (blockIdx.x * 4 + wave) * 32;
+  if (first >= n_rays) return;                       // wave-uniform
+  const int local = first + j;
+  const bool valid = local < n_rays;
+  const float* row = oracle + static_cast<size_t>(valid ? local : n_rays - 1) * kBins;
+  float x[64];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = *reinterpret_cast<const float4*>(row + 32 * m + 8 * g + 4 * h);
+      x[16 * m + 4 * g + 0] = v.x;
+      x[16 * m + 4 * g + 1] = v.y;
+      x[16 * m + 4 * g + 2] = v.z;
+      x[16 * m + 4 * g + 3] = v.w;
+    }
+  const uint32_t stage = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + wave * kPairLdsBytesPerWave + lane * 16;
+  pair_epilogue(x, lane, local, valid, stage, so);
+}
+
 // exclusive scan of the per-block totals by one workgroup; writes S to *total
 __global__ __launch_bounds__(1024) void scan_blocks_kernel(const int32_t* __restrict__ block_total, int n_blocks,
                                                            int32_t* __restrict__ block_offset, int32_t* __restrict__ total) {
@@ -185,34 +213,34 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const int32_t* __rest
 }
 
 // ray offsets + compacted (key, weight) arrays, ray-major / bins ascending
-// One thread per ray; the rays of one select_kernel workgroup are one wave segment, so the in-segment prefix is a
-// width-limited shuffle scan (no LDS, no barrier).  INLINE_SCAN: the workgroup also derives its own base offset by
-// summing the block totals in front of it (a cooperative reduction over <= 16 384 ints from L2) instead of reading the
-// output of scan_blocks_kernel -- one launch and its ~10 us of single-workgroup latency less per batch; the host keeps
-// the separate scan for larger batches, where every workgroup re-reading the totals would be quadratic.
+// One thread per ray; the rays behind one entry of the segment totals (2^seg_shift rays: 64 for select_kernel's workgroups,
+// 32 for the wave-sized segments of the fused / pair selection, k_select_pair.hip.hpp) are part of one wave, so the in-segment
+// prefix is a width-limited shuffle scan (no LDS, no barrier).  INLINE_SCAN: the workgroup also derives its own base offset by
+// summing the segment totals in front of it (a cooperative reduction over <= kInlineScanMaxBlocks ints from L2) instead of
+// reading the output of scan_blocks_kernel -- one launch and its ~10 us of single-workgroup latency less per batch; the host
+// keeps the separate scan for larger batches, where every workgroup re-reading the totals would be quadratic.
 template <bool INLINE_SCAN>
 __global__ __launch_bounds__(256) void expand_kernel(const int32_t* __restrict__ counts, const uint8_t* __restrict__ selbin,
                                                      const float* __restrict__ selw, const int32_t* __restrict__ block_offset,
                                                      const int32_t* __restrict__ block_total, int n_blocks, int n_rays, int n_max,
-                                                     int32_t* __restrict__ ray_offsets, uint32_t* __restrict__ sample_key,
+                                                     int seg_shift, int32_t* __restrict__ ray_offsets, uint32_t* __restrict__ sample_key,
                                                      float* __restrict__ sample_w, int32_t* __restrict__ total) {
-  static_assert(kSelRaysPerBlock <= 64 && 256 % kSelRaysPerBlock == 0, "one segment per wave or less");
-  constexpr int SEGS = 256 / kSelRaysPerBlock;                 // select workgroups covered by this workgroup
+  const int seg_rays = 1 << seg_shift;                         // 32 or 64: one segment per wave or less
+  const int segs = 256 >> seg_shift;                           // segments covered by this workgroup
   const int t = static_cast<int>(threadIdx.x);
   const int r = blockIdx.x * 256 + t;
   const int c = (r < n_rays) ? counts[r] : 0;
-  const int seg_lane = r & (kSelRaysPerBlock - 1);
+  const int seg_lane = r & (seg_rays - 1);
   int x = c;
-#pragma unroll
-  for (int off = 1; off < kSelRaysPerBlock; off <<= 1) {
-    const int y = __shfl_up(x, off, kSelRaysPerBlock);
+  for (int off = 1; off < seg_rays; off <<= 1) {
+    const int y = __shfl_up(x, off, seg_rays);
     if (seg_lane >= off) x += y;
   }
-  const int seg = r / kSelRaysPerBlock;                        // select workgroup of this ray
+  const int seg = r >> seg_shift;                              // segment of this ray
   int seg_base;
   if (INLINE_SCAN) {
     __shared__ int part[4];
-    const int b0 = blockIdx.x * SEGS;                          // first select workgroup of this workgroup
+    const int b0 = blockIdx.x * segs;                          // first segment of this workgroup
     int s = 0;
     for (int i = t; i < b0; i += 256) s += block_total[i];
 #pragma unroll

@@ -87,7 +87,13 @@ struct Fp16 {
 // 256-register cap: 2 leaves the shading kernel spill-free (4: 6 spilled dwords, 3.77 vs 3.73 ms; 8: 4.43 ms).  The
 // one-wave-per-SIMD split sampling kernel keeps a whole chunk (ADN_NR_S).
 #ifndef ADN_NR
-#define ADN_NR 2
+#define ADN_NR 4
+#endif
+#ifndef ADN_DMA_GRP
+#define ADN_DMA_GRP 0   // -1: every wave DMA-copies CF / WAVES pieces per chunk; 0 / 1: only waves 0-3 / 4-7 do (CF / 4 pieces each)
+#endif
+#ifndef ADN_STAGGER
+#define ADN_STAGGER 1   // 1: waves 4-7 of an 8-wave workgroup synchronise half a chunk later than waves 0-3 (ws_sync)
 #endif
 constexpr int kRegFrags = ADN_NR;
 constexpr int kShadeFrags16 = 32 + 4 * 128 + 160 + 2 * 128 + 144 + 72 + 8;   // 1184 per pass (FP=10, FD=4)
@@ -112,6 +118,8 @@ struct WStream {
   uint32_t rd_cur;       // LDS byte address of (current chunk, this lane)
   uint32_t rd_next;      // LDS byte address of (next chunk, this lane)
   uint32_t lds_base;     // LDS byte address of the ring
+  uint32_t grp;          // 0: this wave synchronises at chunk position 0, 1: at position CF / 2 (see ws_sync)
+  uint32_t issuer;       // this wave issues LDS-DMA pieces (all waves, or one group only: ADN_DMA_GRP)
   u32x4 R[NR];           // register ring: fragment p (position inside the chunk) lives in R[p % NR]
 };
 
@@ -140,24 +148,57 @@ __device__ __forceinline__ void ws_issue(WStream<CF, RS, LPW, NR>& st, uint32_t 
   if (st.goff >= st.gbytes) st.goff = 0;
 }
 
-// chunk boundary k: own pieces of chunk k+1 have landed (<= (RS-3) LPW younger DMAs outstanding); barrier =>
-// chunk k+1 complete in LDS for every wave and every wave has consumed chunk k-1 (its MFMAs were
-// issued before the barrier, so its ds_reads returned) => refill the slot of chunk k-1 with chunk k+RS-1.
+// Synchronisation point k of the ring: own pieces of chunk k+1 have landed (<= (RS-3) LPW younger DMAs outstanding);
+// barrier => chunk k+1 is complete in LDS for every wave and every wave has consumed chunk k-1 (its MFMAs were issued
+// before the barrier, so its ds_reads returned) => refill the slot of chunk k-1 with chunk k+RS-1.
+// Waves of group 0 reach it at fragment position 0 of chunk k, waves of group 1 at position CF / 2 of chunk k (ADN_STAGGER):
+// the two waves that share a SIMD (wave i and wave i + 4 of an 8-wave workgroup) then run half an output tile apart, so
+// one of them is issuing MFMAs while the other is in its bias-read / epilogue / DMA-issue phase, instead of both hitting
+// those phases in the same cycles (a workgroup barrier per chunk otherwise keeps all eight waves in lockstep).  Both
+// groups see the same guarantees: a wave of group 1 is at most half a chunk ahead, i.e. still inside chunk k.
+#ifndef ADN_STAG_DBG
+#define ADN_STAG_DBG 0   // hazard-hunting variants of the group-1 synchronisation (tools/ablate.sh); 0 in the shipped build
+#endif
 template <int ABL, int CF, int RS, int LPW, int NR>
-__device__ __forceinline__ void ws_boundary(WStream<CF, RS, LPW, NR>& st) {
+__device__ __forceinline__ void ws_sync(WStream<CF, RS, LPW, NR>& st) {
   static_assert(RS >= 3 && (RS - 2) * LPW < 64, "vmcnt is a 6-bit counter");
   if (ABL & 1) return;
-  if (!(ABL & 32)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 3) * LPW) : "memory");   // 32: no wait/barrier
-  const uint32_t old = st.slot_cur;
-  st.slot_cur = (old + 1 == RS) ? 0 : old + 1;
+  if (!(ABL & 32)) {
+    if ((ADN_STAG_DBG == 1 && st.grp) || ADN_STAG_DBG == 5) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (ADN_STAG_DBG == 6 && st.grp) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier\n\ts_sleep 8" ::"n"((RS - 3) * LPW) : "memory");
+    else if (ADN_STAG_DBG == 2 && st.grp) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RS - 3) * LPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 3) * LPW) : "memory");   // 32: no wait/barrier
+  }
+  // slot of chunk k-1: group 0 is still "in" it (ws_advance follows), group 1 has moved on to chunk k
+  const uint32_t slot = (st.grp == 0) ? st.slot_cur : (st.slot_cur == 0 ? RS - 1 : st.slot_cur - 1);
+  if (!(ABL & 16) && st.issuer) ws_issue(st, slot);                                                                      // 16: no DMA
+}
+
+// the wave moves from chunk k-1 to chunk k: rotate the LDS read addresses
+template <int CF, int RS, int LPW, int NR>
+__device__ __forceinline__ void ws_advance(WStream<CF, RS, LPW, NR>& st) {
+  st.slot_cur = (st.slot_cur + 1 == RS) ? 0 : st.slot_cur + 1;
   const uint32_t nxt = (st.slot_cur + 1 == RS) ? 0 : st.slot_cur + 1;
-  if (!(ABL & 16)) ws_issue(st, old);                                                                       // 16: no DMA
   st.rd_cur = st.rd_next;
   st.rd_next = st.lds_base + nxt * (CF * 1024) + st.lane_off;
 }
 
+// fragment position f (compile-time) of the stream is about to be consumed
+template <int ABL, int CF, int RS, int LPW, int NR>
+__device__ __forceinline__ void ws_position(WStream<CF, RS, LPW, NR>& st, int f) {
+  if (f == 0) {
+    if (ABL & 1) return;
+    if (st.grp == 0) ws_sync<ABL>(st);
+    else if (ADN_STAG_DBG == 4) asm volatile("s_barrier" ::: "memory");
+    ws_advance(st);
+  } else if (f == CF / 2) {
+    if (st.grp != 0) ws_sync<ABL>(st);
+    else if (ADN_STAG_DBG == 4) asm volatile("s_barrier" ::: "memory");
+  }
+}
+
 // fragment position p inside the current chunk has just been consumed: re-fill its register with fragment
-// p + kRegFrags (same chunk, or the next chunk -- already landed: see ws_boundary)
+// p + kRegFrags (same chunk, or the next chunk -- already landed: see ws_sync)
 template <int ABL, int CF, int RS, int LPW, int NR>
 __device__ __forceinline__ void ws_refill(WStream<CF, RS, LPW, NR>& st, int p) {
   if (ABL & 2) {
@@ -169,7 +210,10 @@ __device__ __forceinline__ void ws_refill(WStream<CF, RS, LPW, NR>& st, int p) {
 }
 
 template <int CF, int RS, int LPW, int NR>
-__device__ __forceinline__ void ws_start(WStream<CF, RS, LPW, NR>& st, const void* gbase, uint32_t gbytes, char* lds, int wave, int lane) {
+__device__ __forceinline__ void ws_start(WStream<CF, RS, LPW, NR>& st, const void* gbase, uint32_t gbytes, char* lds, int wave, int lane,
+                                         uint32_t grp = 0, bool issuer = true) {
+  st.grp = grp;
+  st.issuer = issuer;
   st.gbase = reinterpret_cast<const char*>(gbase);
   st.gbytes = gbytes;
 #if ADN_BUFDMA && defined(__HIP_DEVICE_COMPILE__)
@@ -179,10 +223,12 @@ __device__ __forceinline__ void ws_start(WStream<CF, RS, LPW, NR>& st, const voi
   st.lane_off = lane * 16;
   st.wave_off = wave * LPW * 1024;
   st.lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds));
+  if (issuer) {
 #pragma unroll
-  for (int k = 0; k < RS - 1; ++k) ws_issue(st, k);
+    for (int k = 0; k < RS - 1; ++k) ws_issue(st, k);
+  }
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 2) * LPW) : "memory");
-  st.slot_cur = RS - 1;                       // the first boundary moves to slot 0 = chunk 0
+  st.slot_cur = RS - 1;                       // the first ws_advance moves to slot 0 = chunk 0
   st.rd_cur = st.lds_base + st.lane_off;      // unused until then
   st.rd_next = st.lds_base + st.lane_off;     // chunk 0
 #pragma unroll
@@ -287,7 +333,7 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int f = (FPOS + m * KS + s) % CF;     // position inside the chunk; compile-time after unrolling
-      if (f == 0) ws_boundary<ADN_ABLATE>(st);
+      ws_position<ADN_ABLATE>(st, f);
       const uint32_t* src = (s < S1) ? (in1 + 4 * s) : (in2 + 4 * (s - S1));
       u32x4 b = {src[0], src[1], src[2], src[3]};
       acc = ET::mfma(st.R[f % WS::kRegs], b, acc);
@@ -362,7 +408,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
   static_assert(FP == 10 && FD == 4, "fragment positions below assume the 10-4 shading encoding");
   static_assert(WAVES == 4 || WAVES == 8, "chunk = 8 fragments");
   constexpr int QP = pe_slots(FP), QD = pe_slots(FD);
-  constexpr int TILE = WAVES * 32, CF = ADN_CF, RS = ADN_RS, LPW = CF / WAVES;
+  constexpr bool kOneGroupDma = ADN_DMA_GRP >= 0 && WAVES == 8;
+  constexpr int TILE = WAVES * 32, CF = ADN_CF, RS = ADN_RS, LPW = kOneGroupDma ? CF / 4 : CF / WAVES;
   constexpr int kRingBytes = CF * RS * 1024;
   static_assert(CF % WAVES == 0 && CF % kRegFrags == 0 && kShadeFrags16 % CF == 0 && CF % 8 == 0 && CF <= 32, "chunk geometry");
   typedef WStream<CF, RS, LPW> WS;
@@ -387,7 +434,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
   }
   __syncthreads();
   WS st;
-  ws_start(st, a.net.w, kShadeFrags16 * 1024, lds, wave, lane);
+  ws_start(st, a.net.w, kShadeFrags16 * 1024, lds, kOneGroupDma ? (wave & 3) : (ADN_STAG_DBG == 7 ? (wave ^ 4) : wave), lane,
+           (ADN_STAGGER && WAVES == 8) ? static_cast<uint32_t>(wave >> 2) : 0u, !kOneGroupDma || (wave >> 2) == ADN_DMA_GRP);
 
   // LDS byte address of the bias blocks of this lane-half
   const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;

@@ -3,6 +3,7 @@
 // Device code only (gfx950, wave64); part of kernels.hip.hpp.
 #pragma once
 #include "k_common.hip.hpp"
+#include "k_select_pair.hip.hpp"
 
 namespace adanerf {
 
@@ -54,6 +55,8 @@ struct SampleArgs {
   int32_t first_ray, n_rays;
   float* oracle_out;     // [n_rays,128] or null
   float* rays_out;       // [n_rays,8] or null
+  SelectOut sel;         // fused_select: adaptive selection in the kernel's epilogue (16-bit engines)
+  int32_t fused_select;
 };
 
 // A1+A2+A3.  One wave = one block of 32 rays; 4 waves per workgroup (one per SIMD, up to 512 VGPRs).

@@ -68,7 +68,7 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int f = (FPOS + 2 * (m * KS + s)) % ADN_CF_S;   // compile-time after unrolling; always even
-      if (f == 0) ws_boundary<ADN_ABLATE_S>(st);
+      ws_position<ADN_ABLATE_S>(st, f);
       const u32x4 bh = {in_hi[4 * s], in_hi[4 * s + 1], in_hi[4 * s + 2], in_hi[4 * s + 3]};
       const u32x4 bl = {in_lo[4 * s], in_lo[4 * s + 1], in_lo[4 * s + 2], in_lo[4 * s + 3]};
       acc = Fp16::mfma(st.R[f % WS::kRegs], bh, acc);
@@ -114,12 +114,15 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
   static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % WAVES == 0 && CF % ADN_NR_S == 0 && CF <= 32, "chunk geometry");
   typedef WStream<CF, RS, LPW, ADN_NR_S> WS;
   constexpr int kRingBytes = CF * RS * 1024, kBiasFloats = 7 * 256 + 128;
-  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kBiasFloats * 4];
+  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kBiasFloats * 4 + WAVES * kPairLdsBytesPerWave];
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int j = lane & 31, h = lane >> 5;
   const int ntiles = (a.n_rays + TILE - 1) / TILE;
   if (static_cast<int>(blockIdx.x) >= ntiles) return;
+  // staging block of the fused selection (pair_emit), wave-private
+  const uint32_t sel_stage = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + kBiasFloats * 4 +
+                             wave * kPairLdsBytesPerWave + lane * 16;
 
   {
     float* lds_bias = reinterpret_cast<float*>(lds + kRingBytes);
@@ -158,6 +161,15 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
     float out[64];
     layer_16x3<WS, 16, 4, true, 0>(st, bias0 + bo[7] * 4, lane, bH, bL, nullptr, nullptr, out);
 
+    if (a.fused_select) {
+      // A4 in the epilogue: the 128 raw outputs of ray j sit in lanes j and j + 32 (k_select_pair.hip.hpp)
+      float z = 0.f;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) z = __builtin_fmaf(out[i], 0.f, z);    // NaN iff some output is inf / NaN (fp16 range left)
+      const bool bad_ray = (z != z) | (__shfl_xor(static_cast<int>(z != z), 32) != 0);
+      if (bad_ray && valid && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
+      pair_epilogue(out, lane, local, valid, sel_stage, a.sel);
+    }
     if (valid) {
       if (a.oracle_out) {
         float* o = a.oracle_out + static_cast<size_t>(local) * kBins;
@@ -170,8 +182,10 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
             bad |= !(fabsf(v.x) < 3.0e38f) | !(fabsf(v.y) < 3.0e38f) | !(fabsf(v.z) < 3.0e38f) | !(fabsf(v.w) < 3.0e38f);
             *reinterpret_cast<float4*>(o + 32 * m + 8 * g + 4 * h) = v;
           }
-        // an activation beyond the fp16 range (65504) shows up as inf/NaN here
-        if (bad && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
+        // an activation beyond the fp16 range (65504) shows up as inf/NaN here; a ray is owned by lanes j and j + 32
+        // (64 outputs each), counted once
+        const bool bad_ray = bad | (__shfl_xor(static_cast<int>(bad), 32) != 0);
+        if (bad_ray && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
       }
       if (a.rays_out) {
         float ro[3] = {p[0], p[1], p[2]}, rd[3] = {nds[0], nds[1], nds[2]};
@@ -196,24 +210,28 @@ constexpr int sample16_frags() { return ((pe_slots(FD) + pe_slots(FP)) / 8) * 8 
 template <int FP, int FD>
 __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
   constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP;
-  constexpr int WAVES = 8, CF = 16, RS = 4, LPW = CF / WAVES, TILE = WAVES * 32;   // 880 fragments = 55 chunks of 16
+  constexpr bool kOneGroupDma = ADN_DMA_GRP >= 0;
+  constexpr int WAVES = 8, CF = 16, RS = 4, LPW = kOneGroupDma ? CF / 4 : CF / WAVES, TILE = WAVES * 32;   // 880 fragments = 55 chunks of 16
   constexpr int F0 = (Q0 / 8) * 8, FRAGS = sample16_frags<FP, FD>();
   static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % WAVES == 0 && CF % kRegFrags == 0 && CF <= 32, "chunk geometry");
   typedef WStream<CF, RS, LPW> WS;
   constexpr int kRingBytes = CF * RS * 1024, kBiasFloats = 7 * 256 + 128;
-  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kBiasFloats * 4];
+  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kBiasFloats * 4 + WAVES * kPairLdsBytesPerWave];
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int j = lane & 31, h = lane >> 5;
   const int ntiles = (a.n_rays + TILE - 1) / TILE;
   if (static_cast<int>(blockIdx.x) >= ntiles) return;
+  const uint32_t sel_stage = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + kBiasFloats * 4 +
+                             wave * kPairLdsBytesPerWave + lane * 16;
   {
     float* lds_bias = reinterpret_cast<float*>(lds + kRingBytes);
     for (int i = threadIdx.x; i < kBiasFloats; i += blockDim.x) lds_bias[i] = a.net16.bias[i];
   }
   __syncthreads();
   WS st;
-  ws_start(st, a.net16.w, FRAGS * 1024, lds, wave, lane);
+  ws_start(st, a.net16.w, FRAGS * 1024, lds, kOneGroupDma ? (wave & 3) : wave, lane, ADN_STAGGER ? static_cast<uint32_t>(wave >> 2) : 0u,
+           !kOneGroupDma || (wave >> 2) == ADN_DMA_GRP);
   const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
   const uint32_t* bo = a.net16.b_off;
 
@@ -250,6 +268,18 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
     }
     f32x16 out[4];
     layer_16<Fp16, WS, 16, 0, 4, false, F0 % CF, kKeepAllF32>(st, bias0 + bo[7] * 4, lane, hA, hA, hB, out);
+    if (a.fused_select) {
+      float x[64];
+      float z = 0.f;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        x[i] = out[i >> 4][i & 15];
+        z = __builtin_fmaf(x[i], 0.f, z);
+      }
+      const bool bad_ray = (z != z) | (__shfl_xor(static_cast<int>(z != z), 32) != 0);
+      if (bad_ray && valid && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
+      pair_epilogue(x, lane, local, valid, sel_stage, a.sel);
+    }
     if (valid && a.oracle_out) {
       float* o = a.oracle_out + static_cast<size_t>(local) * kBins;
       bool bad = false;
@@ -261,7 +291,8 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
           bad |= !(fabsf(v.x) < 3.0e38f) | !(fabsf(v.y) < 3.0e38f) | !(fabsf(v.z) < 3.0e38f) | !(fabsf(v.w) < 3.0e38f);
           *reinterpret_cast<float4*>(o + 32 * m + 8 * g + 4 * h) = v;
         }
-      if (bad && a.overflow_flag) atomicAdd(a.overflow_flag, 1);   // an activation left the fp16 range
+      const bool bad_ray = bad | (__shfl_xor(static_cast<int>(bad), 32) != 0);   // lanes j and j + 32 own one ray
+      if (bad_ray && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);    // an activation left the fp16 range
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1,0 +1,208 @@
+// A4 (selection half) on the register layout the sampling MLP leaves its outputs in, so that the adaptive selection runs
+// in the epilogue of the kernel that produces the oracle values and the [R,128] fp32 round trip through HBM disappears
+// (SURVEY 8d prices the compaction read at "0 if fused after A3").  select_rows_kernel (k_compact.hip.hpp) runs the very same
+// device code over [R,128] rows in global memory (stage API adanerf_compact, parity tests).
+// Device code only (gfx950, wave64); part of kernels.hip.hpp.
+#pragma once
+#include "k_common.hip.hpp"
+
+namespace adanerf {
+
+// Where the selection stage leaves its results (the inputs of expand_kernel).
+struct SelectOut {
+  int32_t* counts;      // [R]            kept samples per ray, 1..n_max
+  uint8_t* selbin;      // [R, n_max]     kept bins, ascending
+  float* selw;          // [R, n_max]     oracle value of each kept bin
+  int32_t* seg_total;   // [ceil(R / 32)] samples kept by each 32-ray segment (one wave's rays)
+  int32_t n_max;
+  float thr;
+};
+
+constexpr int kPairSegShift = 5;                 // a wave selects for 32 rays = one entry of seg_total
+constexpr int kPairMaxN = 16;                    // largest n_max this path handles (sorted lists live in registers)
+constexpr int kPairLdsBytesPerWave = 32 * 64 * 4;   // staging of 32 values per lane (two passes)
+
+// The MFMA layout (layout.hpp): lane l = (j = l & 31, h = l >> 5) of a wave holds, for ray j, the 64 values
+// x[i], i = 16 m + r, of bins act_feature(i, h) = 32 m + 8 (r >> 2) + 4 h + (r & 3): within every group of 8 consecutive
+// bins the first four sit in lane j, the next four in lane j + 32.  All set arithmetic below is per lane on 64-bit masks over i
+// plus one exchange with the partner lane.
+
+__device__ __forceinline__ uint32_t pair_xchg(uint32_t v) { return static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 32)); }
+__device__ __forceinline__ float pair_xchg(float v) { return __shfl_xor(v, 32); }
+
+// bits [0, n) of a 32-bit word, 0 <= n <= 32
+__device__ __forceinline__ uint32_t low_bits32(int n) { return static_cast<uint32_t>((1ull << n) - 1ull); }
+
+// 64-bit mask {x[i] >= t} / {x[i] > t} over the lane's values (NaN compares false, as in the reference's `samples >= threshold`)
+template <bool STRICT>
+__device__ __forceinline__ void pair_mask(const float* x, float t, uint32_t* lo, uint32_t* hi) {
+  uint32_t a = 0, b = 0;
+#pragma unroll
+  for (int i = 31; i >= 0; --i) {
+    a = a + a + ((STRICT ? x[i] > t : x[i] >= t) ? 1u : 0u);
+    b = b + b + ((STRICT ? x[32 + i] > t : x[32 + i] >= t) ? 1u : 0u);
+  }
+  *lo = a;
+  *hi = b;
+}
+
+// number of PARTNER elements whose bin is below the bins of this lane's group g = i >> 2 (0..15): the partner's groups
+// 0..g-1, plus its group g when this lane is the upper half.  q = partner mask pre-shifted by pair_align().
+__device__ __forceinline__ void pair_align(uint32_t plo, uint32_t phi, int h, uint32_t* qlo, uint32_t* qhi) {
+  // lower half: groups < g <=> partner indices < 4 g <=> (mask << 4) indices < 4 g + 4; upper half: indices < 4 g + 4
+  *qlo = h ? plo : (plo << 4);
+  *qhi = h ? phi : ((phi << 4) | (plo >> 28));
+}
+__device__ __forceinline__ int pair_below(uint32_t qlo, uint32_t qhi, int g) {   // g may be a run-time value
+  const int n = 4 * g + 4;
+  return n <= 32 ? __popc(qlo & low_bits32(n)) : __popc(qlo) + __popc(qhi & low_bits32(n - 32));
+}
+
+// Selection rule of src/nerf_raymarch_common.py:699-757 as a set rule (the same rule select_ray in
+// k_compact.hip.hpp implements with wave ballots): keep the n_max largest values (ties: lower bin first) that are >= thr; if
+// none is, keep the arg-max alone.  Returns this lane's kept set as a mask over i and the ray's kept count.
+//   1. per lane, the NB largest of its 64 values by branch-free insertion into a sorted register list (v_med3_f32 per slot),
+//   2. partner's list by one cross-half exchange, bitonic merge -> the ray's n_max-th largest value,
+//   3. cut value t = max(that, thr) (or the maximum when nothing reaches thr); kept = {x >= t}; only if more than n_max
+//      values pass -- a tie at the cut-off -- the slower exact tie rule runs (wave-uniform branch).
+template <int NB>
+__device__ __forceinline__ int pair_select(const float* x, int h, int n_max, float thr, uint32_t* sel_lo, uint32_t* sel_hi) {
+  static_assert(NB == 4 || NB == 8 || NB == 16, "bitonic merge");
+  float s[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) s[k] = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    const float v = (x[i] == x[i]) ? x[i] : -INFINITY;   // NaN never ranks (fmaxf in select_ray ignores it, too)
+#pragma unroll
+    for (int k = NB - 1; k >= 1; --k) s[k] = __builtin_amdgcn_fmed3f(s[k - 1], s[k], v);
+    s[0] = fmaxf(s[0], v);
+  }
+  float c[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) c[k] = pair_xchg(s[k]);
+  {
+    float p[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) p[k] = fmaxf(s[k], c[NB - 1 - k]);    // the NB largest of the union, bitonic order
+#pragma unroll
+    for (int k = 0; k < NB; ++k) c[k] = p[k];
+  }
+#pragma unroll
+  for (int d = NB / 2; d >= 1; d >>= 1)
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if ((k & d) == 0) {
+        const float a = c[k], b = c[k + d];
+        c[k] = fmaxf(a, b);
+        c[k + d] = fminf(a, b);
+      }
+  float tn = c[0];
+#pragma unroll
+  for (int k = 1; k < NB; ++k) tn = (k == n_max - 1) ? c[k] : tn;
+  const bool none = c[0] < thr;                       // nothing reaches the threshold: arg-max alone
+  const float t = none ? c[0] : fmaxf(tn, thr);
+  const int n_eff = none ? 1 : n_max;
+
+  uint32_t lo, hi;
+  pair_mask<false>(x, t, &lo, &hi);
+  int own = __popc(lo) + __popc(hi);
+  int total = own + static_cast<int>(pair_xchg(static_cast<uint32_t>(own)));
+  const bool tie = total > n_eff;
+  if (__ballot(tie) != 0ull) {
+    // exact tie rule: everything above t, then the lowest-bin members of {x == t} until n_eff are kept
+    uint32_t glo, ghi;
+    pair_mask<true>(x, t, &glo, &ghi);
+    const uint32_t elo = lo & ~glo, ehi = hi & ~ghi;
+    const int gown = __popc(glo) + __popc(ghi);
+    const int need = n_eff - (gown + static_cast<int>(pair_xchg(static_cast<uint32_t>(gown))));
+    uint32_t qlo, qhi;
+    pair_align(pair_xchg(elo), pair_xchg(ehi), h, &qlo, &qhi);
+    // rank of every tie member among the tie members of the ray, in bin order; walked bit by bit (ties are few, and
+    // this path is rare: no unrolled per-index constants)
+    uint32_t klo = 0, khi = 0;
+    for (uint32_t m = tie ? elo : 0u; m; m &= m - 1u) {
+      const int i = __builtin_ctz(m);
+      const int rank = __popc(elo & low_bits32(i)) + pair_below(qlo, qhi, i >> 2);
+      klo |= (rank < need ? 1u : 0u) << i;
+    }
+    for (uint32_t m = tie ? ehi : 0u; m; m &= m - 1u) {
+      const int i = __builtin_ctz(m);
+      const int rank = __popc(elo) + __popc(ehi & low_bits32(i)) + pair_below(qlo, qhi, 8 + (i >> 2));
+      khi |= (rank < need ? 1u : 0u) << i;
+    }
+    if (tie) {
+      lo = glo | klo;
+      hi = ghi | khi;
+    }
+    own = __popc(lo) + __popc(hi);
+    total = own + static_cast<int>(pair_xchg(static_cast<uint32_t>(own)));
+  }
+  if (total == 0) {          // all-NaN row: undefined in the reference; bin 0, like select_ray
+    if (h == 0) lo = 1u;
+    total = 1;
+  }
+  *sel_lo = lo;
+  *sel_hi = hi;
+  return total;
+}
+
+// hand-issued LDS accesses (hipcc would otherwise order them against the LDS-DMA weight ring with vmcnt(0): see k_mlp16.hip.hpp)
+__device__ __forceinline__ void pair_lds_write4(uint32_t byte_addr, float a, float b, float c, float d) {
+  const f32x4 v = {a, b, c, d};
+  asm volatile("ds_write_b128 %0, %1" ::"v"(byte_addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ float pair_lds_read(uint32_t byte_addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(byte_addr) : "memory");
+  return v;
+}
+
+// Writes the kept (bin, value) pairs of this lane in ascending-bin order of the RAY: slot = rank among the ray's kept bins.
+// The values are staged in a wave-private LDS block so that a lane can fetch x[i] for a run-time i (a register array cannot be
+// indexed dynamically); `stage` = LDS byte address of the wave's block + lane * 16.
+__device__ __forceinline__ void pair_emit(const float* x, uint32_t lo, uint32_t hi, int h, uint32_t stage, bool valid, size_t slot0,
+                                          uint8_t* __restrict__ selbin, float* __restrict__ selw) {
+  uint32_t qlo, qhi;
+  pair_align(pair_xchg(lo), pair_xchg(hi), h, &qlo, &qhi);
+  const int nlo = __popc(lo);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous pass's reads are done before the block is overwritten
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      pair_lds_write4(stage + q * 1024, x[32 * pass + 4 * q], x[32 * pass + 4 * q + 1], x[32 * pass + 4 * q + 2], x[32 * pass + 4 * q + 3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint32_t own = pass ? hi : lo;
+    uint32_t m = valid ? own : 0u;
+    while (m) {
+      const int i = __builtin_ctz(m);
+      m &= m - 1u;
+      const float v = pair_lds_read(stage + (i >> 2) * 1024 + (i & 3) * 4);
+      const int rank = (pass ? nlo : 0) + __popc(own & low_bits32(i)) + pair_below(qlo, qhi, (32 * pass + i) >> 2);
+      selbin[slot0 + rank] = static_cast<uint8_t>(act_feature(32 * pass + i, h));
+      selw[slot0 + rank] = v;
+    }
+  }
+}
+
+// The whole epilogue for one wave's 32 rays: select, emit, per-ray counts, segment total.
+//   x        64 values of ray j in lane (j, h) (layout above)
+//   local    ray index of lane j inside the batch, valid = local < n_rays (invalid lanes hold a duplicate ray)
+//   stage    see pair_emit
+__device__ __forceinline__ void pair_epilogue(const float* x, int lane, int local, bool valid, uint32_t stage, const SelectOut& so) {
+  const int h = lane >> 5;
+  uint32_t lo, hi;
+  int total;
+  if (so.n_max <= 4) total = pair_select<4>(x, h, so.n_max, so.thr, &lo, &hi);
+  else if (so.n_max <= 8) total = pair_select<8>(x, h, so.n_max, so.thr, &lo, &hi);
+  else total = pair_select<16>(x, h, so.n_max, so.thr, &lo, &hi);
+  pair_emit(x, lo, hi, h, stage, valid, static_cast<size_t>(local) * so.n_max, so.selbin, so.selw);
+  int t = (valid && h == 0) ? total : 0;
+  if (valid && h == 0) so.counts[local] = total;
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) t += __shfl_xor(t, off);      // lanes 0..31 hold the rays
+  if (lane == 0 && valid) so.seg_total[local >> kPairSegShift] = t;   // lane 0 invalid: the whole wave is beyond n_rays
+}
+
+}  // namespace adanerf

@@ -11,6 +11,7 @@
 #include "k_common.hip.hpp"
 #include "k_mlp_f32.hip.hpp"
 #include "k_compact.hip.hpp"
+#include "k_select_pair.hip.hpp"
 #include "k_mlp16.hip.hpp"
 #include "k_sampling16.hip.hpp"
 #include "k_donerf.hip.hpp"

@@ -17,7 +17,7 @@
 // same (band, component), so each PE value is computed exactly once per sample.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ADN_HD __host__ __device__
 #else
 #define ADN_HD

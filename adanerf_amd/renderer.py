@@ -23,6 +23,7 @@ _PREC = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "fp32": PREC_FP
 
 BUF_RAYS, BUF_ORACLE, BUF_RAY_OFFSETS, BUF_RAY_COUNTS, BUF_SAMPLE_KEY, BUF_SAMPLE_W, BUF_RAW, BUF_TOTAL, BUF_SAMPLE_Z = range(9)
 SAMPLER_ADAPTIVE, SAMPLER_PDF = 0, 1
+FLAG_KEEP_ORACLE, FLAG_WAVE_SELECT = 1, 2
 
 
 class AdaNeRFError(RuntimeError):
@@ -33,7 +34,7 @@ class _Options(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("batch_rays", C.c_int32), ("device_id", C.c_int32),
                 ("precision", C.c_int32), ("num_samples", C.c_int32), ("threshold", C.c_float),
                 ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("strip_rows", C.c_int32),
-                ("sampling_mode", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("sampling_mode", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class Info(C.Structure):
@@ -181,7 +182,7 @@ class NeuralRenderer:
 
     def __init__(self, settings: Settings, precision="bf16", device_id: int = 0, num_samples: int = 0,
                  threshold: float = -1.0, shard_rank: int = 0, shard_world: int = 1, strip_rows: int = 8,
-                 sampling: str = "split", lib_path: Optional[str] = None):
+                 sampling: str = "split", lib_path: Optional[str] = None, keep_oracle: bool = False, wave_select: bool = False):
         self.settings = settings
         self.lib = load_library(lib_path)
         self.handle = None
@@ -189,7 +190,8 @@ class NeuralRenderer:
                              device_id=device_id, precision=_PREC[precision] if isinstance(precision, str) else int(precision),
                              num_samples=num_samples, threshold=threshold, shard_rank=shard_rank,
                              shard_world=shard_world, strip_rows=strip_rows,
-                             sampling_mode={"split": 0, "fp16x3": 0, "fp32": 1, "fp16": 2}[sampling])
+                             sampling_mode={"split": 0, "fp16x3": 0, "fp32": 1, "fp16": 2}[sampling],
+                             flags=(FLAG_KEEP_ORACLE if keep_oracle else 0) | (FLAG_WAVE_SELECT if wave_select else 0))
         self.info = Info()
         self.last_stats = Stats()
         self._own = []

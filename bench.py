@@ -164,7 +164,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # ADANERF_BENCH_FORCE_DIST=1 (tests): take the process-group / gather / assemble path even at world size 1, so the
+    # RCCL branch runs on a 1-GPU box exactly as it does on N > 1 (launch under torch.distributed.run --nproc-per-node 1)
+    use_dist = world > 1 or (os.environ.get("ADANERF_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -197,13 +200,13 @@ def main():
     # has enqueued frame k+1.  No host sync anywhere in a step; flush() drains the last frame inside the timed region.
     tstream = torch.cuda.Stream(device=dev)
     r.set_stream(tstream.cuda_stream)
-    n_buf = 2 if world > 1 else 1
+    n_buf = 2 if use_dist else 1
     outs = [torch.zeros((r.info.rays_local_max, 4), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
     out = outs[0]
     rgb = torch.zeros((max(r.info.rays_local, 1), 3), dtype=torch.float32, device=dev)
     gathered = image = cstream = None
     ev_render = ev_gather = None
-    if world > 1:
+    if use_dist:
         cstream = torch.cuda.Stream(device=dev)
         ev_render = [torch.cuda.Event() for _ in range(2)]
         ev_gather = [torch.cuda.Event() for _ in range(2)]
@@ -212,7 +215,7 @@ def main():
             gathered = [torch.zeros((world, r.info.rays_local_max, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
             gather_lists = [list(g.unbind(0)) for g in gathered]
             image = torch.zeros((h * w, 4), dtype=torch.uint8, device=dev)
-    state = {"k": 0, "pending": None}
+    state = {"k": 0, "pending": None, "gathers": 0}
 
     def finish(b):
         # frame in buffer b: its gather is complete -> de-interleave into the image on the render stream
@@ -236,15 +239,16 @@ def main():
         b = state["k"] & (n_buf - 1)
         state["k"] += 1
         with torch.cuda.stream(tstream):
-            if world > 1 and state["k"] > 2:
+            if use_dist and state["k"] > 2:
                 tstream.wait_event(ev_gather[b])            # frame k-2's payload has left this buffer
             r.render(outs[b], rgb)
-            if world > 1:
+            if use_dist:
                 ev_render[b].record(tstream)
-        if world > 1:
+        if use_dist:
             with torch.cuda.stream(cstream):
                 cstream.wait_event(ev_render[b])
                 dist.gather(outs[b], gather_lists[b], dst=0)
+                state["gathers"] += 1
                 ev_gather[b].record(cstream)
             if state["pending"] is not None:
                 finish(state["pending"])
@@ -274,6 +278,11 @@ def main():
     dt = time.perf_counter() - t0
     st, frames = r.collect_stats()
     r.set_profiling(False)
+    exchange = None
+    if dist:
+        exchange = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
+                    "world_size": dist.get_world_size(), "gathers": state["gathers"],
+                    "payload_bytes_per_rank": int(outs[0].numel())}
     if dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -291,7 +300,7 @@ def main():
         shard_samples = shard_shade_ms = None
 
     if rank == 0 and args.dump_image:
-        np.save(args.dump_image, (image if world > 1 else outs[0][:h * w]).cpu().numpy().reshape(h, w, 4))
+        np.save(args.dump_image, (image if use_dist else outs[0][:h * w]).cpu().numpy().reshape(h, w, 4))
 
     ms_per_step = dt / args.steps * 1e3
     fps = args.steps / dt
@@ -384,7 +393,8 @@ def main():
                                       (args.workload, w, h, n_max, thr, args.precision,
                                        {"split": "split-fp16 (3 MFMAs per term)", "fp32": "fp32 MFMA", "fp16": "plain fp16 (opt-in speed mode)"}[args.sampling]),
                           "parallelism": ("image-strip shard x%d (%d-row strips, round-robin) + %s gather overlapped with the next frame" %
-                                          (world, strip_rows, "RCCL" if backend == "nccl" else backend)) if world > 1 else "single GPU",
+                                          (world, strip_rows, "RCCL" if backend == "nccl" else backend)) if use_dist else "single GPU",
+                          "exchange": exchange,
                           "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame,
                           "camera": ("%d-pose orbit inside the view cell" % args.orbit) if poses else "fixed: view-cell centre, yaw 100 deg"},
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,

@@ -82,6 +82,15 @@ enum {
   ADANERF_PREC_FP32 = 2   /* v_mfma_f32_32x32x2_f32 (exact fp32; parity mode) */
 };
 
+/* adanerf_options.flags */
+enum {
+  ADANERF_FLAG_KEEP_ORACLE = 1, /* adanerf_render writes the raw oracle values [batch,128] to ADANERF_BUF_ORACLE and selects from
+                                   there in a separate launch (debug / the reference's data flow); by default the selection runs
+                                   in the sampling kernel's epilogue and that buffer is not written */
+  ADANERF_FLAG_WAVE_SELECT = 2  /* selection by the wave-per-ray kernel (the only one for numRaymarchSamples > 16) even where the
+                                   lane-pair selection applies; implies the separate launch */
+};
+
 typedef struct adanerf_ctx adanerf_ctx;
 
 typedef struct adanerf_options {
@@ -96,7 +105,8 @@ typedef struct adanerf_options {
   int32_t shard_world;      /* number of shards; 1 */
   int32_t strip_rows;       /* rows per strip for round-robin strip sharding; <=0 -> 8 */
   int32_t sampling_mode;    /* ADANERF_SAMPLING_* */
-  int32_t reserved[5];
+  int32_t flags;            /* ADANERF_FLAG_* (0 = defaults) */
+  int32_t reserved[4];
 } adanerf_options;
 
 typedef struct adanerf_info {

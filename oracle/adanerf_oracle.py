@@ -664,6 +664,13 @@ def composite(raw: np.ndarray, sample_w: np.ndarray, ray_offset: np.ndarray, cou
     return rgb
 
 
+def effective_mult(scene: "Scene") -> str:
+    """The kept oracle values reach compositing only under losses[0] == NeRFWeightMultiplicationLoss
+    (src/features.py:503-505 puts them into the feature dict, :517-519 hands them on as ``depth``); otherwise
+    adaptive_raw2outputs sees depth=None and accumulationMult has no effect (src/nerf_raymarch_common.py:123-133)."""
+    return scene.accumulation_mult if scene.losses0 == "NeRFWeightMultiplicationLoss" else ""
+
+
 def oracle_view(orc: np.ndarray) -> np.ndarray:
     """Sampling-network debug view, [n,128] raw outputs -> [n,4] uint8.  Restates the VIEWER kernel samplesToImage
     (adanerf_real_time_viewer/src/cuda/base_cuda_kernels.cu:487-528; the PyTorch path has no counterpart, and the viewer
@@ -737,7 +744,7 @@ def render_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: 
         z = to_world_depth(tt[mask], scene)
         feat1 = shading_inputs(p, nds, sray, z, scene, w, h)
         raw = shading_mlp(feat1, weights.net1, n_pos)
-        rgb = composite(raw, sw, off, count, scene.accumulation_mult)
+        rgb = composite(raw, sw, off, count, effective_mult(scene))
         out_rgb.append(rgb)
         out_cnt.append(count)
         if keep:

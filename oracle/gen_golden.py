@@ -125,7 +125,7 @@ def run_reference(R, tc, dirs, pose, rot, chunk=8192):
         zv = d1[K.nerf_input_feature_z_vals]
         f1 = d1[K.input_feature_batch]
         ow = d1[K.oracle_weights] if K.oracle_weights in d1 else torch.zeros((n, 1))
-        if K.oracle_weights not in d1:   # FromClassifiedDepth: [R*N,4] raw, [R,N] z, no selection
+        if K.oracle_weights not in d1 and K.adaptive_sample_positions not in d1:   # FromClassifiedDepth: [R*N,4] raw, [R,N] z, no selection
             item["count"] = torch.full((n,), zv.shape[1], dtype=torch.int32)
             item["z"] = zv.reshape(-1)
             item["raw"] = raw
@@ -179,7 +179,12 @@ def subset_dirs(w, h, fov, x0, y0, cw, ch, stride=1):
     return np.ascontiguousarray(dirs[y0:y0 + ch * stride:stride, x0:x0 + cw * stride:stride].reshape(-1, 3))
 
 
+ONLY = None
+
+
 def save_case(name, scene, meta, dirs, pose, rot, ref, n_max, weights_tag):
+    if ONLY is not None and name not in ONLY:
+        return
     count = ref["count"].astype(np.int32)
     if scene.sampler == "FromClassifiedDepth":
         bins = np.zeros((count.shape[0], n_max), dtype=np.int16)
@@ -190,6 +195,10 @@ def save_case(name, scene, meta, dirs, pose, rot, ref, n_max, weights_tag):
     else:
         bins = z_to_bins(ref["z_slot"], count, scene, n_max)
         wts = ref["wts_slot"].astype(np.float32)
+        if wts.shape != bins.shape:
+            # losses[0] != NeRFWeightMultiplicationLoss: the sampler's kept oracle values never reach the feature
+            # dict (src/features.py:503); they are the oracle outputs at the kept bins
+            wts = np.where(bins >= 0, np.take_along_axis(ref["orc"], np.maximum(bins, 0).astype(np.int64), axis=1), 0).astype(np.float32)
     m = dict(meta)
     m.update(dict(view_cell_center=list(scene.view_cell_center), view_cell_size=list(scene.view_cell_size),
                   depth_range=list(scene.depth_range), fov=scene.fov, max_depth=scene.max_depth,
@@ -276,7 +285,10 @@ def gen_selection_edge_cases(R):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--timing", action="store_true")
+    ap.add_argument("--only", default=None, help="comma-separated case names: write only these fixtures")
     args = ap.parse_args()
+    global ONLY
+    ONLY = set(args.only.split(",")) if args.only else None
     os.makedirs(GOLD, exist_ok=True)
     R = import_reference()
     torch = R.torch
@@ -288,7 +300,7 @@ def main():
     w_barb = O.load_weights(barber)
 
     # real exported weights travel as data fixtures (the GPU box has no /root/reference)
-    for tag, wts in [("sample_pavillon_16", w_class), ("sample", w_barb)]:
+    for tag, wts in [("sample_pavillon_16", w_class), ("sample", w_barb)] if not args.only else []:
         d = {"n0/" + k: v for k, v in wts.net0.items()}
         d.update({"n1/" + k: v for k, v in wts.net1.items()})
         np.savez_compressed(os.path.join(GOLD, "weights_%s.npz" % tag), **d)
@@ -372,7 +384,20 @@ def main():
     save_case("classroom_pdf_n8", sc, dict(w=800, h=800, crop=[8, 10, 48, 32, 16], yaw=100.0, pitch=0.0),
               dirs, pose, rot, ref, 8, "sample_pavillon_16")
 
-    gen_selection_edge_cases(R)
+    # --- cases H, I, J: the other compositing multipliers (src/nerf_raymarch_common.py:123-133): accumulationMult =
+    #     weights, unset, and alpha under a losses[0] that keeps the oracle values out of compositing (src/features.py:503)
+    for name, mult, l0 in [("classroom_n8_mult_weights", "weights", "NeRFWeightMultiplicationLoss"),
+                           ("classroom_n8_mult_none", "", "NeRFWeightMultiplicationLoss"),
+                           ("classroom_n8_loss_mse", "alpha", "MSE")]:
+        sc = dataclasses.replace(classroom_scene(8, 0.2), accumulation_mult=mult, losses0=l0)
+        dirs = subset_dirs(800, 800, sc.fov, 20, 30, 24, 16, 32)
+        tc = build_reference(R, sc, w_class, 800, 800)
+        ref = run_reference(R, tc, dirs, pose, rot)
+        save_case(name, sc, dict(w=800, h=800, crop=[20, 30, 24, 16, 32], yaw=100.0, pitch=0.0), dirs, pose, rot, ref, 8,
+                  "sample_pavillon_16")
+
+    if not args.only:
+        gen_selection_edge_cases(R)
 
     if args.timing:
         timing = {"host": "build container", "threads": torch.get_num_threads(), "dtype": "fp32",

@@ -47,5 +47,16 @@ def case_weights(meta):
     return O.Weights(n0, n1)
 
 
+def record(name, **values):
+    """Appends one line of measured quantities (PSNR, agreement fractions, ...) to $ADANERF_MEASURED_LOG, if set: the
+    tolerances stated in the tests are kept a margin below what this log shows (profiles/r02_parity_measured.log)."""
+    path = os.environ.get("ADANERF_MEASURED_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(test=name, **{k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in values.items()})) + "\n")
+
+
 CASES = ["classroom_n8_thr02", "classroom_n16_thr015", "classroom_dense128", "barbershop_n4_thr015",
          "synthetic_fixed8", "ndc_synthetic_n8"]
+# the compositing multipliers other than accumulationMult = alpha (src/nerf_raymarch_common.py:123-133, src/features.py:503)
+MULT_CASES = ["classroom_n8_mult_weights", "classroom_n8_mult_none", "classroom_n8_loss_mse"]

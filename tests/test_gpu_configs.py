@@ -1,0 +1,260 @@
+"""GPU tests at the sizes and settings of BASELINE.json's configurations 3, 4 and 5, the compositing multipliers other
+than accumulationMult = alpha, and the RCCL branch of bench.py.  Same conventions as test_gpu_parity.py: the HIP path
+through the C ABI against the oracle on the rows / crops the oracle finishes in seconds, size-independent properties at
+full size.  Run with `pytest -m gpu` on an MI355X box."""
+import dataclasses
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import adanerf_oracle as O
+from conftest import MULT_CASES, ROOT, case_weights, load_case, record
+
+import adanerf_amd
+from adanerf_amd import renderer as R
+from adanerf_amd import sharding
+from test_gpu_parity import golden_samples, model_dir, same_bin_sets, small_frame
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    adanerf_amd.build_library()
+
+
+@pytest.fixture(scope="module")
+def classroom(tmp_path_factory):
+    z, meta, sc = load_case("classroom_n8_thr02")
+    wts = case_weights(meta)
+    return z, meta, sc, wts
+
+
+def _dir(tmp_path_factory, sc, wts, tag):
+    return model_dir(tmp_path_factory, sc, wts, tag)
+
+
+def render_sharded(d, w, h, pose, rot, world, strip_rows, **kw):
+    """Every rank's strips rendered by its own context on this box's one GPU, then adanerf_assemble_strips."""
+    parts, rmax, samples = [], None, []
+    for rank in range(world):
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), shard_rank=rank, shard_world=world, strip_rows=strip_rows, **kw) as r:
+            r.set_camera(pose, rot)
+            _, rgba, st = r.render_numpy()
+            rmax = r.info.rays_local_max
+            assert r.info.rays_local == sharding.rays_local(w, h, strip_rows, world, rank)
+            pad = np.zeros((rmax, 4), np.uint8)
+            pad[:rgba.shape[0]] = rgba
+            parts.append(pad)
+            samples.append(int(st.total_samples))
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), shard_rank=0, shard_world=world, strip_rows=strip_rows, **kw) as r:
+        img = r.empty((w * h, 4), np.uint8)
+        r.assemble_strips(r.to_device(np.concatenate(parts)), img)
+        r.sync()
+        return img.numpy(), samples
+
+
+def check_rows_against_oracle(sc, wts, w, h, pose, rot, rows, cnt, rgb, min_same, min_psnr, tag):
+    for row in rows:
+        ref = O.render_frame(sc, wts, w, h, pose, rot, rows=(row, row + 1))
+        sl = slice(row * w, (row + 1) * w)
+        same = cnt[sl] == ref["count"]
+        p = O.psnr(rgb[sl][same], ref["rgb"][same])
+        err = float(np.abs(rgb[sl][same] - ref["rgb"][same]).max())
+        record(tag, row=row, identical_counts=float(same.mean()), psnr_db=p, max_abs=err)
+        assert same.mean() >= min_same, "row %d: identical sample counts %.5f" % (row, same.mean())
+        assert p > min_psnr, "row %d: PSNR %.2f dB" % (row, p)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 4: 800x800, threshold 0.1, image-tile shard over 8 ranks (balanced 5-row strips)
+# ---------------------------------------------------------------------------------------------
+
+def test_config4_thr01_eight_way_shard(classroom, tmp_path_factory):
+    z, meta, sc, wts = classroom
+    sc4 = dataclasses.replace(sc, threshold=0.1)
+    d = _dir(tmp_path_factory, sc4, wts, "config4")
+    w = h = 800
+    world = 8
+    strip = sharding.balanced_strip_rows(h, world)
+    assert strip == 5
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16") as r:
+        r.set_camera(z["pose"], z["rot"])
+        assert abs(r.info.threshold - 0.1) < 1e-7
+        rgb, full, st = r.render_numpy()
+        cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,))
+    assert cnt.min() >= 1 and cnt.max() <= 8 and st.total_samples == int(cnt.sum())
+    img, samples = render_sharded(d, w, h, z["pose"], z["rot"], world, strip, precision="bf16")
+    assert np.array_equal(img, full)                       # assembled bytes == unsharded frame
+    assert sum(samples) == st.total_samples
+    record("config4_shard", samples_per_rank=samples, imbalance=max(samples) / (sum(samples) / world))
+    assert max(samples) / (sum(samples) / world) < 1.02    # interleaved strips spread the content evenly
+    check_rows_against_oracle(sc4, wts, w, h, z["pose"], z["rot"], (250, 601), cnt, rgb, 0.999, 55.0, "config4_rows")
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 3: 800x800 dense, 128 samples per ray (no compaction; composite_wave_kernel)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def dense(tmp_path_factory):
+    z, meta, sc = load_case("classroom_dense128")
+    wts = case_weights(meta)
+    return z, meta, sc, wts, _dir(tmp_path_factory, sc, wts, "dense")
+
+
+@pytest.mark.parametrize("prec,min_psnr", [("bf16", 56.0), ("fp16", 75.0)])      # measured 61.9 / 80.5 dB
+def test_dense_small_frame_16bit(dense, prec, min_psnr):
+    z, meta, sc, wts, d = dense
+    w, h = 48, 40
+    ref = small_frame(dense, w, h)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision=prec) as r:
+        r.set_camera(z["pose"], z["rot"])
+        rgb, rgba, st = r.render_numpy()
+    assert st.total_samples == w * h * 128
+    p = O.psnr(rgb, ref["rgb"])
+    record("dense_small_frame", prec=prec, psnr_db=p, max_abs=float(np.abs(rgb - ref["rgb"]).max()))
+    assert p > min_psnr, "PSNR %.2f dB" % p
+    assert np.array_equal(rgba[:, :3], O.to_rgba8(rgb)[:, :3])
+
+
+def test_dense_full_size_properties(dense):
+    z, meta, sc, wts, d = dense
+    w = h = 800
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16") as r:
+        r.set_camera(z["pose"], z["rot"])
+        assert r.info.dense == 1
+        rgb, rgba, st = r.render_numpy()
+        cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,))
+        off = r.buffer(R.BUF_RAY_OFFSETS, np.int32, (w * h,))
+        tot = r.buffer(R.BUF_TOTAL, np.int32, (1,))
+    assert st.total_samples == w * h * 128 == int(tot[0]) and (cnt == 128).all()
+    assert np.array_equal(off.astype(np.int64), np.arange(w * h, dtype=np.int64) * 128)
+    assert np.isfinite(rgb).all() and (rgba[:, 3] == 255).all()
+    assert np.array_equal(rgba[:, :3], O.to_rgba8(rgb)[:, :3])
+    for row in (77, 640):
+        ref = O.render_frame(sc, wts, w, h, z["pose"], z["rot"], rows=(row, row + 1))
+        sl = slice(row * w, (row + 1) * w)
+        p = O.psnr(rgb[sl], ref["rgb"])
+        record("dense_full_rows", row=row, psnr_db=p, max_abs=float(np.abs(rgb[sl] - ref["rgb"]).max()))
+        assert p > 55.0, "row %d: PSNR %.2f dB" % (row, p)       # measured 59.3 / 66.2 dB
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5: 1920x1080 LLFF-NDC, fp16 shading, the thresholds the sweep test does not cover + 8-way shard
+# ---------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def ndc(tmp_path_factory):
+    z, meta, sc = load_case("ndc_synthetic_n8")
+    wts = case_weights(meta)
+    return z, meta, sc, wts, _dir(tmp_path_factory, sc, wts, "ndc")
+
+
+@pytest.mark.parametrize("thr", [0.1, 0.3])
+def test_config5_thresholds_01_03(ndc, thr):
+    z, meta, sc, wts, d = ndc
+    w, h = 1920, 1080
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="fp16", threshold=thr) as r:
+        r.set_camera(z["pose"], z["rot"])
+        rgb, rgba, st = r.render_numpy()
+        cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,))
+        off = r.buffer(R.BUF_RAY_OFFSETS, np.int32, (w * h,))
+        assert r.last_stats.sampling_overflow == 0
+    assert cnt.min() >= 1 and cnt.max() <= 8 and st.total_samples == int(cnt.sum())
+    assert np.array_equal(off[1:].astype(np.int64), np.cumsum(cnt.astype(np.int64))[:-1])
+    assert np.isfinite(rgb).all() and np.array_equal(rgba[:, :3], O.to_rgba8(rgb)[:, :3])
+    sct = dataclasses.replace(sc, threshold=thr)
+    check_rows_against_oracle(sct, wts, w, h, z["pose"], z["rot"], (200, 803), cnt, rgb, 0.999, 75.0, "config5_thr%.1f" % thr)   # measured 82.2 - 88.9 dB
+
+
+def test_config5_eight_way_shard_1080p(ndc):
+    z, meta, sc, wts, d = ndc
+    w, h = 1920, 1080
+    world = 8
+    strip = sharding.balanced_strip_rows(h, world)
+    assert strip == 5 and (h // strip) % world == 0
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="fp16", threshold=0.1) as r:
+        r.set_camera(z["pose"], z["rot"])
+        _, full, st = r.render_numpy()
+    img, samples = render_sharded(d, w, h, z["pose"], z["rot"], world, strip, precision="fp16", threshold=0.1)
+    assert np.array_equal(img, full) and sum(samples) == st.total_samples
+    record("config5_shard", samples_per_rank=samples, imbalance=max(samples) / (sum(samples) / world))
+    assert max(samples) / (sum(samples) / world) < 1.02
+
+
+# ---------------------------------------------------------------------------------------------
+# compositing multipliers: accumulationMult = weights / unset, and alpha under a losses[0] that keeps the oracle values
+# out of compositing (reference-generated fixtures)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def mult_cases(tmp_path_factory):
+    out = {}
+    for name in MULT_CASES:
+        z, meta, sc = load_case(name)
+        wts = case_weights(meta)
+        out[name] = (z, meta, sc, wts, _dir(tmp_path_factory, sc, wts, name))
+    return out
+
+
+@pytest.mark.parametrize("name", MULT_CASES)
+def test_composite_multiplier_modes_match_reference(mult_cases, name):
+    z, meta, sc, wts, d = mult_cases[name]
+    count, off, key, sw, sray, sbin = golden_samples(z, sc)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, meta["w"], meta["h"])) as r:
+        n = count.shape[0]
+        rgb = r.empty((n, 3), np.float32)
+        rgba = r.empty((n, 4), np.uint8)
+        r.composite(r.to_device(z["shade_out"]), r.to_device(sw), r.to_device(off), r.to_device(count), n, rgb, rgba)
+        out, out8 = rgb.numpy(), rgba.numpy()
+    np.testing.assert_allclose(out, z["rgb"], rtol=0, atol=2e-6)       # reference output; expf vs torch.sigmoid
+    exp8 = O.to_rgba8(z["rgb"])
+    assert (np.abs(out8.astype(np.int16) - exp8.astype(np.int16)) <= 1).all() and (out8[:, 3] == 255).all()
+
+
+@pytest.mark.parametrize("name", MULT_CASES)
+def test_frame_multiplier_modes_match_oracle(mult_cases, name):
+    z, meta, sc, wts, d = mult_cases[name]
+    w, h = 112, 80
+    ref = small_frame(mult_cases[name], w, h)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="fp32") as r:
+        r.set_camera(z["pose"], z["rot"])
+        rgb, rgba, st = r.render_numpy()
+        cnt, same = same_bin_sets(r, ref, w * h, sc.num_samples)
+    assert same.mean() >= 0.995
+    np.testing.assert_allclose(rgb[same], ref["rgb"][same], rtol=0, atol=3e-4)
+    # the three modes really differ on this frame (a test that cannot tell them apart would be vacuous)
+    other = dataclasses.replace(sc, accumulation_mult="alpha", losses0="NeRFWeightMultiplicationLoss")
+    ref_alpha = O.render_rays(O.generate_ray_directions(w, h, sc.fov), z["pose"], z["rot"], other, wts, w, h)
+    assert np.abs(ref_alpha["rgb"] - ref["rgb"]).max() > 0.05
+
+
+# ---------------------------------------------------------------------------------------------
+# the RCCL branch of bench.py on this box's one GPU: world size 1 under torch.distributed.run, backend nccl
+# ---------------------------------------------------------------------------------------------
+
+def test_bench_rccl_branch_world_size_one(tmp_path):
+    """Process-group init on nccl (= RCCL), dist.gather of the strip payload, assemble_strips: the code path the driver's
+    N > 1 runs take, with nothing swapped out -- only the world size differs."""
+    one, dist1 = str(tmp_path / "one.npy"), str(tmp_path / "dist1.npy")
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-speed-mode"]
+    a = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--dump-image", one] + common, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0, a.stderr[-2000:]
+    env = dict(os.environ, ADANERF_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29741", "bench.py", "--gpus", "1",
+                        "--dump-image", dist1] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-3000:]
+    lines = [ln for ln in b.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, b.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0
+    assert rec["config"]["exchange"]["backend"] == "nccl" and rec["config"]["exchange"]["rccl_ranks"] == 1
+    assert rec["config"]["exchange"]["gathers"] == 3 + 1           # one RCCL gather per frame, warm-up included
+    assert np.array_equal(np.load(one), np.load(dist1))

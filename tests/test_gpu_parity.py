@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import adanerf_oracle as O
-from conftest import CASES, GOLD, case_weights, load_case
+from conftest import CASES, GOLD, case_weights, load_case, record
 
 import adanerf_amd
 from adanerf_amd import renderer as R
@@ -144,17 +144,24 @@ def check_compact(r, orc, n_max, thr, exp=None):
     assert np.array_equal(sw, e_sw)                      # copies of the oracle values: bit-exact
 
 
+# Both selection kernels behind adanerf_compact: the lane-pair selection (k_select_pair.hip.hpp, n_max <= 16; the code that
+# also runs fused into the sampling kernels' epilogue) and the wave-per-ray select_kernel (any n_max).
+BOTH_SELECTS = pytest.mark.parametrize("wave_select", [False, True], ids=["pair", "wave"])
+
+
+@BOTH_SELECTS
 @pytest.mark.parametrize("name", [c for c in CASES if c != "classroom_dense128"])
-def test_compact_on_reference_oracle_values_bit_exact(cases, name):
+def test_compact_on_reference_oracle_values_bit_exact(cases, name, wave_select):
     z, meta, sc, wts, d = cases[name]
-    with make(cases[name]) as r:
+    with make(cases[name], wave_select=wave_select) as r:
         check_compact(r, z["oracle_out"], sc.num_samples, sc.threshold,
                       (z["sel_count"].astype(np.int32), z["sel_bins"], z["sel_weight"]))
 
 
-def test_compact_edge_cases_bit_exact(cases):
+@BOTH_SELECTS
+def test_compact_edge_cases_bit_exact(cases, wave_select):
     z = np.load(os.path.join(GOLD, "selection_edge_cases.npz"))
-    with make(cases["classroom_n8_thr02"]) as r:
+    with make(cases["classroom_n8_thr02"], wave_select=wave_select) as r:
         for n_max in (1, 4, 8, 16, 32):
             k = "n%d" % n_max
             check_compact(r, z[k + "_orc"], n_max, float(z[k + "_thr"]),
@@ -177,16 +184,34 @@ def test_compact_edge_cases_bit_exact(cases):
         assert list(key[:8] & 127) == list(range(8)) and int(key[8] & 127) == 0
         off, cnt, key, sw, total = gpu_compact(r, orc, 4, 0.25)
         assert list(key[off[2]:off[2] + 4] & 127) == [3, 5, 70, 90]
+        # ties at the cut-off everywhere: quantised values (many equal), every n_max, against the oracle's rule
+        # ("lower bin first"); NaN / inf rows: NaN never ranks, an all-NaN row keeps bin 0
+        q = (rng.integers(0, 6, size=(777, 128)) * 0.25 - 0.25).astype(np.float32)
+        for n_max in (1, 2, 3, 4, 5, 8, 11, 16, 32):
+            check_compact(r, q, n_max, 0.5)
+        sp = np.full((6, 128), -1.0, np.float32)
+        sp[0, :] = np.nan
+        sp[1, :] = np.nan
+        sp[1, 77] = -3.0                       # the only number in the row: arg-max
+        sp[2, 10:30] = np.inf                  # 20 x +inf, N = 8 -> bins 10..17
+        sp[3, :] = -np.inf                     # all equal (-inf) -> bin 0
+        sp[4, [0, 127]] = [0.9, 0.9]
+        sp[5, 64] = np.nan
+        sp[5, 3] = 0.75
+        off, cnt, key, sw, total = gpu_compact(r, sp, 8, 0.5)
+        rows = [list(key[off[i]:off[i] + cnt[i]] & 127) for i in range(6)]
+        assert rows == [[0], [77], list(range(10, 18)), [0], [0, 127], [3]], rows
 
 
-def test_compact_large_random_vs_oracle_and_properties(cases):
+@BOTH_SELECTS
+def test_compact_large_random_vs_oracle_and_properties(cases, wave_select):
     """Full-size (800x800 rays) properties + exactness against the numpy oracle on a 60k-ray prefix."""
     rng = np.random.default_rng(11)
     n = 640000
     base = rng.standard_normal((2048, 128)).astype(np.float32) * 0.4 + 0.05
     orc = np.tile(base, (n // 2048 + 1, 1))[:n].copy()
     orc += (np.arange(n, dtype=np.float32)[:, None] % 977) * np.float32(1e-4)
-    with make(cases["classroom_n8_thr02"]) as r:
+    with make(cases["classroom_n8_thr02"], wave_select=wave_select) as r:
         for n_max, thr in [(8, 0.2), (16, 0.1), (3, 0.6)]:
             off, cnt, key, sw, total = gpu_compact(r, orc, n_max, thr)
             assert cnt.min() >= 1 and cnt.max() <= n_max
@@ -256,9 +281,12 @@ def test_shade_features_match_reference(cases, name):
     np.testing.assert_allclose(f, z["shade_in"], rtol=0, atol=1e-3)   # 2^9 band x (<= 2 ulp z difference)
 
 
-# fp32: exact-fp32 MFMA path, raw outputs of trained nets reach |30|; bf16/fp16: operand rounding
-# 2^-9 / 2^-12 relative per layer over 11 layers (measured by the survey: 0.022 / 0.003 max-abs rgb).
-@pytest.mark.parametrize("prec,atol,rtol", [("fp32", 2e-3, 1e-4), ("fp16", 0.06, 0.02), ("bf16", 0.5, 0.1)])
+# fp32: exact-fp32 MFMA path, raw outputs of trained nets reach |30|; bf16/fp16: operand rounding 2^-9 / 2^-12 relative
+# per layer over 11 layers.  Bounds = measured on MI355X (profiles/r02_parity_measured.log) plus a margin: worst case over
+# the six cases  fp32: max|err| 5.6e-4;  fp16: 0.018 beyond 2 % relative, rms 0.0042, sigmoid 0.0056;
+# bf16: 0.23 beyond 10 % relative, rms 0.036, sigmoid 0.058.  A packing / layout error shows up as O(1) errors and an
+# rms two orders of magnitude above these.
+@pytest.mark.parametrize("prec,atol,rtol", [("fp32", 1.2e-3, 1e-4), ("fp16", 0.03, 0.02), ("bf16", 0.3, 0.1)])
 @pytest.mark.parametrize("name", CASES)
 def test_shade_mlp_matches_oracle(cases, name, prec, atol, rtol):
     z, meta, sc, wts, d = cases[name]
@@ -280,11 +308,15 @@ def test_shade_mlp_matches_oracle(cases, name, prec, atol, rtol):
         d_tot2 = r.to_device(np.array([S // 2], dtype=np.int32))
         r.shade_mlp(d_rays, d_key, d_tot2, S, raw2)
         out2 = raw2.numpy()
+    sg, sgr = O.sigmoid(out), O.sigmoid(ref)
+    record("shade_mlp_raw", case=name, prec=prec, max_abs=float(np.abs(out - ref).max()),
+           max_excess_over_rtol=float((np.abs(out - ref) - rtol * np.abs(ref)).max()), max_sigmoid_err=float(np.abs(sg - sgr).max()),
+           rms=float(np.sqrt(np.mean((out - ref) ** 2))))
     np.testing.assert_allclose(out, ref, rtol=rtol, atol=atol)
     assert np.array_equal(out2[:S // 2], out[:S // 2]) and (out2[S // 2:] == 7.0).all()
-    sg, sgr = O.sigmoid(out), O.sigmoid(ref)
-    lim = {"fp32": 1e-4, "fp16": 1.5e-2, "bf16": 1e-1}[prec]
+    lim = {"fp32": 1e-4, "fp16": 1e-2, "bf16": 8e-2}[prec]
     assert np.abs(sg - sgr).max() < lim
+    assert np.sqrt(np.mean((out - ref) ** 2)) < {"fp32": 1e-4, "fp16": 8e-3, "bf16": 6e-2}[prec]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -374,12 +406,12 @@ def test_frame_fp32_matches_oracle(cases, name):
     assert O.psnr(rgb[same], ref["rgb"][same]) > 60.0
 
 
-@pytest.mark.parametrize("prec,min_psnr", [("bf16", 45.0), ("fp16", 60.0)])
+@pytest.mark.parametrize("prec,min_psnr", [("bf16", 55.0), ("fp16", 72.0)])
 @pytest.mark.parametrize("name", ["classroom_n8_thr02", "barbershop_n4_thr015", "ndc_synthetic_n8"])
 def test_frame_low_precision_psnr(cases, name, prec, min_psnr):
-    """Stated tolerance of the 16-bit shading path: PSNR(build, oracle) -- the survey's target is
-    >= 50 dB for <= 0.1 dB PSNR-vs-ground-truth loss at ~30 dB scene PSNR; measured values are
-    reported by bench.py."""
+    """Stated tolerance of the 16-bit shading path: PSNR(build, oracle) -- the survey's target is >= 50 dB for
+    <= 0.1 dB PSNR-vs-ground-truth loss at ~30 dB scene PSNR.  Measured (profiles/r02_parity_measured.log): bf16
+    58.4 / 60.3 / 67.5 dB, fp16 76.7 / 77.9 / 84.5 dB on the three cases; the bounds sit ~3-5 dB below the worst."""
     z, meta, sc, wts, d = cases[name]
     w, h = 160, 120
     ref = small_frame(cases[name], w, h)
@@ -389,6 +421,8 @@ def test_frame_low_precision_psnr(cases, name, prec, min_psnr):
         cnt, same = same_bin_sets(r, ref, w * h, sc.num_samples)
     assert same.mean() >= 0.995            # selection runs in exact fp32 regardless of the shading precision
     p = O.psnr(rgb[same], ref["rgb"][same])
+    record("frame_low_precision", case=name, prec=prec, psnr_db=p, max_abs=float(np.abs(rgb[same] - ref["rgb"][same]).max()),
+           identical_bin_sets=float(same.mean()))
     assert p > min_psnr, "PSNR %.2f dB" % p
 
 
@@ -404,6 +438,43 @@ def test_batched_render_equals_single_batch(cases):
     for rgb, rgba, ts, nb in outs[1:]:
         assert np.array_equal(rgb, outs[0][0]) and np.array_equal(rgba, outs[0][1]) and ts == outs[0][2]
     assert [o[3] for o in outs] == [1, 7, 2, 167]
+
+
+@pytest.mark.parametrize("sampling", ["split", "fp16"])
+@pytest.mark.parametrize("name,w,h,bs", [("classroom_n8_thr02", 200, 160, -1), ("classroom_n8_thr02", 97, 61, 1000),
+                                         ("classroom_n16_thr015", 160, 120, -1), ("barbershop_n4_thr015", 131, 77, 4096),
+                                         ("ndc_synthetic_n8", 192, 108, -1), ("synthetic_fixed8", 64, 64, 37)])
+def test_fused_selection_equals_separate_launches(cases, name, w, h, bs, sampling):
+    """adanerf_render selects in the sampling kernel's epilogue by default (the [R,128] oracle values never reach HBM).
+    With ADANERF_FLAG_KEEP_ORACLE the oracle buffer is written and the same lane-pair code runs as its own launch;
+    with ADANERF_FLAG_WAVE_SELECT the wave-per-ray kernel selects.  All three must agree bit for bit on every
+    intermediate (counts, offsets, keys, kept oracle values) and on the image; the kept oracle buffer must be what
+    adanerf_sample_mlp returns."""
+    z, meta, sc, wts, d = cases[name]
+    res = []
+    for kw in (dict(), dict(keep_oracle=True), dict(wave_select=True)):
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=bs), precision="bf16", sampling=sampling, **kw) as r:
+            r.set_camera(z["pose"], z["rot"])
+            rgb, rgba, st = r.render_numpy()
+            nb = r.info.batch_rays
+            last = (w * h) - ((w * h - 1) // nb) * nb                   # rays of the last batch (what the buffers hold)
+            cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (last,))
+            off = r.buffer(R.BUF_RAY_OFFSETS, np.int32, (last,))
+            tot = int(r.buffer(R.BUF_TOTAL, np.int32, (1,))[0])
+            key = r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (tot,))
+            sw = r.buffer(R.BUF_SAMPLE_W, np.float32, (tot,))
+            assert st.sampling_overflow == 0
+            res.append((rgb, rgba, int(st.total_samples), cnt, off, tot, key, sw))
+            if kw.get("keep_oracle"):
+                orc = r.buffer(R.BUF_ORACLE, np.float32, (last, 128))
+                ref_orc = r.empty((last, 128), np.float32)
+                r.sample_mlp(w * h - last, last, ref_orc, None)
+                assert np.array_equal(orc, ref_orc.numpy())
+                e_cnt, e_bins, e_w = O.select_adaptive(orc, sc.num_samples, sc.threshold)   # and the rule itself, on these values
+                assert np.array_equal(cnt, e_cnt) and np.array_equal(sw, O.compact(e_cnt, e_bins, e_w)[3])
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a, b)
 
 
 def test_render_is_deterministic(cases):
@@ -462,8 +533,10 @@ def test_full_size_frame_properties(cases):
         ref = O.render_frame(sc, wts, w, h, z["pose"], z["rot"], rows=(row, row + 1))
         sl = slice(row * w, (row + 1) * w)
         same = cnt[sl] == ref["count"]
-        assert same.mean() >= 0.99
-        assert O.psnr(rgb[sl][same], ref["rgb"][same]) > 45.0
+        record("full_size_rows_config2", row=row, identical_counts=float(same.mean()), psnr_db=O.psnr(rgb[sl][same], ref["rgb"][same]),
+               max_abs=float(np.abs(rgb[sl][same] - ref["rgb"][same]).max()))
+        assert same.mean() >= 0.999                                   # measured 1.0 on both rows
+        assert O.psnr(rgb[sl][same], ref["rgb"][same]) > 55.0        # measured 60.1 / 62.3 dB
 
 
 def test_errors_are_reported_not_thrown(cases):
@@ -507,8 +580,9 @@ def test_ndc_1080p_threshold_sweep_properties(cases):
         ref = O.render_frame(sct, wts, w, h, z["pose"], z["rot"], rows=(row, row + 1))
         sl = slice(row * w, (row + 1) * w)
         same = cnt[sl] == ref["count"]
-        assert same.mean() >= 0.99
-        assert O.psnr(rgb[sl][same], ref["rgb"][same]) > 55.0
+        record("ndc_1080p_sweep", thr=thr, identical_counts=float(same.mean()), psnr_db=O.psnr(rgb[sl][same], ref["rgb"][same]))
+        assert same.mean() >= 0.999                                   # measured 1.0 at every threshold
+        assert O.psnr(rgb[sl][same], ref["rgb"][same]) > 78.0        # measured 83.6 - 88.1 dB (fp16 shading)
 
 
 def test_headless_cli_matches_library(cases, tmp_path):
@@ -562,13 +636,22 @@ def test_ragged_frame_sizes(cases, w, h, bs):
     with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=bs), precision="fp32") as r:
         r.set_camera(z["pose"], z["rot"])
         rgb, rgba, st = r.render_numpy()
-    assert st.total_samples == int(ref["count"].sum()) or abs(st.total_samples - int(ref["count"].sum())) <= 2
-    assert O.psnr(rgb, ref["rgb"]) > 45.0
-    np.testing.assert_allclose(rgb, ref["rgb"], rtol=0, atol=0.05)
+    record("ragged_fp32", w=w, h=h, bs=bs, sample_diff=int(st.total_samples) - int(ref["count"].sum()), psnr_db=O.psnr(rgb, ref["rgb"]),
+           max_abs=float(np.abs(rgb - ref["rgb"]).max()))
+    # measured: identical sample totals, 115-149 dB, max |err| 4e-5.  A ray whose N-th / (N+1)-th oracle values differ by
+    # less than the summation-order noise of two fp32 GEMMs may flip (SURVEY "Hard parts"): allow two such rays
+    flips = abs(int(st.total_samples) - int(ref["count"].sum()))
+    assert flips <= 2
+    if flips == 0:
+        assert O.psnr(rgb, ref["rgb"]) > 100.0
+        np.testing.assert_allclose(rgb, ref["rgb"], rtol=0, atol=2e-4)
+    else:
+        assert O.psnr(rgb, ref["rgb"]) > 45.0
     with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=bs), precision="bf16") as r:
         r.set_camera(z["pose"], z["rot"])
         rgb2, _, st2 = r.render_numpy()
-    assert st2.total_samples == st.total_samples and O.psnr(rgb2, rgb) > 40.0
+    record("ragged_bf16_vs_fp32", w=w, h=h, bs=bs, psnr_db=O.psnr(rgb2, rgb))
+    assert st2.total_samples == st.total_samples and O.psnr(rgb2, rgb) > 55.0      # measured 60.5 - 74.7 dB
 
 
 def test_shard_with_no_rows_renders_nothing(cases):

@@ -400,3 +400,49 @@ print("OK", sorted(codes.items()))
     out = subprocess.run([sys.executable, "-c", script, root, d, str(tmp_path / "work")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.startswith("OK"), (out.returncode, out.stdout[-500:], out.stderr[-2000:])
     assert "(-2," in out.stdout or ", -2)" in out.stdout      # corruption was actually detected in some cases
+
+
+REF_SAMPLE_DIRS = {"sample_pavillon_16": "/root/reference/adanerf_real_time_viewer/sample_pavillon_16",
+                   "sample": "/root/reference/adanerf_real_time_viewer/sample"}
+
+
+@pytest.mark.skipif(not all(os.path.isdir(p) for p in REF_SAMPLE_DIRS.values()),
+                    reason="the reference's shipped model directories exist in the build container only")
+@pytest.mark.parametrize("tag", sorted(REF_SAMPLE_DIRS))
+def test_cxx_loader_reads_the_reference_sample_dirs(lib, tmp_path, tag):
+    """The drop-in claim at the file level: the C++ loader (format.cpp) is fed the reference's OWN exported model
+    directories -- config.ini as src/export.py wrote it (the 71-line training form for `sample`, the trimmed 19-key form
+    for `sample_pavillon_16`), dataset_info.txt, and the two torch.onnx.export files (Slice/Split/Gemm/Relu/Concat
+    graphs, opset 9) -- and must (a) parse them to the scalars the oracle's independent reader finds, (b) pack every
+    network / precision to exactly the bytes it packs from this repo's re-encoded weight fixture of the same model
+    (tests/golden/weights_<tag>.npz written back through the minimal ONNX writer)."""
+    src = REF_SAMPLE_DIRS[tag]
+    lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+    info = R.Info()
+    o = _opts(width=800, height=800)
+    assert lib.adanerf_host_parse_model(src.encode(), C.byref(o), C.byref(info)) == 0, lib.adanerf_last_error(None)
+    sc = O.load_scene(src + "/")
+    assert info.num_samples == sc.num_samples and abs(info.threshold - sc.threshold) < 1e-7
+    assert (info.n_in0, info.n_in1, info.use_ndc, info.dense) == (sc.n_in0, sc.n_in1, int(sc.use_ndc), 0)
+    assert abs(info.fov - sc.fov) < 1e-6 and abs(info.max_depth - sc.max_depth) < 1e-5
+    assert np.allclose([info.depth_range[0], info.depth_range[1]], sc.depth_range, rtol=1e-6)
+    assert np.allclose(list(info.view_cell_center), sc.view_cell_center, rtol=1e-6)
+    assert abs(info.view_cell_radius - sc.radius) < 1e-6
+    assert info.sampler_mode == R.SAMPLER_ADAPTIVE
+    # trailing separator optional (the viewer's CLI passes "model/")
+    assert lib.adanerf_host_parse_model((src + "/").encode(), C.byref(o), C.byref(info)) == 0
+    # the same weights through this repo's writer
+    z = np.load(os.path.join(ROOT, "tests", "golden", "weights_%s.npz" % tag))
+    wts = O.Weights({k[3:]: z[k] for k in z.files if k.startswith("n0/")}, {k[3:]: z[k] for k in z.files if k.startswith("n1/")})
+    d, _, _ = _model_dir(tmp_path, sc, wts, name="re_" + tag)
+    for net, precs in ((0, (2, 3, 1)), (1, (0, 1, 2))):
+        for prec in precs:
+            a = pack_weights(lib, src, net, prec)
+            b = pack_weights(lib, d, net, prec)
+            for x, y in zip(a, b):
+                assert x.dtype == y.dtype and np.array_equal(x, y), (tag, net, prec)
+    # depth table from the shipped dataset_info.txt
+    lib.adanerf_host_depth_table.argtypes = [C.c_char_p, C.POINTER(R._Options), C.c_void_p]
+    zt = np.zeros(128, dtype=np.float32)
+    assert lib.adanerf_host_depth_table(src.encode(), C.byref(o), zt.ctypes.data) == 0
+    np.testing.assert_allclose(zt, O.to_world_depth(O.bin_t(np.arange(128)), sc), rtol=3e-7, atol=1e-6)
