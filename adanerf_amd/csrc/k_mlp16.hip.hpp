@@ -120,6 +120,7 @@ struct WStream {
   uint32_t lds_base;     // LDS byte address of the ring
   uint32_t grp;          // 0: this wave synchronises at chunk position 0, 1: at position CF / 2 (see ws_sync)
   uint32_t issuer;       // this wave issues LDS-DMA pieces (all waves, or one group only: ADN_DMA_GRP)
+  bool stag;             // the workgroup runs its two wave groups half a chunk apart (compile-time constant per kernel)
   u32x4 R[NR];           // register ring: fragment p (position inside the chunk) lives in R[p % NR]
 };
 
@@ -156,11 +157,17 @@ __device__ __forceinline__ void ws_issue(WStream<CF, RS, LPW, NR>& st, uint32_t 
 // one of them is issuing MFMAs while the other is in its bias-read / epilogue / DMA-issue phase, instead of both hitting
 // those phases in the same cycles (a workgroup barrier per chunk otherwise keeps all eight waves in lockstep).  Both
 // groups see the same guarantees: a wave of group 1 is at most half a chunk ahead, i.e. still inside chunk k.
+// see ws_position
+#ifndef ADN_PAD
+#define ADN_PAD 11   // s_nop argument: wait states - 1 on the short side of a branch that follows a tile's last MFMA
+#endif
+__device__ __forceinline__ void ws_skip_pad() { asm volatile("s_nop %0" ::"n"(ADN_PAD) : "memory"); }
+
 #ifndef ADN_STAG_DBG
 #define ADN_STAG_DBG 0   // hazard-hunting variants of the group-1 synchronisation (tools/ablate.sh); 0 in the shipped build
 #endif
 template <int ABL, int CF, int RS, int LPW, int NR>
-__device__ __forceinline__ void ws_sync(WStream<CF, RS, LPW, NR>& st) {
+__device__ __forceinline__ void ws_sync(WStream<CF, RS, LPW, NR>& st, bool pad) {
   static_assert(RS >= 3 && (RS - 2) * LPW < 64, "vmcnt is a 6-bit counter");
   if (ABL & 1) return;
   if (!(ABL & 32)) {
@@ -171,7 +178,10 @@ __device__ __forceinline__ void ws_sync(WStream<CF, RS, LPW, NR>& st) {
   }
   // slot of chunk k-1: group 0 is still "in" it (ws_advance follows), group 1 has moved on to chunk k
   const uint32_t slot = (st.grp == 0) ? st.slot_cur : (st.slot_cur == 0 ? RS - 1 : st.slot_cur - 1);
-  if (!(ABL & 16) && st.issuer) ws_issue(st, slot);                                                                      // 16: no DMA
+  if (!(ABL & 16)) {                                                                                                      // 16: no DMA
+    if (st.issuer) ws_issue(st, slot);
+    else if (pad) ws_skip_pad();      // a barrier that releases at once is not 11 wait states
+  }
 }
 
 // the wave moves from chunk k-1 to chunk k: rotate the LDS read addresses
@@ -184,16 +194,29 @@ __device__ __forceinline__ void ws_advance(WStream<CF, RS, LPW, NR>& st) {
 }
 
 // fragment position f (compile-time) of the stream is about to be consumed
+// The group that has no synchronisation point at this position jumps over it -- the only branches inside the MFMA stream.
+// ws_skip_pad(): the MFMA -> VALU read-after-write distance (11 wait states for these 8-pass MFMAs) is inserted by the
+// compiler, and on the short side of such a branch it came out too small (7 wait states between the last MFMA of a
+// tile and the first v_cvt_pk of its epilogue, hipcc / ROCm 7.2 with -amdgpu-mfma-vgpr-form: the epilogue then read
+// accumulator rows the last MFMA had not written yet -- wrong rgb for waves 4-7 in the variants of
+// profiles/r02_stagger_hazard.md).  16 explicit wait states on the short side make the distance independent of what the
+// scheduler puts after the join.
+
+// tile_start: the instruction stream in front of this position ends with the last MFMA of an output tile (whose epilogue
+// the compiler may have moved behind the branch); mid-tile, the next consumer of the accumulator is the next MFMA of the chain.
 template <int ABL, int CF, int RS, int LPW, int NR>
-__device__ __forceinline__ void ws_position(WStream<CF, RS, LPW, NR>& st, int f) {
+__device__ __forceinline__ void ws_position(WStream<CF, RS, LPW, NR>& st, int f, bool tile_start) {
+  const bool pad = ADN_STAG_DBG != 8 && (tile_start || ADN_STAG_DBG == 9);
   if (f == 0) {
     if (ABL & 1) return;
-    if (st.grp == 0) ws_sync<ABL>(st);
+    if (st.grp == 0) ws_sync<ABL>(st, pad);
     else if (ADN_STAG_DBG == 4) asm volatile("s_barrier" ::: "memory");
+    else if (pad) ws_skip_pad();
     ws_advance(st);
-  } else if (f == CF / 2) {
-    if (st.grp != 0) ws_sync<ABL>(st);
+  } else if (f == CF / 2 && st.stag) {
+    if (st.grp != 0) ws_sync<ABL>(st, pad);
     else if (ADN_STAG_DBG == 4) asm volatile("s_barrier" ::: "memory");
+    else if (pad) ws_skip_pad();
   }
 }
 
@@ -211,8 +234,10 @@ __device__ __forceinline__ void ws_refill(WStream<CF, RS, LPW, NR>& st, int p) {
 
 template <int CF, int RS, int LPW, int NR>
 __device__ __forceinline__ void ws_start(WStream<CF, RS, LPW, NR>& st, const void* gbase, uint32_t gbytes, char* lds, int wave, int lane,
-                                         uint32_t grp = 0, bool issuer = true) {
-  st.grp = grp;
+                                         int grp = -1, bool issuer = true) {
+  // wave: which pieces of a chunk this wave DMA-copies; grp: -1 = the workgroup is not staggered, else the wave's group (0 / 1)
+  st.stag = grp >= 0;
+  st.grp = grp > 0 ? 1u : 0u;
   st.issuer = issuer;
   st.gbase = reinterpret_cast<const char*>(gbase);
   st.gbytes = gbytes;
@@ -333,7 +358,7 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int f = (FPOS + m * KS + s) % CF;     // position inside the chunk; compile-time after unrolling
-      ws_position<ADN_ABLATE>(st, f);
+      ws_position<ADN_ABLATE>(st, f, s == 0);
       const uint32_t* src = (s < S1) ? (in1 + 4 * s) : (in2 + 4 * (s - S1));
       u32x4 b = {src[0], src[1], src[2], src[3]};
       acc = ET::mfma(st.R[f % WS::kRegs], b, acc);
@@ -435,7 +460,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
   __syncthreads();
   WS st;
   ws_start(st, a.net.w, kShadeFrags16 * 1024, lds, kOneGroupDma ? (wave & 3) : (ADN_STAG_DBG == 7 ? (wave ^ 4) : wave), lane,
-           (ADN_STAGGER && WAVES == 8) ? static_cast<uint32_t>(wave >> 2) : 0u, !kOneGroupDma || (wave >> 2) == ADN_DMA_GRP);
+           (ADN_STAGGER && WAVES == 8) ? (wave >> 2) : -1, !kOneGroupDma || (wave >> 2) == ADN_DMA_GRP);
 
   // LDS byte address of the bias blocks of this lane-half
   const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;

@@ -68,7 +68,7 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int f = (FPOS + 2 * (m * KS + s)) % ADN_CF_S;   // compile-time after unrolling; always even
-      ws_position<ADN_ABLATE_S>(st, f);
+      ws_position<ADN_ABLATE_S>(st, f, s == 0);
       const u32x4 bh = {in_hi[4 * s], in_hi[4 * s + 1], in_hi[4 * s + 2], in_hi[4 * s + 3]};
       const u32x4 bl = {in_lo[4 * s], in_lo[4 * s + 1], in_lo[4 * s + 2], in_lo[4 * s + 3]};
       acc = Fp16::mfma(st.R[f % WS::kRegs], bh, acc);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
   }
   __syncthreads();
   WS st;
-  ws_start(st, a.net16.w, FRAGS * 1024, lds, kOneGroupDma ? (wave & 3) : wave, lane, ADN_STAGGER ? static_cast<uint32_t>(wave >> 2) : 0u,
+  ws_start(st, a.net16.w, FRAGS * 1024, lds, kOneGroupDma ? (wave & 3) : wave, lane, ADN_STAGGER ? (wave >> 2) : -1,
            !kOneGroupDma || (wave >> 2) == ADN_DMA_GRP);
   const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
   const uint32_t* bo = a.net16.b_off;

@@ -39,3 +39,10 @@ for S in (6000, key.shape[0]):
                 idx = np.nonzero(bad)[0]
                 waves = sorted(set((int(i) // 256, (int(i) % 256) // 32) for i in idx))
                 print("S=%d %s run %d: %d wrong samples; (tile, wave): %s" % (S, prec, it, idx.size, waves[:40]))
+                if it == 0 and S == 6000:
+                    err = np.abs(out - ref)
+                    w47 = ((np.arange(S) % 256) // 32) >= 4
+                    print("   rms err waves 0-3: %.5f  waves 4-7: %.5f; per channel (4-7): %s" %
+                          (np.sqrt((err[~w47] ** 2).mean()), np.sqrt((err[w47] ** 2).mean()), np.sqrt((err[w47] ** 2).mean(0)).round(5)))
+                    print("   lanes (sample %% 32) of wrong samples:", np.bincount(idx % 32, minlength=32).tolist())
+                    print("   first wrong samples:", [(int(i), out[i].round(3).tolist(), ref[i].round(3).tolist()) for i in idx[:4]])
