@@ -21,6 +21,19 @@ HIPCC_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off
 TU_FLAGS = {"adanerf_hip.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
+def source_hash():
+    """sha1 over the library's sources (csrc + the ABI header): stamps profiles so that bench.py can tell a PMC summary
+    taken with other kernels from a current one."""
+    import hashlib
+    h = hashlib.sha1()
+    for d in sorted(LIB_DEPS):
+        path = os.path.join(CSRC, d)
+        if os.path.exists(path):
+            h.update(d.encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def library_path():
     return os.path.join(LIBDIR, "libadanerf_hip.so")
 

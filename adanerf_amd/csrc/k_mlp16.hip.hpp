@@ -458,6 +458,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
     for (int i = threadIdx.x; i < kShadeBiasFloats; i += blockDim.x) lds_bias[i] = a.net.bias[i];
   }
   __syncthreads();
+#ifndef ADN_PRIO
+#define ADN_PRIO 0   // 1 / 2: static s_setprio 1 for waves 4-7 / 0-3 (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
+  if (ADN_PRIO == 1 && (wave >> 2) == 1) __builtin_amdgcn_s_setprio(1);
+  if (ADN_PRIO == 2 && (wave >> 2) == 0) __builtin_amdgcn_s_setprio(1);
   WS st;
   ws_start(st, a.net.w, kShadeFrags16 * 1024, lds, kOneGroupDma ? (wave & 3) : (ADN_STAG_DBG == 7 ? (wave ^ 4) : wave), lane,
            (ADN_STAGGER && WAVES == 8) ? (wave >> 2) : -1, !kOneGroupDma || (wave >> 2) == ADN_DMA_GRP);

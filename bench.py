@@ -70,57 +70,58 @@ def build_model_dir(td, tag, n, thr):
     return scene, data
 
 
-def cpu_baseline(model_dir, w, h, pose, rot, budget_s=15.0):
-    """The oracle (numpy port of the reference's PyTorch path, validated against the golden vectors)
-    timed on this box's host cores over a bounded band of image rows of the same frame.  This leg (and the
-    quality check that reuses its output) is the ONLY place bench.py touches oracle/."""
+def cpu_baseline(model_dir, w, h, pose, rot, budget_s=10.0):
+    """The oracle (numpy port of the reference's PyTorch path with torch's CPU GEMM, validated against the golden vectors)
+    timed on this box's host cores: P worker processes x T threads, each rendering its own band of rows of the same frame
+    AT THE SAME TIME (oracle/cpu_worker.py), i.e. one parallel CPU render of (a bounded part of) the frame.  The reference's
+    own CPU path is one PyTorch process; on many-core hosts a single process leaves most cores idle in the element-wise
+    stages (encodings, sort), so the port is run the way a CPU deployment would run it.  `cores` = P x T threads actually
+    computing.  This leg (and the quality check that reuses its output) is the ONLY place bench.py touches oracle/."""
+    import shutil
+    import subprocess
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import adanerf_oracle as O
-    sc = O.load_scene(model_dir)
-    wts = O.load_weights(model_dir)
-    backend = "numpy"
-    try:                                       # pick the faster fp32 GEMM on this host (the reference's CPU path is PyTorch)
-        import numpy as np
-        import torch
-        torch.set_num_threads(os.cpu_count() or 1)
-        xs = np.random.rand(32768, 256).astype(np.float32)
-        ws = np.random.rand(256, 256).astype(np.float32)
-        bs = np.zeros(256, np.float32)
-        best = {}
-        for be in ("numpy", "torch"):
-            O.set_matmul_backend(be)
-            ts = []
-            for _ in range(4):
-                t0 = time.time()
-                O._linear(xs, ws, bs)
-                ts.append(time.time() - t0)
-            best[be] = min(ts[1:])
-        if best["torch"] < best["numpy"]:
-            backend = "numpy + torch CPU GEMM"
-        O.set_matmul_backend("torch" if backend != "numpy" else "numpy")
+    try:
+        avail = len(os.sched_getaffinity(0))
     except Exception:
-        O.set_matmul_backend("numpy")
-    cores = os.cpu_count() or 1
-    if backend == "numpy":
-        try:
-            from threadpoolctl import threadpool_info
-            cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-        except Exception:
-            pass
-    CH = 65536
-    r0 = h // 2
-    O.render_frame(sc, wts, w, h, pose, rot, chunk=CH, rows=(r0, r0 + 2))     # warm up thread pools
-    t0 = time.time()
-    O.render_frame(sc, wts, w, h, pose, rot, chunk=CH, rows=(r0, r0 + 2))
-    probe = max(time.time() - t0, 1e-3)
-    rows = int(max(2, min(h // 4, (budget_s / probe) * 2)))
-    t0 = time.time()
-    res = O.render_frame(sc, wts, w, h, pose, rot, chunk=CH, rows=(r0 - rows // 2, r0 - rows // 2 + rows))
-    dt = time.time() - t0
-    fps = 1.0 / (dt * h / rows)
-    return {"value": fps, "unit": "frames/s", "cores": int(cores), "kind": "port",
-            "sample": "%d of %d image rows (%d rays, %.2f samples/ray) of the same frame, %s fp32, chunk %d, %.1f s" %
-                      (rows, h, rows * w, float(res["count"].mean()), backend, CH, dt)}, res, (r0 - rows // 2, rows), O.psnr
+        avail = os.cpu_count() or 1
+    T = 4 if avail >= 8 else max(1, avail // 2)
+    P = max(1, min(avail // T, 64, h // 2))
+    band = h // P
+    sync = tempfile.mkdtemp(prefix="adanerf_cpu_")
+    cam = os.path.join(sync, "cam.npy")
+    np.save(cam, np.concatenate([np.asarray(pose, np.float32).reshape(3), np.asarray(rot, np.float32).reshape(9)]))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "oracle"), os.environ.get("PYTHONPATH", "")]))
+    procs = []
+    for i in range(P):
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), model_dir, str(w), str(h),
+                                       str(i * band), str(band), str(T), str(budget_s), sync, str(i), cam], env=env,
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.PIPE))
+    t_wait = time.time()
+    while sum(os.path.exists(os.path.join(sync, "ready.%d" % i)) for i in range(P)) < P:
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() - t_wait > 600:
+            err = b"".join(p.stderr.read() for p in procs if p.poll() not in (None, 0))
+            for p in procs:
+                p.kill()
+            raise RuntimeError("cpu_baseline worker failed: %s" % err[-2000:].decode(errors="replace"))
+        time.sleep(0.05)
+    open(os.path.join(sync, "go"), "w").close()
+    for p in procs:
+        p.wait()
+    outs = [np.load(os.path.join(sync, "out.%d.npz" % i)) for i in range(P)]
+    rows_done = int(sum(int(o["rows_done"]) for o in outs))
+    wall = max(float(o["seconds"]) for o in outs)
+    fps = (rows_done / float(h)) / wall
+    mid = outs[P // 2]                                   # the band the quality check compares against the GPU frame
+    res = {"rgb": mid["rgb"], "count": mid["count"]}
+    row0, rows = int(mid["row0"]), int(mid["rows_done"])
+    spp = float(np.mean(np.concatenate([o["count"] for o in outs])))
+    backend = str(outs[0]["backend"])
+    shutil.rmtree(sync, ignore_errors=True)
+    return {"value": fps, "unit": "frames/s", "cores": int(P * T), "kind": "port",
+            "sample": "%d of %d image rows (%d rays, %.2f samples/ray) of the same frame in %.1f s: %d processes x %d threads, "
+                      "numpy + %s fp32, %d host cores available" % (rows_done, h, rows_done * w, spp, wall, P, T, backend, avail)}, \
+        res, (row0, rows), O.psnr
 
 
 def main():
@@ -136,7 +137,7 @@ def main():
                     help="sampling-MLP arithmetic: split-fp16 (default, fp32-accurate), exact fp32, or the opt-in plain fp16 speed mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-speed-mode", action="store_true", help="skip the extra fp16-sampling measurement reported under speed_mode")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of wall time the CPU baseline may compute (all its cores busy)")
     ap.add_argument("--orbit", type=int, default=0,
                     help="K > 0: step i renders pose i %% K of a K-pose orbit inside the view cell (yaw and position vary) instead of "
                          "the fixed camera; quality / cpu_baseline still refer to pose 0")
@@ -317,14 +318,22 @@ def main():
         achieved = flop_per_launch / (shade_ms * 1e-3) / 1e12 if shade_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
         kname = "shade_mlp%s_kernel" % ("32" if args.precision == "fp32" else "16")
-        # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes of this same
-        # workload (tools/collect_profiles.sh -> profiles/; PMC cannot be read from inside this process)
+        # HBM bytes per launch of this kernel: PMC counters cannot be read from inside this process, so they come from the
+        # committed rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh -> profiles/).  A summary is used
+        # only if it was taken with the very sources this library is built from (source_hash), else traffic is null.
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary_%s.json" % args.workload)
-        if os.path.exists(pmc_path) and world == 1 and args.precision == "bf16" and r.info.batch_rays >= r.info.rays_local:
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary_%s.json" % args.workload)
+        if os.path.exists(pmc_path) and world == 1 and r.info.batch_rays >= r.info.rays_local:
             try:
-                traffic = json.load(open(pmc_path)).get(kname, {}).get("hbm_bytes_per_launch")
-                traffic_src = os.path.relpath(pmc_path, ROOT)
+                pmc = json.load(open(pmc_path))
+                meta = pmc.get("_meta", {})
+                want = "--precision %s" % args.precision if args.precision != "bf16" else ""
+                if meta.get("source_hash") == B.source_hash() and (want in meta.get("bench_args", "")) and \
+                        ("--threshold" in meta.get("bench_args", "")) == (args.threshold is not None):
+                    traffic = pmc.get(kname, {}).get("hbm_bytes_per_launch")
+                    traffic_src = os.path.relpath(pmc_path, ROOT)
+                else:
+                    traffic_src = "stale: %s was collected with other sources / arguments" % os.path.relpath(pmc_path, ROOT)
             except Exception:
                 traffic = None
         roofline = {"bound": "mfma", "kernel": kname,

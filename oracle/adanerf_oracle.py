@@ -456,8 +456,10 @@ def _linear(x, w, b):
 
 def sampling_mlp(x: np.ndarray, net0: Dict[str, np.ndarray]) -> np.ndarray:
     """src/models.py:183-195 (BaseNet.forward, no skips): 7x(Linear+ReLU) + Linear; raw output."""
-    h = x.astype(F32)
     n = len([k for k in net0 if k.endswith(".weight")])
+    if _MATMUL == "torch":
+        return _torch_sampling_mlp(x, net0, n)
+    h = x.astype(F32)
     for i in range(n):
         h = _linear(h, net0["layers.%d.weight" % i], net0["layers.%d.bias" % i])
         if i + 1 < n:
@@ -467,6 +469,8 @@ def sampling_mlp(x: np.ndarray, net0: Dict[str, np.ndarray]) -> np.ndarray:
 
 def shading_mlp(x: np.ndarray, net1: Dict[str, np.ndarray], n_pos: int = 63) -> np.ndarray:
     """src/models.py:254-277 (NeRF.forward, skips=[4], use_viewdirs=True) -> [rgb(3), alpha(1)] raw."""
+    if _MATMUL == "torch":
+        return _torch_shading_mlp(x, net1, n_pos)
     x = x.astype(F32)
     pts, views = x[:, :n_pos], x[:, n_pos:]
     h = pts
@@ -480,6 +484,43 @@ def shading_mlp(x: np.ndarray, net1: Dict[str, np.ndarray], n_pos: int = 63) -> 
     h = np.maximum(_linear(h, net1["views_linears.0.weight"], net1["views_linears.0.bias"]), F32(0))
     rgb = _linear(h, net1["rgb_linear.weight"], net1["rgb_linear.bias"])
     return np.concatenate([rgb, alpha], axis=-1).astype(F32)
+
+
+# The two networks with every op in torch (multi-threaded addmm / relu / cat, as the reference's own CPU path runs them):
+# used by bench.py's cpu_baseline through set_matmul_backend("torch"); tests/test_oracle_golden.py checks it against the
+# numpy path above, which is the one the golden vectors pin.
+def _tt(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=F32))
+
+
+def _torch_sampling_mlp(x, net0, n):
+    import torch
+    with torch.no_grad():
+        h = _tt(x)
+        for i in range(n):
+            h = torch.addmm(_tt(net0["layers.%d.bias" % i]), h, _tt(net0["layers.%d.weight" % i]).t())
+            if i + 1 < n:
+                h.relu_()
+        return h.numpy()
+
+
+def _torch_shading_mlp(x, net1, n_pos):
+    import torch
+    with torch.no_grad():
+        x = _tt(x)
+        pts, views = x[:, :n_pos], x[:, n_pos:]
+        lin = lambda h, nm: torch.addmm(_tt(net1[nm + ".bias"]), h, _tt(net1[nm + ".weight"]).t())
+        h = pts
+        for i in range(8):
+            h = lin(h, "pts_linears.%d" % i).relu_()
+            if i == 4:
+                h = torch.cat([pts, h], -1)
+        alpha = lin(h, "alpha_linear")
+        feat = lin(h, "feature_linear")
+        h = lin(torch.cat([feat, views], -1), "views_linears.0").relu_()
+        rgb = lin(h, "rgb_linear")
+        return torch.cat([rgb, alpha], -1).numpy()
 
 
 # --------------------------------------------------------------------------------------

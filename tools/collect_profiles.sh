@@ -7,7 +7,7 @@
 # Copy what should be judged into profiles/ afterwards.
 set -u
 R=$PWD
-OUT=$R/gpurun_out/prof
+OUT=$R/gpurun_out/${PROF_DIR:-prof}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -19,6 +19,6 @@ for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ
   timeout 300 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/pmc_$N -o pmc -- python $R/bench.py $ARGS > $OUT/pmc_$N.log 2>&1
 done
 cd $R
-python tools/summarize_pmc.py $OUT > $OUT/pmc_summary.json
+PMC_WORKLOAD=${WORKLOAD:-config2} BENCH_ARGS="${BENCH_ARGS:-}" python tools/summarize_pmc.py $OUT > $OUT/pmc_summary.json
 cat $OUT/kernel_stats.csv | head -8
 head -c 1500 $OUT/pmc_summary.json

@@ -10,9 +10,11 @@ import os
 import sys
 
 root = sys.argv[1]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 names = {"shade_mlp16": "shade_mlp16_kernel", "shade_mlp32": "shade_mlp32_kernel", "sample_mlp16x3": "sample_mlp16x3_kernel",
-         "sample_mlp_kernel": "sample_mlp_kernel", "select_kernel": "select_kernel", "expand_kernel": "expand_kernel",
-         "scan_blocks": "scan_blocks_kernel", "composite_kernel": "composite_kernel", "dense_expand": "dense_expand_kernel"}
+         "sample_mlp16_kernel": "sample_mlp16_kernel", "sample_mlp_kernel": "sample_mlp_kernel", "select_kernel": "select_kernel",
+         "select_rows": "select_rows_kernel", "expand_kernel": "expand_kernel", "scan_blocks": "scan_blocks_kernel",
+         "composite_kernel": "composite_kernel", "composite_wave": "composite_wave_kernel", "dense_expand": "dense_expand_kernel"}
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in glob.glob(os.path.join(root, "pmc_*", "pmc_counter_collection.csv")):
@@ -35,4 +37,9 @@ for k, d in vals.items():
         rec["mfma_pipe_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc if cyc else None
         rec["effective_clock_ghz"] = cyc / rec["mean_duration_ns_under_pmc"]
     out[k] = rec
+try:
+    from adanerf_amd.build import source_hash
+    out["_meta"] = {"source_hash": source_hash(), "workload": os.environ.get("PMC_WORKLOAD", ""), "bench_args": os.environ.get("BENCH_ARGS", "")}
+except Exception as e:      # noqa
+    out["_meta"] = {"source_hash": None, "error": str(e)}
 json.dump(out, sys.stdout, indent=1)
