@@ -52,6 +52,7 @@ struct adanerf_ctx {
   RayGenParams rg{};
   ShadeParams sp{};
   int mult_mode = 1;   // 0 none, 1 alpha, 2 weights
+  int transform = 0;   // kOracle*: sampler's transform of the raw oracle outputs (losses[0])
   int fp0 = 10, fd0 = 4, fp1 = 10, fd1 = 4;
 
   PackedDev net0;                 // sampling net, fp32 fragments (exact engine)
@@ -137,6 +138,7 @@ struct ModelSetup {
   RayGenParams rg{};
   ShadeParams sp{};
   int mult_mode = 1;
+  int transform = 0;
   int fp0 = 10, fd0 = 4, fp1 = 10, fd1 = 4;
   std::vector<float> ztab;
   DepthMap dm{};
@@ -174,12 +176,13 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   const bool pdf_mode = cf.rayMarchSampler.size() == 2 && cf.rayMarchSampler[1] == "FromClassifiedDepth";
   if (cf.rayMarchSampler.size() != 2 || (!pdf_mode && !contains(cf.rayMarchSampler[1], "FromClassifiedDepthAdaptive")))
     return bad(ADANERF_EUNSUPPORTED, "rayMarchSampler[1] must be FromClassifiedDepthAdaptive[NoDepthRange] or FromClassifiedDepth");
-  if (pdf_mode) {
-    // the oracle-output transform follows losses[0] (src/nerf_raymarch_common.py:624-630); the viewer's samplePDF
-    // always applies the sigmoid (base_cuda_kernels.cu:296-372).  Softmax variants are not on this path.
-    if (!cf.losses.empty() && cf.losses[0] != "BCEWithLogitsLoss")
-      return bad(ADANERF_EUNSUPPORTED, "FromClassifiedDepth is supported with losses[0] == BCEWithLogitsLoss (sigmoid) only");
-    if (cf.useNDC) return bad(ADANERF_EUNSUPPORTED, "FromClassifiedDepth with useNDC is not supported");
+  // The transform every sampler applies to the raw oracle outputs follows losses[0] (src/nerf_raymarch_common.py:624-630,
+  // 686-690, 782-788).  A model directory without a losses key (the trimmed 19-key config.ini) is an AdaNeRF export
+  // (NeRFWeightMultiplicationLoss: no transform) -- except under FromClassifiedDepth, where the viewer's samplePDF
+  // (base_cuda_kernels.cu:296-372) and every DONeRF config apply the sigmoid.
+  {
+    const std::string l0 = cf.losses.empty() ? std::string(pdf_mode ? "BCEWithLogitsLoss" : "NeRFWeightMultiplicationLoss") : cf.losses[0];
+    ms->transform = l0 == "BCEWithLogitsLoss" ? kOracleSigmoid : ((l0 == "CrossEntropyLoss" || l0 == "CrossEntropyLossWeighted") ? kOracleSoftmax : kOracleRaw);
   }
   for (int v : cf.raySampleInput)
     if (v != 0) return bad(ADANERF_EUNSUPPORTED, "raySampleInput != 0 is outside the supported path");
@@ -195,7 +198,7 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   if (ms->fp1 != 10 || ms->fd1 != 4) return bad(ADANERF_EUNSUPPORTED, "posEncArgs[1] must be 10-4");
   const bool ndc = cf.useNDC;
   const bool no_range = contains(cf.rayMarchSampler[1], "NoDepthRange");
-  if (ndc != no_range) return bad(ADANERF_EUNSUPPORTED, "useNDC requires the NoDepthRange sampler and vice versa");
+  if (!pdf_mode && ndc != no_range) return bad(ADANERF_EUNSUPPORTED, "useNDC requires the NoDepthRange sampler and vice versa");
   std::string norm = cf.rayMarchNormalization.size() >= 2 ? cf.rayMarchNormalization[1] : std::string("None");
   if (norm != "InverseSqrtDistCentered" && norm != "None")
     return bad(ADANERF_EUNSUPPORTED, "rayMarchNormalization[1] must be InverseSqrtDistCentered or None");
@@ -208,10 +211,7 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
     // losses[0] drives two things on the adaptive path (src/nerf_raymarch_common.py:686-690, src/features.py:503):
     // the transform applied to the oracle outputs before the threshold test (sigmoid / softmax for the BCE / CE losses)
     // and whether the kept oracle values reach compositing at all (only under NeRFWeightMultiplicationLoss).
-    const std::string& l0 = cf.losses[0];
-    if (l0 == "BCEWithLogitsLoss" || l0 == "CrossEntropyLoss" || l0 == "CrossEntropyLossWeighted")
-      return bad(ADANERF_EUNSUPPORTED, "losses[0] = " + l0 + " (sigmoid / softmax oracle transform) is not supported on the adaptive path");
-    if (l0 != "NeRFWeightMultiplicationLoss") ms->mult_mode = 0;   // no oracle weights in compositing
+    if (cf.losses[0] != "NeRFWeightMultiplicationLoss") ms->mult_mode = 0;   // no oracle weights in compositing
   }
 
   int n_max = opt->num_samples > 0 ? opt->num_samples : cf.numRaymarchSamples.back();
@@ -449,6 +449,7 @@ SelectOut select_out(adanerf_ctx* c, int n_max, float thr, int32_t* d_cnt) {
   so.seg_total = reinterpret_cast<int32_t*>(c->block_total.p);
   so.n_max = n_max;
   so.thr = thr;
+  so.transform = c->transform;
   return so;
 }
 
@@ -490,7 +491,7 @@ int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max,
     return launch_expand(c, n_rays, n_max, kPairSegShift, d_off, d_cnt, d_key, d_w, d_total);
   }
   const int nblk = (n_rays + kSelRaysPerBlock - 1) / kSelRaysPerBlock;
-  hipLaunchKernelGGL(select_kernel, dim3(nblk), dim3(256), 0, c->stream, d_oracle, n_rays, n_max, thr, d_cnt,
+  hipLaunchKernelGGL(select_kernel, dim3(nblk), dim3(256), 0, c->stream, d_oracle, n_rays, n_max, thr, c->transform, d_cnt,
                      reinterpret_cast<uint8_t*>(c->selbin.p), reinterpret_cast<float*>(c->selw.p),
                      reinterpret_cast<int32_t*>(c->block_total.p));
   return launch_expand(c, n_rays, n_max, kSelSegShift, d_off, d_cnt, d_key, d_w, d_total);
@@ -541,7 +542,7 @@ int launch_sample_pdf(adanerf_ctx* c, const float* d_oracle, int n_rays, int n, 
                       float* d_z, int32_t* d_total) {
   if (n_rays <= 0) return ADANERF_OK;
   const int grid = std::min((n_rays + 3) / 4, c->info.compute_units * 8);
-  hipLaunchKernelGGL(pdf_sample_kernel, dim3(grid), dim3(256), 0, c->stream, d_oracle, n_rays, n, c->dm, d_off, d_cnt, d_key, d_w, d_z, d_total);
+  hipLaunchKernelGGL(pdf_sample_kernel, dim3(grid), dim3(256), 0, c->stream, d_oracle, n_rays, n, c->transform, c->dm, d_off, d_cnt, d_key, d_w, d_z, d_total);
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;
 }
@@ -609,6 +610,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   c->rg = ms.rg;
   c->sp = ms.sp;
   c->mult_mode = ms.mult_mode;
+  c->transform = ms.transform;
   c->dm = ms.dm;
   c->fp0 = ms.fp0;
   c->fd0 = ms.fd0;

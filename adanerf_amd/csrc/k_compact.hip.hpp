@@ -96,7 +96,28 @@ __device__ __forceinline__ void select_ray(float v0, float v1, int lane, int n_m
   *s1 = sel1;
 }
 
-__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ oracle, int n_rays, int n_max, float thr,
+// wave-wide sum (every lane gets it)
+__device__ __forceinline__ float wave_sum_all_f32(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// the sampler's transform of a ray's 128 raw outputs held two per lane (kOracle*, k_select_pair.hip.hpp)
+__device__ __forceinline__ void oracle_transform_wave(int transform, float* v0, float* v1) {
+  if (transform == kOracleSigmoid) {
+    *v0 = 1.0f / (1.0f + expf(-*v0));
+    *v1 = 1.0f / (1.0f + expf(-*v1));
+  } else if (transform == kOracleSoftmax) {
+    const float m = wave_max_f32(fmaxf(*v0, *v1));
+    const float e0 = expf(*v0 - m), e1 = expf(*v1 - m);
+    const float s = wave_sum_all_f32(e0 + e1);
+    *v0 = e0 / s;
+    *v1 = e1 / s;
+  }
+}
+
+__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ oracle, int n_rays, int n_max, float thr, int transform,
                                                      int32_t* __restrict__ counts, uint8_t* __restrict__ selbin,
                                                      float* __restrict__ selw, int32_t* __restrict__ block_total) {
   __shared__ int wave_tot[4];
@@ -132,6 +153,7 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ o
       const int r = base + i + u;
       if (r >= n_rays) break;     // wave-uniform
       uint64_t s0, s1;
+      oracle_transform_wave(transform, &v0[u], &v1[u]);
       select_ray(v0[u], v1[u], lane, n_max, thr, &s0, &s1);
       const int c0 = __popcll(s0);
       const int cnt = c0 + __popcll(s1);

@@ -2,6 +2,7 @@
 // Device code only (gfx950, wave64); part of kernels.hip.hpp.
 #pragma once
 #include "k_common.hip.hpp"
+#include "k_compact.hip.hpp"
 
 namespace adanerf {
 
@@ -29,9 +30,10 @@ __device__ __forceinline__ float wave_incl_scan_f32(float v, int lane) {
 }
 
 // FromClassifiedDepth.generate + nerf_sample_pdf(det=True) (src/nerf_raymarch_common.py:606-660, 160-192):
-// sigmoid(oracle) + 1e-5 -> pdf -> cdf over the 129 bin edges -> invert at u = k/(n+1), k = 1..n.
+// transform(oracle) + 1e-5 (sigmoid for DONeRF's BCEWithLogitsLoss; softmax / none for the other losses) -> pdf -> cdf over
+// the 129 bin edges -> invert at u = k/(n+1), k = 1..n.
 // One wave per ray; the cdf goes through a wave-private LDS row and every lane inverts its own u.
-__global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict__ oracle, int n_rays, int n, DepthMap dm,
+__global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict__ oracle, int n_rays, int n, int transform, DepthMap dm,
                                                          int32_t* __restrict__ ray_offsets, int32_t* __restrict__ counts,
                                                          uint32_t* __restrict__ sample_key, float* __restrict__ sample_w,
                                                          float* __restrict__ sample_z, int32_t* __restrict__ total) {
@@ -42,7 +44,9 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict
   if (blockIdx.x == 0 && threadIdx.x == 0) *total = n_rays * n;
   for (int r = (blockIdx.x * 4 + wave); r < n_rays; r += gridDim.x * 4) {
     const float* row = oracle + static_cast<size_t>(r) * kBins;
-    const float w0 = sigmoidf_dev(row[lane]) + 1e-5f, w1 = sigmoidf_dev(row[64 + lane]) + 1e-5f;
+    float t0 = row[lane], t1 = row[64 + lane];
+    oracle_transform_wave(transform, &t0, &t1);
+    const float w0 = t0 + 1e-5f, w1 = t1 + 1e-5f;
     const float tot = wave_sum_f32(w0 + w1);
     const float p0 = w0 / tot, p1 = w1 / tot;
     const float cA = wave_incl_scan_f32(p0, lane);

@@ -16,7 +16,11 @@ struct SelectOut {
   int32_t* seg_total;   // [ceil(R / 32)] samples kept by each 32-ray segment (one wave's rays)
   int32_t n_max;
   float thr;
+  int32_t transform;    // kOracle*: what the sampler applies to the raw network outputs first (losses[0])
 };
+
+// src/nerf_raymarch_common.py:624-630 / 686-690: BCEWithLogitsLoss -> sigmoid, CrossEntropyLoss[Weighted] -> softmax over the bins
+constexpr int kOracleRaw = 0, kOracleSigmoid = 1, kOracleSoftmax = 2;
 
 constexpr int kPairSegShift = 5;                 // a wave selects for 32 rays = one entry of seg_total
 constexpr int kPairMaxN = 16;                    // largest n_max this path handles (sorted lists live in registers)
@@ -190,8 +194,30 @@ __device__ __forceinline__ void pair_emit(const float* x, uint32_t lo, uint32_t 
 //   x        64 values of ray j in lane (j, h) (layout above)
 //   local    ray index of lane j inside the batch, valid = local < n_rays (invalid lanes hold a duplicate ray)
 //   stage    see pair_emit
-__device__ __forceinline__ void pair_epilogue(const float* x, int lane, int local, bool valid, uint32_t stage, const SelectOut& so) {
+__device__ __forceinline__ void pair_epilogue(const float* x_raw, int lane, int local, bool valid, uint32_t stage, const SelectOut& so) {
   const int h = lane >> 5;
+  float x[64];
+  if (so.transform == kOracleSigmoid) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) x[i] = 1.0f / (1.0f + expf(-x_raw[i]));
+  } else if (so.transform == kOracleSoftmax) {
+    float m = x_raw[0];
+#pragma unroll
+    for (int i = 1; i < 64; ++i) m = fmaxf(m, x_raw[i]);
+    m = fmaxf(m, pair_xchg(m));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      x[i] = expf(x_raw[i] - m);
+      sum += x[i];
+    }
+    sum += pair_xchg(sum);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) x[i] = x[i] / sum;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) x[i] = x_raw[i];
+  }
   uint32_t lo, hi;
   int total;
   if (so.n_max <= 4) total = pair_select<4>(x, h, so.n_max, so.thr, &lo, &hi);

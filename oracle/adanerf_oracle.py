@@ -578,10 +578,11 @@ def dense_t(scene: Scene, n: int = D_BINS) -> np.ndarray:
 
 
 def to_world_depth(t: np.ndarray, scene: Scene) -> np.ndarray:
-    """src/util/depth_transformations.py:37-48 (log) / :57-58 (linear); NDC sampler
-    (…NoDepthRange, src/nerf_raymarch_common.py:796-851) returns t unchanged."""
+    """src/util/depth_transformations.py:37-48 (log) / :57-58 (linear); the adaptive NDC sampler
+    (…NoDepthRange, src/nerf_raymarch_common.py:796-851) returns t unchanged, FromClassifiedDepth always maps
+    through the depth range (:660), also under NDC."""
     t = t.astype(F32)
-    if scene.use_ndc:
+    if scene.use_ndc and scene.sampler != "FromClassifiedDepth":
         return t
     d0, d1 = scene.depth_range
     if scene.depth_transform == "log":
@@ -590,11 +591,26 @@ def to_world_depth(t: np.ndarray, scene: Scene) -> np.ndarray:
     return (t * F32(d1 - d0) + F32(d0)).astype(F32)
 
 
-def sample_pdf(orc: np.ndarray, n: int) -> np.ndarray:
+def oracle_transform(orc: np.ndarray, losses0: str) -> np.ndarray:
+    """What the samplers apply to the sampling network's raw outputs before they look at them
+    (src/nerf_raymarch_common.py:624-630 / :686-690 / :782-788): sigmoid under BCEWithLogitsLoss, softmax over the
+    bins under CrossEntropyLoss[Weighted] (the weighted variant slices to the first `disc` = 128 outputs: all of
+    them), nothing otherwise."""
+    orc = orc.astype(F32)
+    if losses0 == "BCEWithLogitsLoss":
+        return sigmoid(orc)
+    if losses0 in ("CrossEntropyLoss", "CrossEntropyLossWeighted"):
+        e = np.exp(orc - np.max(orc, axis=-1, keepdims=True), dtype=F32)
+        return (e / np.sum(e, axis=-1, keepdims=True, dtype=F32)).astype(F32)
+    return orc
+
+
+def sample_pdf(orc: np.ndarray, n: int, losses0: str = "BCEWithLogitsLoss") -> np.ndarray:
     """DONeRF sampler: FromClassifiedDepth.generate, src/nerf_raymarch_common.py:606-660, with
-    the BCEWithLogitsLoss transform (sigmoid), then nerf_sample_pdf (:160-192) with det=True over the 129 bin
-    edges linspace(0,1,129), n+2 uniform u values, first and last dropped.  Returns warped depths t [R,n]."""
-    w = (sigmoid(orc) + F32(1e-5)).astype(F32)
+    the transform losses[0] selects (oracle_transform; DONeRF trains with BCEWithLogitsLoss -> sigmoid), then
+    nerf_sample_pdf (:160-192) with det=True over the 129 bin edges linspace(0,1,129), n+2 uniform u values, first
+    and last dropped.  Returns warped depths t [R,n]."""
+    w = (oracle_transform(orc, losses0) + F32(1e-5)).astype(F32)
     pdf = (w / np.sum(w, axis=-1, keepdims=True, dtype=F32)).astype(F32)
     cdf = np.cumsum(pdf, axis=-1, dtype=F32)
     cdf = np.concatenate([np.zeros_like(cdf[:, :1]), cdf], axis=-1)          # [R,129]
@@ -759,26 +775,29 @@ def render_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: 
         orc = sampling_mlp(feat0, weights.net0)
         if scene.sampler == "FromClassifiedDepth":
             r, n = orc.shape[0], scene.num_samples
-            tt = sample_pdf(orc, n)
+            tt = sample_pdf(orc, n, scene.losses0)
             z2 = to_world_depth(tt, scene)
             sray = np.repeat(np.arange(r, dtype=np.int32), n)
             feat1 = shading_inputs(p, nds, sray, z2.reshape(-1), scene, w, h)
             raw = shading_mlp(feat1, weights.net1, n_pos)
-            rgb = composite_classic(raw.reshape(r, n, 4), z2, nds)
+            # |rays_d| of the rays the samples were placed on: the NDC directions under useNDC (src/features.py:426-431, 507)
+            rd = ndc_rays(h, w, focal_from_fov(w, scene.fov), 1.0, p, nds)[1] if scene.use_ndc else nds
+            rgb = composite_classic(raw.reshape(r, n, 4), z2, rd)
             out_rgb.append(rgb)
             out_cnt.append(np.full(r, n, dtype=np.int32))
             if keep:
                 for k, v in dict(nds=nds, p=p, feat0=feat0, orc=orc, z=z2.reshape(-1), t=tt, feat1=feat1, raw=raw).items():
                     kept.setdefault(k, []).append(v)
             continue
+        orc_t = oracle_transform(orc, scene.losses0)      # what the sampler thresholds / ranks and hands on as weights
         if scene.threshold == 0.0:
             r = orc.shape[0]
             count = np.full(r, D_BINS, dtype=np.int32)
             bins = np.repeat(np.arange(D_BINS, dtype=np.int16)[None], r, 0)
-            wts = orc
+            wts = orc_t
             tt = np.repeat(dense_t(scene)[None], r, 0)
         else:
-            count, bins, wts = select_adaptive(orc, scene.num_samples, scene.threshold)
+            count, bins, wts = select_adaptive(orc_t, scene.num_samples, scene.threshold)
             tt = bin_t(bins)
         off, sray, sbin, sw = compact(count, bins, wts)
         mask = np.arange(bins.shape[1])[None, :] < count[:, None]

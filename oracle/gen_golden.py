@@ -198,7 +198,8 @@ def save_case(name, scene, meta, dirs, pose, rot, ref, n_max, weights_tag):
         if wts.shape != bins.shape:
             # losses[0] != NeRFWeightMultiplicationLoss: the sampler's kept oracle values never reach the feature
             # dict (src/features.py:503); they are the oracle outputs at the kept bins
-            wts = np.where(bins >= 0, np.take_along_axis(ref["orc"], np.maximum(bins, 0).astype(np.int64), axis=1), 0).astype(np.float32)
+            # (after the sampler's transform; restated here, since the reference drops them -- informational, unused downstream)
+            wts = np.where(bins >= 0, np.take_along_axis(O.oracle_transform(ref["orc"], scene.losses0), np.maximum(bins, 0).astype(np.int64), axis=1), 0).astype(np.float32)
     m = dict(meta)
     m.update(dict(view_cell_center=list(scene.view_cell_center), view_cell_size=list(scene.view_cell_size),
                   depth_range=list(scene.depth_range), fov=scene.fov, max_depth=scene.max_depth,
@@ -395,6 +396,36 @@ def main():
         ref = run_reference(R, tc, dirs, pose, rot)
         save_case(name, sc, dict(w=800, h=800, crop=[20, 30, 24, 16, 32], yaw=100.0, pitch=0.0), dirs, pose, rot, ref, 8,
                   "sample_pavillon_16")
+
+    # --- cases K, L: the oracle-output transforms of the other losses on the adaptive path
+    #     (src/nerf_raymarch_common.py:686-690): sigmoid (BCEWithLogitsLoss) and softmax (CrossEntropyLoss) before the
+    #     threshold test; the kept values then never reach compositing (src/features.py:503)
+    for name, l0, thr in [("classroom_n8_bce_thr06", "BCEWithLogitsLoss", 0.6), ("classroom_n8_ce_thr0012", "CrossEntropyLoss", 0.012)]:
+        sc = dataclasses.replace(classroom_scene(8, thr), losses0=l0)
+        dirs = subset_dirs(800, 800, sc.fov, 20, 30, 32, 24, 24)
+        tc = build_reference(R, sc, w_class, 800, 800)
+        ref = run_reference(R, tc, dirs, pose, rot)
+        save_case(name, sc, dict(w=800, h=800, crop=[20, 30, 32, 24, 24], yaw=100.0, pitch=0.0), dirs, pose, rot, ref, 8,
+                  "sample_pavillon_16")
+
+    # --- cases M, N: FromClassifiedDepth under NDC (linear depth through depth_range, NDC rays), and with the softmax transform
+    sc = O.Scene(view_cell_center=(0.0, 0.0, 0.0), view_cell_size=(2.0, 2.0, 1.0), depth_range=(0.05, 0.95),
+                 fov=1.0, max_depth=12.0, num_samples=8, threshold=0.2, use_ndc=True, depth_transform="linear",
+                 pos_enc=((2, 2), (10, 4)), normalization="None", sampler="FromClassifiedDepth", losses0="BCEWithLogitsLoss",
+                 accumulation_mult="")
+    full = O.generate_ray_directions(480, 270, sc.fov).reshape(270, 480, 3)
+    dirs = np.ascontiguousarray(full[100:124, 200:232].reshape(-1, 3))
+    tc = build_reference(R, sc, w_ndc, 480, 270)
+    ref = run_reference(R, tc, dirs, pose_f, rot_f)
+    save_case("ndc_pdf_n8", sc, dict(w=480, h=270, crop=[200, 100, 32, 24], yaw=0.0, pitch=0.0,
+                                     syn=dict(seed=7, n_in0=30, oracle_bias=-0.55, oracle_scale=0.5)),
+              dirs, pose_f, rot_f, ref, 8, "synthetic")
+    sc = dataclasses.replace(classroom_scene(8, 0.2), sampler="FromClassifiedDepth", losses0="CrossEntropyLoss", accumulation_mult="")
+    dirs = subset_dirs(800, 800, sc.fov, 20, 30, 32, 24, 24)
+    tc = build_reference(R, sc, w_class, 800, 800)
+    ref = run_reference(R, tc, dirs, pose, rot)
+    save_case("classroom_pdf_ce_n8", sc, dict(w=800, h=800, crop=[20, 30, 32, 24, 24], yaw=100.0, pitch=0.0), dirs, pose, rot, ref, 8,
+              "sample_pavillon_16")
 
     if not args.only:
         gen_selection_edge_cases(R)

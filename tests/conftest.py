@@ -60,3 +60,8 @@ CASES = ["classroom_n8_thr02", "classroom_n16_thr015", "classroom_dense128", "ba
          "synthetic_fixed8", "ndc_synthetic_n8"]
 # the compositing multipliers other than accumulationMult = alpha (src/nerf_raymarch_common.py:123-133, src/features.py:503)
 MULT_CASES = ["classroom_n8_mult_weights", "classroom_n8_mult_none", "classroom_n8_loss_mse"]
+# sigmoid / softmax applied to the sampling network's outputs before the adaptive selection (losses[0] = BCEWithLogitsLoss /
+# CrossEntropyLoss, src/nerf_raymarch_common.py:686-690)
+TRANSFORM_CASES = ["classroom_n8_bce_thr06", "classroom_n8_ce_thr0012"]
+# FromClassifiedDepth beyond the DONeRF default: under NDC, and with the softmax transform
+PDF_CASES = ["classroom_pdf_n8", "ndc_pdf_n8", "classroom_pdf_ce_n8"]

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import adanerf_oracle as O
-from conftest import CASES, GOLD, case_weights, load_case, record
+from conftest import CASES, GOLD, PDF_CASES, TRANSFORM_CASES, case_weights, load_case, record
 
 import adanerf_amd
 from adanerf_amd import renderer as R
@@ -241,6 +241,49 @@ def test_compact_dense_mode(cases):
         assert total == n * 128 and (cnt == 128).all() and np.array_equal(off, np.arange(n) * 128)
         assert np.array_equal(key, np.arange(n * 128, dtype=np.uint32))
         assert np.array_equal(sw, orc.reshape(-1))
+
+
+@pytest.fixture(scope="module")
+def transform_cases(tmp_path_factory):
+    out = {}
+    for name in TRANSFORM_CASES:
+        z, meta, sc = load_case(name)
+        wts = case_weights(meta)
+        out[name] = (z, meta, sc, wts, model_dir(tmp_path_factory, sc, wts, name))
+    return out
+
+
+@BOTH_SELECTS
+@pytest.mark.parametrize("name", TRANSFORM_CASES)
+def test_compact_applies_the_samplers_transform(transform_cases, name, wave_select):
+    """losses[0] = BCEWithLogitsLoss / CrossEntropyLoss: sigmoid / softmax over the bins before the threshold test and the
+    ranking (src/nerf_raymarch_common.py:686-690).  Counts and bins against the reference-generated fixture; the kept
+    values are the transformed ones (device expf vs torch: a few ulp)."""
+    z, meta, sc, wts, d = transform_cases[name]
+    with make(transform_cases[name], wave_select=wave_select) as r:
+        off, cnt, key, sw, total = gpu_compact(r, z["oracle_out"], sc.num_samples, sc.threshold)
+    e_cnt, e_bins, e_w = z["sel_count"].astype(np.int32), z["sel_bins"], z["sel_weight"]
+    same = cnt == e_cnt
+    assert same.mean() >= 0.995, same.mean()            # a value within an ulp of the threshold may fall on the other side
+    e_off, e_ray, e_bin, e_sw = O.compact(e_cnt, e_bins, e_w)
+    if same.all():
+        assert np.array_equal((key & 127).astype(np.int16), e_bin)
+        np.testing.assert_allclose(sw, e_sw, rtol=3e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", TRANSFORM_CASES)
+def test_frame_with_transformed_oracle_matches_oracle(transform_cases, name):
+    z, meta, sc, wts, d = transform_cases[name]
+    w, h = 112, 80
+    ref = small_frame(transform_cases[name], w, h)
+    for kw in (dict(), dict(keep_oracle=True), dict(wave_select=True)):        # fused epilogue, pair launch, wave launch
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="fp32", **kw) as r:
+            r.set_camera(z["pose"], z["rot"])
+            rgb, rgba, st = r.render_numpy()
+            cnt, same = same_bin_sets(r, ref, w * h, sc.num_samples)
+        assert same.mean() >= 0.99, (kw, same.mean())
+        np.testing.assert_allclose(rgb[same], ref["rgb"][same], rtol=0, atol=3e-4)
+    assert 1.5 < st.total_samples / (w * h) < 7.5
 
 
 # ---------------------------------------------------------------------------------------------
@@ -669,10 +712,19 @@ def test_shard_with_no_rows_renders_nothing(cases):
 # ---------------------------------------------------------------------------------------------
 
 @pytest.fixture(scope="module")
-def pdf_case(tmp_path_factory):
-    z, meta, sc = load_case("classroom_pdf_n8")
-    wts = case_weights(meta)
-    return z, meta, sc, wts, model_dir(tmp_path_factory, sc, wts, "pdf")
+def pdf_cases(tmp_path_factory):
+    out = {}
+    for name in PDF_CASES:
+        z, meta, sc = load_case(name)
+        wts = case_weights(meta)
+        out[name] = (z, meta, sc, wts, model_dir(tmp_path_factory, sc, wts, name))
+    return out
+
+
+@pytest.fixture(params=PDF_CASES)
+def pdf_case(request, pdf_cases):
+    """DONeRF default (sigmoid, log depth), FromClassifiedDepth under NDC, and with the softmax transform."""
+    return pdf_cases[request.param]
 
 
 def test_pdf_sampler_matches_reference(pdf_case):
@@ -688,7 +740,7 @@ def test_pdf_sampler_matches_reference(pdf_case):
         zz, kk = sz.numpy(), key.numpy()
         assert int(tot.numpy()[0]) == R_ * n and (cnt.numpy() == n).all() and np.array_equal(off.numpy(), np.arange(R_) * n)
         assert np.array_equal(kk >> 7, np.repeat(np.arange(R_, dtype=np.uint32), n))
-    ref = z["z_world"][:R_ * n] if z["z_world"].shape[0] >= R_ * n else O.to_world_depth(O.sample_pdf(z["oracle_out"], n), sc).reshape(-1)
+    ref = z["z_world"][:R_ * n] if z["z_world"].shape[0] >= R_ * n else O.to_world_depth(O.sample_pdf(z["oracle_out"], n, sc.losses0), sc).reshape(-1)
     ref = ref.reshape(-1)
     m = min(ref.shape[0], zz.shape[0])
     # the cdf is a wave-parallel fp32 scan here and a double-accumulated torch.cumsum in the reference: where a
@@ -702,13 +754,13 @@ def test_classic_compositing_matches_reference(pdf_case):
     z, meta, sc, wts, d = pdf_case
     n = sc.num_samples
     R_ = z["nds"].shape[0]
-    zw = O.to_world_depth(O.sample_pdf(z["oracle_out"], n), sc)
+    zw = O.to_world_depth(O.sample_pdf(z["oracle_out"], n, sc.losses0), sc)
     rec = golden_ray_records(z, meta, sc)
     with make(pdf_case) as r:
         rgb, rgba = r.empty((R_, 3), np.float32), r.empty((R_, 4), np.uint8)
         r.composite_classic(r.to_device(z["shade_out"]), r.to_device(zw.reshape(-1)), r.to_device(rec), R_, n, rgb, rgba)
         out, out8 = rgb.numpy(), rgba.numpy()
-    ref = O.composite_classic(z["shade_out"].reshape(R_, n, 4), zw, z["nds"])
+    ref = O.composite_classic(z["shade_out"].reshape(R_, n, 4), zw, rec[:, 4:7])      # |d| of the (NDC) ray the samples sit on
     np.testing.assert_allclose(out, ref, rtol=0, atol=3e-6)
     np.testing.assert_allclose(out, z["rgb"], rtol=0, atol=3e-5)
     assert (np.abs(out8[:, :3].astype(np.int16) - O.to_rgba8(ref)[:, :3].astype(np.int16)) <= 1).all()
