@@ -74,6 +74,8 @@ struct adanerf_ctx {
   DepthMap dm{};
   int shade_grid[3] = {0, 0, 0};
   int device = 0;                 // HIP device ordinal this context lives on
+  float* aux_depth = nullptr;        // adanerf_set_aux_outputs: caller-owned [rays_local] buffers filled by adanerf_render
+  float* aux_acc = nullptr;
   hipEvent_t peer_event = nullptr;   // adanerf_gather_to: orders the destination stream behind the copy
   uint64_t peer_tried = 0;           // bit d: peer access to device d has been requested once
 };
@@ -548,20 +550,27 @@ int launch_sample_pdf(adanerf_ctx* c, const float* d_oracle, int n_rays, int n, 
 }
 
 int launch_composite_classic(adanerf_ctx* c, const float* d_raw, const float* d_z, const float* d_rays, int n_rays, int n, float* d_rgb,
-                             void* d_rgba8) {
+                             void* d_rgba8, float* d_depth = nullptr, float* d_acc = nullptr) {
   if (n_rays <= 0) return ADANERF_OK;
   hipLaunchKernelGGL(composite_classic_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw),
-                     d_z, d_rays, n_rays, n, d_rgb, reinterpret_cast<uchar4*>(d_rgba8));
+                     d_z, d_rays, n_rays, n, d_rgb, reinterpret_cast<uchar4*>(d_rgba8), d_depth, d_acc);
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;
 }
 
 int launch_composite(adanerf_ctx* c, const float* d_raw, const float* d_w, const int32_t* d_off, const int32_t* d_cnt, int n_rays,
-                     float* d_rgb, void* d_rgba8) {
+                     float* d_rgb, void* d_rgba8, const uint32_t* d_key = nullptr, float* d_depth = nullptr, float* d_acc = nullptr) {
   if (n_rays <= 0) return ADANERF_OK;
+  AuxOut aux{};
+  if (d_key && (d_depth || d_acc)) {
+    aux.depth = d_depth;
+    aux.acc = d_acc;
+    aux.sample_key = d_key;
+    aux.ztab = reinterpret_cast<const float*>(c->ztab.p);
+  }
   if (c->info.num_samples > 32)   // long rays (dense mode): one wave per ray, coalesced
     hipLaunchKernelGGL(composite_wave_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw), d_w,
-                       d_off, d_cnt, n_rays, c->mult_mode, d_rgb, reinterpret_cast<uchar4*>(d_rgba8));
+                       d_off, d_cnt, n_rays, c->mult_mode, d_rgb, reinterpret_cast<uchar4*>(d_rgba8), aux);
   else {
     // samples of RB consecutive rays staged in LDS (20 B each), RB chosen so that RB * N * 20 B <= 48 KB
     const int N = c->info.num_samples;
@@ -570,7 +579,7 @@ int launch_composite(adanerf_ctx* c, const float* d_raw, const float* d_w, const
       const int cap = RB * N;
       hipLaunchKernelGGL(composite_kernel<RB>, dim3((n_rays + RB - 1) / RB), dim3(RB), static_cast<size_t>(cap) * 20, c->stream,
                          reinterpret_cast<const float4*>(d_raw), d_w, d_off, d_cnt, n_rays, c->mult_mode, cap, d_rgb,
-                         reinterpret_cast<uchar4*>(d_rgba8));
+                         reinterpret_cast<uchar4*>(d_rgba8), aux);
     };
     if (N <= 9) run(std::integral_constant<int, 256>{});
     else if (N <= 19) run(std::integral_constant<int, 128>{});
@@ -987,8 +996,10 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     float* rgb_b = d_rgb ? d_rgb + static_cast<size_t>(first) * 3 : nullptr;
     void* rgba_b = d_rgba8 ? static_cast<char*>(d_rgba8) + static_cast<size_t>(first) * 4 : nullptr;
-    if (pdf) rc = launch_composite_classic(c, raw, sz, rays, n, N, rgb_b, rgba_b);
-    else rc = launch_composite(c, raw, sw, off, cnt, n, rgb_b, rgba_b);
+    float* depth_b = c->aux_depth ? c->aux_depth + first : nullptr;
+    float* acc_b = c->aux_acc ? c->aux_acc + first : nullptr;
+    if (pdf) rc = launch_composite_classic(c, raw, sz, rays, n, N, rgb_b, rgba_b, depth_b, acc_b);
+    else rc = launch_composite(c, raw, sw, off, cnt, n, rgb_b, rgba_b, key, depth_b, acc_b);
     if (rc) return rc;
     if (ev) {
       HIP_TRY(c, hipEventRecord(ev[4], c->stream));
@@ -1009,6 +1020,13 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     c->prof_frames = 0;
     c->folded = adanerf_stats{};
   }
+  return ADANERF_OK;
+}
+
+int adanerf_set_aux_outputs(adanerf_ctx* c, float* d_depth_map, float* d_acc_map) {
+  if (!c) return ADANERF_EINVAL;
+  c->aux_depth = d_depth_map;
+  c->aux_acc = d_acc_map;
   return ADANERF_OK;
 }
 

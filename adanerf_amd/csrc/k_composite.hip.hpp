@@ -11,9 +11,18 @@ namespace adanerf {
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Optional secondary outputs of the compositing step (src/nerf_raymarch_common.py:137-139 / 60-62): per ray
+// depth_map = sum w z (z = world depth of the sample as the sampler placed it) and acc_map = sum w.
+struct AuxOut {
+  float* depth;               // [R] or null
+  float* acc;                 // [R] or null
+  const uint32_t* sample_key; // adaptive / dense path: z = ztab[key & 127]
+  const float* ztab;
+};
+
 // one sample of the front-to-back recurrence (src/nerf_raymarch_common.py:91-144): every product and sum rounds
-// to fp32 where the reference's does
-__device__ __forceinline__ void composite_step(const float4 v, float wv, int mult_mode, float& cr, float& cg, float& cb, float& T) {
+// to fp32 where the reference's does; returns the sample's weight
+__device__ __forceinline__ float composite_step(const float4 v, float wv, int mult_mode, float& cr, float& cg, float& cb, float& T) {
   float al = sigmoidf(v.w);
   if (mult_mode == 1) al = __fmul_rn(al, wv);
   float wt = __fmul_rn(al, T);
@@ -22,6 +31,7 @@ __device__ __forceinline__ void composite_step(const float4 v, float wv, int mul
   cg = __fadd_rn(cg, __fmul_rn(wt, sigmoidf(v.y)));
   cb = __fadd_rn(cb, __fmul_rn(wt, sigmoidf(v.z)));
   T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, al), 1e-10f));
+  return wt;
 }
 
 // Thread per ray, sequential over its samples (the reference's cumprod order, bit for bit).  The samples of the
@@ -34,7 +44,7 @@ template <int RB>
 __global__ __launch_bounds__(RB) void composite_kernel(const float4* __restrict__ raw, const float* __restrict__ sample_w,
                                                        const int32_t* __restrict__ ray_offsets, const int32_t* __restrict__ counts,
                                                        int n_rays, int mult_mode, int cap, float* __restrict__ rgb_out,
-                                                       uchar4* __restrict__ rgba8_out) {
+                                                       uchar4* __restrict__ rgba8_out, AuxOut aux) {
   extern __shared__ __attribute__((aligned(16))) char comp_lds[];
   float4* s_raw = reinterpret_cast<float4*>(comp_lds);
   float* s_w = reinterpret_cast<float*>(comp_lds + static_cast<size_t>(cap) * sizeof(float4));
@@ -56,7 +66,16 @@ __global__ __launch_bounds__(RB) void composite_kernel(const float4* __restrict_
   const int o = ray_offsets[r], c = counts[r];
   const int ol = o - base;
   float cr = 0.f, cg = 0.f, cb = 0.f, T = 1.f;
-  if (staged && ol >= 0 && ol + c <= n) {
+  if (aux.depth || aux.acc) {                                   // the rarely used path keeps the plain loads
+    float dm = 0.f, am = 0.f;
+    for (int k = 0; k < c; ++k) {
+      const float wt = composite_step(raw[o + k], sample_w[o + k], mult_mode, cr, cg, cb, T);
+      dm = __fadd_rn(dm, __fmul_rn(wt, aux.ztab[aux.sample_key[o + k] & 127u]));
+      am = __fadd_rn(am, wt);
+    }
+    if (aux.depth) aux.depth[r] = dm;
+    if (aux.acc) aux.acc[r] = am;
+  } else if (staged && ol >= 0 && ol + c <= n) {
     for (int k = 0; k < c; ++k) composite_step(s_raw[ol + k], s_w[ol + k], mult_mode, cr, cg, cb, T);
   } else {
     for (int k = 0; k < c; ++k) composite_step(raw[o + k], sample_w[o + k], mult_mode, cr, cg, cb, T);
@@ -91,7 +110,8 @@ __device__ __forceinline__ float wave_incl_prod_f32(float v, int lane) {
 
 __global__ __launch_bounds__(256) void composite_wave_kernel(const float4* __restrict__ raw, const float* __restrict__ sample_w,
                                                              const int32_t* __restrict__ ray_offsets, const int32_t* __restrict__ counts,
-                                                             int n_rays, int mult_mode, float* __restrict__ rgb_out, uchar4* __restrict__ rgba8_out) {
+                                                             int n_rays, int mult_mode, float* __restrict__ rgb_out, uchar4* __restrict__ rgba8_out,
+                                                             AuxOut aux) {
   const int lane = lane_id();
   const int r = blockIdx.x * 4 + (static_cast<int>(threadIdx.x) >> 6);
   if (r >= n_rays) return;
@@ -125,6 +145,25 @@ __global__ __launch_bounds__(256) void composite_wave_kernel(const float4* __res
   }
   const float w0 = al[0] * e0, w1 = al[1] * (tot0 * e1);
   float cr = w0 * col[0][0] + w1 * col[1][0], cg = w0 * col[0][1] + w1 * col[1][1], cb = w0 * col[0][2] + w1 * col[1][2];
+  if (aux.depth || aux.acc) {      // weights of the two samples of this lane (mult_mode 2 scales the weight, not alpha)
+    float q0 = w0, q1 = w1;
+    if (mult_mode == 2) {
+      q0 *= (lane < c) ? sample_w[o + lane] : 0.f;
+      q1 *= (lane + 64 < c) ? sample_w[o + lane + 64] : 0.f;
+    }
+    float dm = q0 * ((lane < c) ? aux.ztab[aux.sample_key[o + lane] & 127u] : 0.f) +
+               q1 * ((lane + 64 < c) ? aux.ztab[aux.sample_key[o + lane + 64] & 127u] : 0.f);
+    float am = q0 + q1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      dm += __shfl_xor(dm, off);
+      am += __shfl_xor(am, off);
+    }
+    if (lane == 0) {
+      if (aux.depth) aux.depth[r] = dm;
+      if (aux.acc) aux.acc[r] = am;
+    }
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     cr += __shfl_xor(cr, off);

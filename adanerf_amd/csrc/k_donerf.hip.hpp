@@ -91,13 +91,14 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict
 // last interval 1e10; rgb = sigmoid(raw); front-to-back with the 1e-10 transmittance floor.
 __global__ __launch_bounds__(256) void composite_classic_kernel(const float4* __restrict__ raw, const float* __restrict__ sample_z,
                                                                 const float* __restrict__ rays, int n_rays, int n,
-                                                                float* __restrict__ rgb_out, uchar4* __restrict__ rgba8_out) {
+                                                                float* __restrict__ rgb_out, uchar4* __restrict__ rgba8_out,
+                                                                float* __restrict__ depth_out, float* __restrict__ acc_out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rays) return;
   const float4 d4 = reinterpret_cast<const float4*>(rays + static_cast<size_t>(r) * 8)[1];
   const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d4.x, d4.x), __fmul_rn(d4.y, d4.y)), __fmul_rn(d4.z, d4.z)));
   const size_t o = static_cast<size_t>(r) * n;
-  float cr = 0.f, cg = 0.f, cb = 0.f, T = 1.f;
+  float cr = 0.f, cg = 0.f, cb = 0.f, T = 1.f, dm = 0.f, am = 0.f;
   float zk = sample_z[o];
   for (int k = 0; k < n; ++k) {
     const float4 v = raw[o + k];
@@ -109,8 +110,12 @@ __global__ __launch_bounds__(256) void composite_classic_kernel(const float4* __
     cg = __fadd_rn(cg, __fmul_rn(wt, sigmoidf_dev(v.y)));
     cb = __fadd_rn(cb, __fmul_rn(wt, sigmoidf_dev(v.z)));
     T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, al), 1e-10f));
+    dm = __fadd_rn(dm, __fmul_rn(wt, zk));
+    am = __fadd_rn(am, wt);
     zk = zn;
   }
+  if (depth_out) depth_out[r] = dm;       // src/nerf_raymarch_common.py:60-62
+  if (acc_out) acc_out[r] = am;
   if (rgb_out) {
     rgb_out[3 * static_cast<size_t>(r) + 0] = cr;
     rgb_out[3 * static_cast<size_t>(r) + 1] = cg;

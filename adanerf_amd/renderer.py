@@ -54,7 +54,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_last_error", "adanerf_set_camera",
-           "adanerf_render", "adanerf_assemble_strips", "adanerf_sync", "adanerf_set_stream", "adanerf_set_profiling",
+           "adanerf_render", "adanerf_set_aux_outputs", "adanerf_assemble_strips", "adanerf_sync", "adanerf_set_stream", "adanerf_set_profiling",
            "adanerf_collect_stats", "adanerf_ray_features", "adanerf_sample_mlp",
            "adanerf_compact", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_shade_mlp_z", "adanerf_sample_pdf",
            "adanerf_composite", "adanerf_composite_classic", "adanerf_copy_result_sampling_network",
@@ -82,6 +82,7 @@ def load_library(path: Optional[str] = None):
     lib.adanerf_set_camera.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.adanerf_render.argtypes = [vp, vp, vp, C.POINTER(Stats)]
     lib.adanerf_assemble_strips.argtypes = [vp, vp, vp]
+    lib.adanerf_set_aux_outputs.argtypes = [vp, vp, vp]
     lib.adanerf_sync.argtypes = [vp]
     lib.adanerf_set_stream.argtypes = [vp, vp]
     lib.adanerf_set_profiling.argtypes = [vp, i32]
@@ -257,6 +258,10 @@ class NeuralRenderer:
         if stats:
             self.last_stats = st
         return st
+
+    def set_aux_outputs(self, depth_map=None, acc_map=None):
+        """Subsequent renders also fill [rays_local] fp32 depth_map (sum w z) / acc_map (sum w); None switches them off."""
+        self._check(self.lib.adanerf_set_aux_outputs(self.handle, _ptr(depth_map), _ptr(acc_map)))
 
     def gather_from(self, dst, src_renderer: "NeuralRenderer", src, nbytes: int):
         """Stream-ordered copy of ``nbytes`` from ``src`` (on ``src_renderer``'s device / stream) into ``dst`` on this

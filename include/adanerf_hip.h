@@ -170,6 +170,17 @@ int adanerf_set_camera(adanerf_ctx* ctx, const float pos[3], const float rot_c2w
  * the call synchronous and fills the per-stage timings. */
 int adanerf_render(adanerf_ctx* ctx, void* d_rgba8_out, float* d_rgb_f32_out, adanerf_stats* stats);
 
+/* Secondary outputs of the compositing step (reference: adaptive_raw2outputs / nerf_raw2outputs return them next to the
+ * colour, src/nerf_raymarch_common.py:137-139 and :60-62; the viewer has no counterpart): until reset with NULLs, every
+ * adanerf_render also fills
+ *   d_depth_map [rays_local] fp32   sum_k w_k z_k, z = world depth of the sample as the sampler placed it (NDC depth for
+ *                                   useNDC models).  The reference's NeRFOutputDepth is this value under NDC and
+ *                                   depth_transform.from_world(.) of it otherwise (src/features.py:571-577); its disp_map
+ *                                   is 1 / max(1e-10, depth_map / acc_map)
+ *   d_acc_map   [rays_local] fp32   sum_k w_k (accumulated opacity)
+ * with w_k the compositing weight of sample k (after accumulationMult).  Either may be NULL.  Caller-owned buffers. */
+int adanerf_set_aux_outputs(adanerf_ctx* ctx, float* d_depth_map, float* d_acc_map);
+
 /* De-interleaves the gathered shard payloads ([shard_world][rays_local_max] uchar4, rank-major)
  * into the full row-major image [h*w] uchar4. */
 int adanerf_assemble_strips(adanerf_ctx* ctx, const void* d_gathered, void* d_image_out);

@@ -268,7 +268,7 @@ def load_weights(model_dir: str) -> Weights:
 
 
 def synthetic_weights(seed: int, n_in0: int = 90, n_in1_pos: int = 63, n_in1_dir: int = 27,
-                      oracle_bias: float = 0.0, oracle_scale: float = 1.0) -> Weights:
+                      oracle_bias: float = 0.0, oracle_scale: float = 1.0, alpha_bias: float = 0.0) -> Weights:
     """Seeded Kaiming-normal weights in the exported layout (nn.init.kaiming_normal_ as
     src/models.py:77-78, 246-250: std = sqrt(2/fan_in)); biases U(-1/sqrt(fan_in), ..) like
     nn.Linear's default.  ``oracle_bias`` is added to the sampling net's last bias so a
@@ -300,6 +300,8 @@ def synthetic_weights(seed: int, n_in0: int = 90, n_in1_pos: int = 63, n_in1_dir
         w, b = lin(o, k)
         n1[nm + ".weight"] = w
         n1[nm + ".bias"] = b
+    # classic sigma/delta compositing takes relu(density): shift it so that a random-init net is not transparent everywhere
+    n1["alpha_linear.bias"] = (n1["alpha_linear.bias"] + F32(alpha_bias)).astype(F32)
     return Weights(n0, n1)
 
 
@@ -591,6 +593,18 @@ def to_world_depth(t: np.ndarray, scene: Scene) -> np.ndarray:
     return (t * F32(d1 - d0) + F32(d0)).astype(F32)
 
 
+def from_world_depth(z: np.ndarray, scene: Scene) -> np.ndarray:
+    """Inverse of to_world_depth: LogTransform.from_world (src/util/depth_transformations.py:13-35: values <= 0 after
+    subtracting the range minimum become 0.001) / LinearTransform.from_world (:52-54)."""
+    z = z.astype(F32)
+    d0, d1 = scene.depth_range
+    if scene.depth_transform == "log":
+        d = (z - F32(d0)).astype(F32)
+        d = np.where(d <= 0, F32(0.001), d)
+        return (np.log(d + F32(1.0)) / F32(math.log((d1 - d0) + 1))).astype(F32)
+    return ((z - F32(d0)) / F32(d1 - d0)).astype(F32)
+
+
 def oracle_transform(orc: np.ndarray, losses0: str) -> np.ndarray:
     """What the samplers apply to the sampling network's raw outputs before they look at them
     (src/nerf_raymarch_common.py:624-630 / :686-690 / :782-788): sigmoid under BCEWithLogitsLoss, softmax over the
@@ -630,10 +644,10 @@ def sample_pdf(orc: np.ndarray, n: int, losses0: str = "BCEWithLogitsLoss") -> n
     return out[:, 1:-1]
 
 
-def composite_classic(raw: np.ndarray, z: np.ndarray, rays_d: np.ndarray) -> np.ndarray:
+def composite_classic(raw: np.ndarray, z: np.ndarray, rays_d: np.ndarray, aux: bool = False):
     """nerf_raw2outputs, src/nerf_raymarch_common.py:19-68 (no noise, no white background, no oracle weights):
     alpha = 1 - exp(-relu(raw_a) * dist * |d|), dist = z[k+1] - z[k] (last 1e10), rgb = sigmoid(raw).
-    raw [R,N,4], z [R,N] world depths, rays_d [R,3] -> [R,3]."""
+    raw [R,N,4], z [R,N] world depths, rays_d [R,3] -> [R,3]; aux: (rgb, depth_map = sum w*z, acc_map = sum w)."""
     raw = raw.astype(F32)
     dists = np.concatenate([z[:, 1:] - z[:, :-1], np.full((z.shape[0], 1), 1e10, dtype=F32)], -1).astype(F32)
     dists = (dists * np.sqrt(np.sum(rays_d * rays_d, -1, keepdims=True, dtype=F32))).astype(F32)
@@ -641,7 +655,10 @@ def composite_classic(raw: np.ndarray, z: np.ndarray, rays_d: np.ndarray) -> np.
     alpha = (F32(1.0) - np.exp(-np.maximum(raw[..., 3], F32(0)) * dists, dtype=F32)).astype(F32)
     trans = np.cumprod(np.concatenate([np.ones((alpha.shape[0], 1), F32), F32(1.0) - alpha + F32(1e-10)], -1), -1, dtype=F32)[:, :-1]
     wts = (alpha * trans).astype(F32)
-    return np.sum(wts[..., None] * rgb, -2, dtype=F32).astype(F32)
+    out = np.sum(wts[..., None] * rgb, -2, dtype=F32).astype(F32)
+    if aux:
+        return out, np.sum(wts * z, -1, dtype=F32).astype(F32), np.sum(wts, -1, dtype=F32).astype(F32)
+    return out
 
 
 # --------------------------------------------------------------------------------------
@@ -698,15 +715,18 @@ def sigmoid(x):
 
 
 def composite(raw: np.ndarray, sample_w: np.ndarray, ray_offset: np.ndarray, count: np.ndarray,
-              accumulation_mult: str = "alpha") -> np.ndarray:
+              accumulation_mult: str = "alpha", z: Optional[np.ndarray] = None):
     """src/nerf_raymarch_common.py:91-144 (adaptive_raw2outputs): sigmoid on all four
     channels, alpha *= oracle value, w = alpha * cumprod(1 - alpha + 1e-10) (exclusive),
-    rgb = sum w*c.  Inactive slots contribute alpha 0.  fp32, unclamped.  [R,3]."""
+    rgb = sum w*c.  Inactive slots contribute alpha 0.  fp32, unclamped.  [R,3].
+    With ``z`` (world depth per sample): also depth_map = sum w*z and acc_map = sum w (:137-139) -> (rgb, depth, acc)."""
     r = count.shape[0]
     n = int(count.max()) if r else 0
     sg = sigmoid(raw)
     rgb = np.zeros((r, 3), dtype=F32)
     trans = np.ones(r, dtype=F32)
+    depth = np.zeros(r, dtype=F32)
+    acc = np.zeros(r, dtype=F32)
     for s in range(n):
         act = count > s
         idx = np.where(act, ray_offset + s, 0)
@@ -717,8 +737,11 @@ def composite(raw: np.ndarray, sample_w: np.ndarray, ray_offset: np.ndarray, cou
         if accumulation_mult == "weights":
             wgt = (wgt * np.where(act, sample_w[idx], F32(0))).astype(F32)
         rgb += (wgt[:, None] * np.where(act[:, None], sg[idx, :3], F32(0))).astype(F32)
+        if z is not None:
+            depth += (wgt * np.where(act, z[idx], F32(0))).astype(F32)
+            acc += wgt
         trans = (trans * (F32(1.0) - a + F32(1e-10))).astype(F32)
-    return rgb
+    return rgb if z is None else (rgb, depth, acc)
 
 
 def effective_mult(scene: "Scene") -> str:
@@ -766,6 +789,8 @@ def render_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: 
     every intermediate the golden fixtures hold."""
     out_rgb = []
     out_cnt = []
+    out_depth = []
+    out_acc = []
     kept: Dict[str, list] = {}
     n_pos = 3 + 6 * scene.pos_enc[1][0]
     for s in range(0, dirs_cam.shape[0], chunk):
@@ -782,8 +807,10 @@ def render_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: 
             raw = shading_mlp(feat1, weights.net1, n_pos)
             # |rays_d| of the rays the samples were placed on: the NDC directions under useNDC (src/features.py:426-431, 507)
             rd = ndc_rays(h, w, focal_from_fov(w, scene.fov), 1.0, p, nds)[1] if scene.use_ndc else nds
-            rgb = composite_classic(raw.reshape(r, n, 4), z2, rd)
+            rgb, dm, am = composite_classic(raw.reshape(r, n, 4), z2, rd, aux=True)
             out_rgb.append(rgb)
+            out_depth.append(dm)
+            out_acc.append(am)
             out_cnt.append(np.full(r, n, dtype=np.int32))
             if keep:
                 for k, v in dict(nds=nds, p=p, feat0=feat0, orc=orc, z=z2.reshape(-1), t=tt, feat1=feat1, raw=raw).items():
@@ -804,14 +831,17 @@ def render_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: 
         z = to_world_depth(tt[mask], scene)
         feat1 = shading_inputs(p, nds, sray, z, scene, w, h)
         raw = shading_mlp(feat1, weights.net1, n_pos)
-        rgb = composite(raw, sw, off, count, effective_mult(scene))
+        rgb, dm, am = composite(raw, sw, off, count, effective_mult(scene), z)
         out_rgb.append(rgb)
+        out_depth.append(dm)
+        out_acc.append(am)
         out_cnt.append(count)
         if keep:
             for k, v in dict(nds=nds, p=p, feat0=feat0, orc=orc, bins=bins, wts=wts, z=z,
                              feat1=feat1, raw=raw).items():
                 kept.setdefault(k, []).append(v)
-    res = {"rgb": np.concatenate(out_rgb), "count": np.concatenate(out_cnt)}
+    res = {"rgb": np.concatenate(out_rgb), "count": np.concatenate(out_cnt),
+           "depth_map": np.concatenate(out_depth), "acc_map": np.concatenate(out_acc)}
     if keep:
         for k, v in kept.items():
             res[k] = np.concatenate(v)

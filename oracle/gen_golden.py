@@ -120,7 +120,7 @@ def run_reference(R, tc, dirs, pose, rot, chunk=8192):
         n = dc.shape[0]
         item = dict(feat0=d0[K.input_feature_batch], orc=d0[K.network_output],
                     p=d0[K.input_feature_ray_origins], nds=d0[K.input_feature_ray_directions],
-                    rgb=outs[1])
+                    rgb=outs[1], est_depth=d1[K.nerf_estimated_depth].reshape(-1), acc=d1[K.nerf_weights_output].sum(-1))
         raw = d1[K.network_output]
         zv = d1[K.nerf_input_feature_z_vals]
         f1 = d1[K.input_feature_batch]
@@ -221,7 +221,10 @@ def save_case(name, scene, meta, dirs, pose, rot, ref, n_max, weights_tag):
         oracle_in=ref["feat0"][:n_f].astype(np.float32), oracle_out=ref["orc"].astype(np.float32),
         sel_count=count.astype(np.uint8), sel_bins=bins, sel_weight=wts,
         z_world=ref["z"][:16384].astype(np.float32), shade_in=ref["feat1"][:m_f].astype(np.float32),
-        shade_out=raw, rgb=ref["rgb"].astype(np.float32))
+        shade_out=raw, rgb=ref["rgb"].astype(np.float32),
+        # secondary outputs of the compositing step: NeRFOutputDepth (from_world of the weight-averaged sample depth;
+        # src/features.py:571-577) and the accumulated opacity sum(weights) (src/nerf_raymarch_common.py:137-139)
+        est_depth=ref["est_depth"].astype(np.float32), acc=ref["acc"].astype(np.float32))
     sz = os.path.getsize(os.path.join(GOLD, name + ".npz"))
     print("wrote %s.npz (%d KB)  rays=%d samples=%d mean=%.2f" %
           (name, sz // 1024, count.shape[0], int(count.sum()), float(count.mean())))
@@ -397,6 +400,24 @@ def main():
         save_case(name, sc, dict(w=800, h=800, crop=[20, 30, 24, 16, 32], yaw=100.0, pitch=0.0), dirs, pose, rot, ref, 8,
                   "sample_pavillon_16")
 
+    # --- cases O, P: small crops that carry the secondary compositing outputs (all cases written from now on do)
+    sc = classroom_scene(8, 0.2)
+    dirs = subset_dirs(800, 800, sc.fov, 24, 40, 24, 16, 32)
+    tc = build_reference(R, sc, w_class, 800, 800)
+    ref = run_reference(R, tc, dirs, pose, rot)
+    save_case("classroom_n8_aux", sc, dict(w=800, h=800, crop=[24, 40, 24, 16, 32], yaw=100.0, pitch=0.0), dirs, pose, rot, ref, 8,
+              "sample_pavillon_16")
+    sc = O.Scene(view_cell_center=(0.0, 0.0, 0.0), view_cell_size=(2.0, 2.0, 1.0), depth_range=(0.9, 12.0),
+                 fov=1.0, max_depth=12.0, num_samples=8, threshold=0.2, use_ndc=True,
+                 depth_transform="linear", pos_enc=((2, 2), (10, 4)), normalization="None")
+    full = O.generate_ray_directions(480, 270, sc.fov).reshape(270, 480, 3)
+    dirs = np.ascontiguousarray(full[60:76, 100:124].reshape(-1, 3))
+    tc = build_reference(R, sc, w_ndc, 480, 270)
+    ref = run_reference(R, tc, dirs, pose_f, rot_f)
+    save_case("ndc_n8_aux", sc, dict(w=480, h=270, crop=[100, 60, 24, 16], yaw=0.0, pitch=0.0,
+                                     syn=dict(seed=7, n_in0=30, oracle_bias=-0.55, oracle_scale=0.5)),
+              dirs, pose_f, rot_f, ref, 8, "synthetic")
+
     # --- cases K, L: the oracle-output transforms of the other losses on the adaptive path
     #     (src/nerf_raymarch_common.py:686-690): sigmoid (BCEWithLogitsLoss) and softmax (CrossEntropyLoss) before the
     #     threshold test; the kept values then never reach compositing (src/features.py:503)
@@ -415,10 +436,11 @@ def main():
                  accumulation_mult="")
     full = O.generate_ray_directions(480, 270, sc.fov).reshape(270, 480, 3)
     dirs = np.ascontiguousarray(full[100:124, 200:232].reshape(-1, 3))
-    tc = build_reference(R, sc, w_ndc, 480, 270)
+    w_ndc_pdf = O.synthetic_weights(7, n_in0=30, oracle_bias=-0.55, oracle_scale=0.5, alpha_bias=2.3)   # some opaque, some empty rays
+    tc = build_reference(R, sc, w_ndc_pdf, 480, 270)
     ref = run_reference(R, tc, dirs, pose_f, rot_f)
     save_case("ndc_pdf_n8", sc, dict(w=480, h=270, crop=[200, 100, 32, 24], yaw=0.0, pitch=0.0,
-                                     syn=dict(seed=7, n_in0=30, oracle_bias=-0.55, oracle_scale=0.5)),
+                                     syn=dict(seed=7, n_in0=30, oracle_bias=-0.55, oracle_scale=0.5, alpha_bias=2.3)),
               dirs, pose_f, rot_f, ref, 8, "synthetic")
     sc = dataclasses.replace(classroom_scene(8, 0.2), sampler="FromClassifiedDepth", losses0="CrossEntropyLoss", accumulation_mult="")
     dirs = subset_dirs(800, 800, sc.fov, 20, 30, 32, 24, 24)

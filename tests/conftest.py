@@ -40,7 +40,7 @@ def case_weights(meta):
     if tag == "synthetic":
         s = meta["syn"]
         return O.synthetic_weights(s["seed"], n_in0=s.get("n_in0", 90), oracle_bias=s["oracle_bias"],
-                                   oracle_scale=s["oracle_scale"])
+                                   oracle_scale=s["oracle_scale"], alpha_bias=s.get("alpha_bias", 0.0))
     z = np.load(os.path.join(GOLD, "weights_%s.npz" % tag))
     n0 = {k[3:]: z[k] for k in z.files if k.startswith("n0/")}
     n1 = {k[3:]: z[k] for k in z.files if k.startswith("n1/")}
@@ -65,3 +65,5 @@ MULT_CASES = ["classroom_n8_mult_weights", "classroom_n8_mult_none", "classroom_
 TRANSFORM_CASES = ["classroom_n8_bce_thr06", "classroom_n8_ce_thr0012"]
 # FromClassifiedDepth beyond the DONeRF default: under NDC, and with the softmax transform
 PDF_CASES = ["classroom_pdf_n8", "ndc_pdf_n8", "classroom_pdf_ce_n8"]
+# fixtures that also carry the secondary compositing outputs (NeRFOutputDepth, accumulated opacity)
+AUX_CASES = ["classroom_n8_aux", "ndc_n8_aux", "classroom_n8_mult_weights", "classroom_n8_bce_thr06", "ndc_pdf_n8", "classroom_pdf_ce_n8"]
