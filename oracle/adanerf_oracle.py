@@ -79,6 +79,7 @@ class Scene:
     # "FromClassifiedDepthAdaptive" (AdaNeRF) or "FromClassifiedDepth" (DONeRF inverse-CDF sampling)
     sampler: str = "FromClassifiedDepthAdaptive"
     losses0: str = "NeRFWeightMultiplicationLoss"    # losses[0]: BCEWithLogitsLoss -> sigmoid on the oracle output
+    ray_sample_input: int = 0                        # raySampleInput[0]: extra encoded points along the ray in the oracle input
 
     @property
     def radius(self) -> float:
@@ -87,8 +88,8 @@ class Scene:
 
     @property
     def n_in0(self) -> int:
-        fp, fd = self.pos_enc[0]
-        return 3 + 6 * fp + 3 + 6 * fd
+        fp, fd = self.pos_enc[0]      # src/features.py:738-740
+        return (self.ray_sample_input * 3 + 3) * (2 * fp + 1) + 3 + 6 * fd
 
     @property
     def n_in1(self) -> int:
@@ -131,6 +132,8 @@ def load_scene(model_dir: str, num_samples: Optional[int] = None,
     sc.sampler = "FromClassifiedDepth" if smp[-1] == "FromClassifiedDepth" else "FromClassifiedDepthAdaptive"
     ls = _parse_list(kv.get("losses", "[NeRFWeightMultiplicationLoss,MSE]"))
     sc.losses0 = ls[0] if ls else "NeRFWeightMultiplicationLoss"
+    rsi = _parse_list(kv.get("raySampleInput", "[0,0]"))
+    sc.ray_sample_input = int(rsi[0]) if rsi else 0
     if num_samples is not None:
         sc.num_samples = num_samples
     if threshold is not None:
@@ -268,11 +271,14 @@ def load_weights(model_dir: str) -> Weights:
 
 
 def synthetic_weights(seed: int, n_in0: int = 90, n_in1_pos: int = 63, n_in1_dir: int = 27,
-                      oracle_bias: float = 0.0, oracle_scale: float = 1.0, alpha_bias: float = 0.0) -> Weights:
+                      oracle_bias: float = 0.0, oracle_scale: float = 1.0, alpha_bias: float = 0.0,
+                      layers: Tuple[int, int] = (8, 8), widths: Tuple[int, int] = (256, 256), skip1: int = 4) -> Weights:
     """Seeded Kaiming-normal weights in the exported layout (nn.init.kaiming_normal_ as
     src/models.py:77-78, 246-250: std = sqrt(2/fan_in)); biases U(-1/sqrt(fan_in), ..) like
     nn.Linear's default.  ``oracle_bias`` is added to the sampling net's last bias so a
-    chosen fraction of outputs clears the threshold (SURVEY §8d "W-syn")."""
+    chosen fraction of outputs clears the threshold (SURVEY §8d "W-syn").  ``layers`` / ``widths`` / ``skip1``: depth
+    and width of the two networks and the NeRF trunk's skip index (src/models.py:18-82, 199-250; defaults = every
+    shipped config)."""
     rng = np.random.default_rng(seed)
 
     def lin(n_out, n_in, scale=1.0):
@@ -282,21 +288,23 @@ def synthetic_weights(seed: int, n_in0: int = 90, n_in1_pos: int = 63, n_in1_dir
         return w, b
 
     n0: Dict[str, np.ndarray] = {}
-    dims = [n_in0] + [256] * 7 + [128]
-    for i in range(8):
-        w, b = lin(dims[i + 1], dims[i], oracle_scale if i == 7 else 1.0)
-        if i == 7:
+    d0, w0 = layers[0], widths[0]
+    dims = [n_in0] + [w0] * (d0 - 1) + [D_BINS]
+    for i in range(d0):
+        w, b = lin(dims[i + 1], dims[i], oracle_scale if i == d0 - 1 else 1.0)
+        if i == d0 - 1:
             b = (b + oracle_bias).astype(F32)
         n0["layers.%d.weight" % i] = w
         n0["layers.%d.bias" % i] = b
     n1: Dict[str, np.ndarray] = {}
-    for i in range(8):
-        k = n_in1_pos if i == 0 else (256 + n_in1_pos if i == 5 else 256)
-        w, b = lin(256, k)
+    d1, w1 = layers[1], widths[1]
+    for i in range(d1):
+        k = n_in1_pos if i == 0 else (w1 + n_in1_pos if i == skip1 + 1 else w1)
+        w, b = lin(w1, k)
         n1["pts_linears.%d.weight" % i] = w
         n1["pts_linears.%d.bias" % i] = b
-    for nm, (o, k) in {"views_linears.0": (128, 256 + n_in1_dir), "feature_linear": (256, 256),
-                       "alpha_linear": (1, 256), "rgb_linear": (3, 128)}.items():
+    for nm, (o, k) in {"views_linears.0": (w1 // 2, w1 + n_in1_dir), "feature_linear": (w1, w1),
+                       "alpha_linear": (1, w1), "rgb_linear": (3, w1 // 2)}.items():
         w, b = lin(o, k)
         n1[nm + ".weight"] = w
         n1[nm + ".bias"] = b
@@ -324,7 +332,7 @@ def write_model_dir(path: str, scene: Scene, weights: Weights) -> None:
         f.write("numRaymarchSamples = [%d, %d]\n" % (scene.num_samples, scene.num_samples))
         f.write("rayMarchSamplingStep = [0.0078125, 0.0078125]\n")
         f.write("rayMarchSamplingNoise = [0.0, 0.0]\n")
-        f.write("raySampleInput = [0, 0]\n")
+        f.write("raySampleInput = [%d, 0]\n" % scene.ray_sample_input)
         f.write("depthTransform = %s\n" % scene.depth_transform)
         f.write("zNear = [%r, %r]\n" % (scene.z_near, scene.z_near))
         f.write("zFar = [%r, %r]\n" % (scene.z_far, scene.z_far))
@@ -423,11 +431,33 @@ def world_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: S
 
 
 def oracle_features(nds: np.ndarray, p: np.ndarray, scene: Scene) -> np.ndarray:
-    """src/features.py:868-874: [PE_dir(nds/||nds||) | PE_pos(p)]."""
+    """src/features.py:868-888: [PE_dir(nds/||nds||) | PE_pos(p)] and, for raySampleInput = A > 0, the A points
+    p + nds * z_a (z_a = to_world of the A bin centres of [0,1]) encoded as PE_pos(x / d1) with the identity part
+    scaled back by d1 (d1 = upper end of the warped depth range) -- A * (3 + 6 fp) more columns."""
     fp, fd = scene.pos_enc[0]
     nrm = np.sqrt(np.sum(nds * nds, axis=-1, keepdims=True, dtype=F32)).astype(F32)
-    return np.concatenate([positional_encoding((nds / nrm).astype(F32), fd),
-                           positional_encoding(p, fp)], axis=-1).astype(F32)
+    cols = [positional_encoding((nds / nrm).astype(F32), fd), positional_encoding(p, fp)]
+    a = scene.ray_sample_input
+    if a:
+        zs = ray_sample_depths(scene)
+        d1 = F32(scene.depth_range[1])
+        pts = (p[:, None, :] + nds[:, None, :] * zs[None, :, None]).astype(F32)            # [R, A, 3]
+        enc = positional_encoding((pts / d1).astype(F32), fp)                               # [R, A, 3 + 6 fp]
+        enc[..., :3] = (enc[..., :3] * d1).astype(F32)
+        cols.append(enc.reshape(pts.shape[0], -1))
+    return np.concatenate(cols, axis=-1).astype(F32)
+
+
+def ray_sample_depths(scene: Scene) -> np.ndarray:
+    """World depths of the raySampleInput points: to_world(linspace(step/2, 1 - step/2, A)), step = 1/A
+    (src/features.py:876-881; always through the depth range, also for NDC scenes)."""
+    a = scene.ray_sample_input
+    step = 1.0 / a
+    t = np.linspace(step / 2, 1.0 - step / 2, a, dtype=F32)
+    d0, d1 = scene.depth_range
+    if scene.depth_transform == "log":
+        return (np.power(F32((d1 - d0) + 1), t).astype(F32) - F32(1.0) + F32(d0)).astype(F32)
+    return (t * F32(d1 - d0) + F32(d0)).astype(F32)
 
 
 # --------------------------------------------------------------------------------------
@@ -469,6 +499,15 @@ def sampling_mlp(x: np.ndarray, net0: Dict[str, np.ndarray]) -> np.ndarray:
     return h
 
 
+def shading_topology(net1: Dict[str, np.ndarray], n_pos: int):
+    """(depth D, skip indices) of an exported NeRF trunk: layer i + 1 takes cat([input_pts, h]) iff i is a skip
+    (src/models.py:226-228, 257-261), i.e. iff its weight has W + n_pos columns."""
+    depth = len([k for k in net1 if k.startswith("pts_linears.") and k.endswith(".weight")])
+    width = net1["pts_linears.0.weight"].shape[0]
+    skips = [i - 1 for i in range(1, depth) if net1["pts_linears.%d.weight" % i].shape[1] == width + n_pos]
+    return depth, skips
+
+
 def shading_mlp(x: np.ndarray, net1: Dict[str, np.ndarray], n_pos: int = 63) -> np.ndarray:
     """src/models.py:254-277 (NeRF.forward, skips=[4], use_viewdirs=True) -> [rgb(3), alpha(1)] raw."""
     if _MATMUL == "torch":
@@ -476,9 +515,10 @@ def shading_mlp(x: np.ndarray, net1: Dict[str, np.ndarray], n_pos: int = 63) -> 
     x = x.astype(F32)
     pts, views = x[:, :n_pos], x[:, n_pos:]
     h = pts
-    for i in range(8):
+    depth, skips = shading_topology(net1, n_pos)
+    for i in range(depth):
         h = np.maximum(_linear(h, net1["pts_linears.%d.weight" % i], net1["pts_linears.%d.bias" % i]), F32(0))
-        if i == 4:
+        if i in skips:
             h = np.concatenate([pts, h], axis=-1)
     alpha = _linear(h, net1["alpha_linear.weight"], net1["alpha_linear.bias"])
     feat = _linear(h, net1["feature_linear.weight"], net1["feature_linear.bias"])
@@ -514,9 +554,10 @@ def _torch_shading_mlp(x, net1, n_pos):
         pts, views = x[:, :n_pos], x[:, n_pos:]
         lin = lambda h, nm: torch.addmm(_tt(net1[nm + ".bias"]), h, _tt(net1[nm + ".weight"]).t())
         h = pts
-        for i in range(8):
+        depth, skips = shading_topology(net1, n_pos)
+        for i in range(depth):
             h = lin(h, "pts_linears.%d" % i).relu_()
-            if i == 4:
+            if i in skips:
                 h = torch.cat([pts, h], -1)
         alpha = lin(h, "alpha_linear")
         feat = lin(h, "feature_linear")

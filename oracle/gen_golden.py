@@ -49,8 +49,15 @@ def import_reference():
                            nrc=nerf_raymarch_common, train_data=train_data, dt=dt)
 
 
-def make_config(scene: O.Scene):
+def make_config(scene: O.Scene, weights=None):
     n = scene.num_samples
+    layers, widths, skips = [8, 8], [256, 256], ["", "auto"]
+    if weights is not None:      # topology of the two networks as the training config states it (src/models.py:362-370)
+        d0 = len([k for k in weights.net0 if k.endswith(".weight")])
+        d1, sk = O.shading_topology(weights.net1, 3 + 6 * scene.pos_enc[1][0])
+        layers = [d0, d1]
+        widths = [int(weights.net0["layers.0.weight"].shape[0]), int(weights.net1["pts_linears.0.weight"].shape[0])]
+        skips = ["", "auto" if (d1 == 8 and sk == [4]) else (str(sk[0]) if sk else "99")]
     sampler = "FromClassifiedDepthAdaptiveNoDepthRange" if scene.use_ndc else "FromClassifiedDepthAdaptive"
     if scene.sampler == "FromClassifiedDepth":
         sampler = "FromClassifiedDepth"
@@ -58,9 +65,9 @@ def make_config(scene: O.Scene):
         inFeatures=["SpherePosDir", "RayMarchFromPoses"], outFeatures=["Raw", "RGBARayMarch"],
         posEnc=["nerf", "nerf"],
         posEncArgs=["%d-%d" % scene.pos_enc[0], "%d-%d" % scene.pos_enc[1]],
-        raySampleInput=[0, 0], multiDepthFeatures=[128, 128], multiDepthIgnoreValue=[1.01, 1.01],
-        multiDepthWindowSize=[], activation=["relu", "nerf"], layers=[8, 8], layerWidth=[256, 256],
-        skips=["", "auto"], losses=[scene.losses0, "MSE"],
+        raySampleInput=[scene.ray_sample_input, 0], multiDepthFeatures=[128, 128], multiDepthIgnoreValue=[1.01, 1.01],
+        multiDepthWindowSize=[], activation=["relu", "nerf"], layers=layers, layerWidth=widths,
+        skips=skips, losses=[scene.losses0, "MSE"],
         numRaymarchSamples=[n, n], rayMarchSampler=["none", sampler],
         rayMarchSamplingStep=[1 / 128.0, 1 / 128.0], rayMarchSamplingNoise=[0.0, 0.0],
         rayMarchNormalization=["InverseSqrtDistCentered", scene.normalization],
@@ -81,7 +88,7 @@ class Wrapper:
 
 def build_reference(R, scene: O.Scene, weights: O.Weights, w, h):
     torch = R.torch
-    cfg = make_config(scene)
+    cfg = make_config(scene, weights)
     f_in, f_out = R.features.FeatureSet.get_sets(cfg, "cpu")
     view = SimpleNamespace(fov=scene.fov, focal=O.focal_from_fov(w, scene.fov),
                            view_cell_center=list(scene.view_cell_center),
@@ -207,8 +214,8 @@ def save_case(name, scene, meta, dirs, pose, rot, ref, n_max, weights_tag):
                   z_far=scene.z_far, use_ndc=scene.use_ndc, depth_transform=scene.depth_transform,
                   pos_enc=[list(scene.pos_enc[0]), list(scene.pos_enc[1])],
                   normalization=scene.normalization, accumulation_mult=scene.accumulation_mult,
-                  sampler=scene.sampler, losses0=scene.losses0, weights=weights_tag))
-    n_f = min(64, ref["feat0"].shape[0])
+                  sampler=scene.sampler, losses0=scene.losses0, ray_sample_input=scene.ray_sample_input, weights=weights_tag))
+    n_f = min(64, ref["feat0"].shape[0], max(4, 65536 // ref["feat0"].shape[1]))
     m_f = min(64, ref["feat1"].shape[0])
     raw = ref["raw"].astype(np.float32)
     if raw.shape[0] > 40000:      # dense: keep the first 32 rays' samples only
@@ -399,6 +406,21 @@ def main():
         ref = run_reference(R, tc, dirs, pose, rot)
         save_case(name, sc, dict(w=800, h=800, crop=[20, 30, 24, 16, 32], yaw=100.0, pitch=0.0), dirs, pose, rot, ref, 8,
                   "sample_pavillon_16")
+
+    # --- cases Q, R, S: other topologies than 8 x 256 / skip 4 through the reference's own model
+    #     classes (BaseNet / NeRF, src/models.py:18-82, 199-277), and the raySampleInput oracle input (src/features.py:876-888)
+    base = classroom_scene(8, 0.65)      # random-init outputs spread over [-0.8, 0.9]: ~6 of 128 clear 0.65
+    for name, syn, rsi in [("syn_6x128_skip2", dict(seed=21, layers=[6, 6], widths=[128, 128], skip1=2, oracle_bias=0.1, oracle_scale=0.3), 0),
+                           ("syn_d2w128_d3w256_skip1", dict(seed=22, layers=[2, 3], widths=[128, 256], skip1=1, oracle_bias=0.1, oracle_scale=0.3), 0),
+                           ("syn_rsi128_4x128", dict(seed=23, layers=[4, 8], widths=[128, 256], skip1=4, oracle_bias=0.1, oracle_scale=0.3), 128)]:
+        sc = dataclasses.replace(base, ray_sample_input=rsi)
+        wts = O.synthetic_weights(syn["seed"], n_in0=sc.n_in0, oracle_bias=syn["oracle_bias"], oracle_scale=syn["oracle_scale"],
+                                  layers=tuple(syn["layers"]), widths=tuple(syn["widths"]), skip1=syn["skip1"])
+        dirs = subset_dirs(400, 400, sc.fov, 12, 20, 24, 16, 16)
+        tc = build_reference(R, sc, wts, 400, 400)
+        ref = run_reference(R, tc, dirs, pose, rot)
+        save_case(name, sc, dict(w=400, h=400, crop=[12, 20, 24, 16, 16], yaw=100.0, pitch=0.0, syn=dict(syn, n_in0=sc.n_in0)),
+                  dirs, pose, rot, ref, 8, "synthetic")
 
     # --- cases O, P: small crops that carry the secondary compositing outputs (all cases written from now on do)
     sc = classroom_scene(8, 0.2)

@@ -27,7 +27,7 @@ def load_case(name):
                  pos_enc=(tuple(meta["pos_enc"][0]), tuple(meta["pos_enc"][1])),
                  normalization=meta["normalization"], accumulation_mult=meta["accumulation_mult"],
                  sampler=meta.get("sampler", "FromClassifiedDepthAdaptive"),
-                 losses0=meta.get("losses0", "NeRFWeightMultiplicationLoss"))
+                 losses0=meta.get("losses0", "NeRFWeightMultiplicationLoss"), ray_sample_input=meta.get("ray_sample_input", 0))
     return z, meta, sc
 
 
@@ -40,7 +40,8 @@ def case_weights(meta):
     if tag == "synthetic":
         s = meta["syn"]
         return O.synthetic_weights(s["seed"], n_in0=s.get("n_in0", 90), oracle_bias=s["oracle_bias"],
-                                   oracle_scale=s["oracle_scale"], alpha_bias=s.get("alpha_bias", 0.0))
+                                   oracle_scale=s["oracle_scale"], alpha_bias=s.get("alpha_bias", 0.0),
+                                   layers=tuple(s.get("layers", (8, 8))), widths=tuple(s.get("widths", (256, 256))), skip1=s.get("skip1", 4))
     z = np.load(os.path.join(GOLD, "weights_%s.npz" % tag))
     n0 = {k[3:]: z[k] for k in z.files if k.startswith("n0/")}
     n1 = {k[3:]: z[k] for k in z.files if k.startswith("n1/")}
@@ -66,4 +67,6 @@ TRANSFORM_CASES = ["classroom_n8_bce_thr06", "classroom_n8_ce_thr0012"]
 # FromClassifiedDepth beyond the DONeRF default: under NDC, and with the softmax transform
 PDF_CASES = ["classroom_pdf_n8", "ndc_pdf_n8", "classroom_pdf_ce_n8"]
 # fixtures that also carry the secondary compositing outputs (NeRFOutputDepth, accumulated opacity)
+# topologies other than 8 x 256 / skip 4, and the raySampleInput oracle input
+TOPOLOGY_CASES = ["syn_6x128_skip2", "syn_d2w128_d3w256_skip1", "syn_rsi128_4x128"]
 AUX_CASES = ["classroom_n8_aux", "ndc_n8_aux", "classroom_n8_mult_weights", "classroom_n8_bce_thr06", "ndc_pdf_n8", "classroom_pdf_ce_n8"]
