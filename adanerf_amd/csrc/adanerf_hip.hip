@@ -15,6 +15,7 @@
 #include "format.hpp"
 #include "kernels.hip.hpp"
 #include "launch_f32.hpp"
+#include "k_generic_f32.hip.hpp"   // GenericTopo (the kernels themselves live in launch_f32.hip)
 #include "pack.hpp"
 
 using namespace adanerf;
@@ -54,6 +55,12 @@ struct adanerf_ctx {
   int mult_mode = 1;   // 0 none, 1 alpha, 2 weights
   int transform = 0;   // kOracle*: sampler's transform of the raw oracle outputs (losses[0])
   int fp0 = 10, fd0 = 4, fp1 = 10, fd1 = 4;
+  int ray_samples = 0;            // raySampleInput[0]
+  NetTopology topo0, topo1;       // read off the ONNX initializers
+  bool generic0 = false, generic1 = false;   // not the 8 x 256 (/ skip 4) topology: the run-time-shaped fp32 kernels (k_generic_f32.hip.hpp)
+  GenericTopo gen0{}, gen1{};
+  DevBuf rsi_z;                   // [ray_samples] world depths of the raySampleInput points
+  int shade_gen_grid = 0;
 
   PackedDev net0;                 // sampling net, fp32 fragments (exact engine)
   PackedDev net0_split;           // sampling net, fp16 hi/lo' fragment pairs (split-precision engine)
@@ -142,6 +149,8 @@ struct ModelSetup {
   int mult_mode = 1;
   int transform = 0;
   int fp0 = 10, fd0 = 4, fp1 = 10, fd1 = 4;
+  int ray_samples = 0;
+  std::vector<float> rsi_z;
   std::vector<float> ztab;
   DepthMap dm{};
 };
@@ -186,8 +195,10 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
     const std::string l0 = cf.losses.empty() ? std::string(pdf_mode ? "BCEWithLogitsLoss" : "NeRFWeightMultiplicationLoss") : cf.losses[0];
     ms->transform = l0 == "BCEWithLogitsLoss" ? kOracleSigmoid : ((l0 == "CrossEntropyLoss" || l0 == "CrossEntropyLossWeighted") ? kOracleSoftmax : kOracleRaw);
   }
-  for (int v : cf.raySampleInput)
-    if (v != 0) return bad(ADANERF_EUNSUPPORTED, "raySampleInput != 0 is outside the supported path");
+  // raySampleInput[0] = A > 0: A extra encoded points along the ray in the oracle net's input (src/features.py:876-888);
+  // the shading net takes no such input on this path (RayMarchFromPoses ignores the key)
+  ms->ray_samples = cf.raySampleInput.empty() ? 0 : cf.raySampleInput[0];
+  if (ms->ray_samples < 0 || ms->ray_samples > 1024) return bad(ADANERF_EUNSUPPORTED, "raySampleInput[0] must be in 0..1024");
   if (cf.viewcellCenter.size() != 3 || cf.viewcellSize.size() != 3 || cf.depthRange.size() != 2 || cf.fov <= 0.f)
     return bad(ADANERF_EIO, "dataset_info.txt: view_cell_center/view_cell_size/depth_range/fov missing or malformed");
   if (cf.numRaymarchSamples.empty()) return bad(ADANERF_EIO, "config.ini: numRaymarchSamples missing");
@@ -244,7 +255,7 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   // sample offsets, keys and totals are int32 on the device
   if (static_cast<int64_t>(I.batch_rays) * n_max > 0x7fffffffll)
     return bad(ADANERF_EINVAL, "batch_rays * num_samples exceeds 2^31 - 1; use a smaller batch (-bs)");
-  I.n_in0 = 6 + 6 * (ms->fp0 + ms->fd0);
+  I.n_in0 = (ms->ray_samples * 3 + 3) * (2 * ms->fp0 + 1) + 3 + 6 * ms->fd0;     // src/features.py:738-740
   I.n_in1 = 6 + 6 * (ms->fp1 + ms->fd1);
   I.num_samples = n_max;
   I.threshold = thr;
@@ -300,6 +311,16 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   ms->dm.d0 = cf.depthRange[0];
   ms->dm.d1 = cf.depthRange[1];
   ms->dm.log_transform = cf.depthTransform == "log";
+  // world depths of the raySampleInput points: to_world(linspace(step/2, 1 - step/2, A)), always through the depth range
+  for (int a = 0; a < ms->ray_samples; ++a) {
+    const float step2 = static_cast<float>(0.5 / ms->ray_samples), end = static_cast<float>(1.0 - 0.5 / ms->ray_samples);
+    // torch.linspace(start, end, A): start + a * (end - start) / (A - 1) in fp32 (symmetric form for the upper half)
+    const int A = ms->ray_samples;
+    const float inc = A > 1 ? (end - step2) / static_cast<float>(A - 1) : 0.f;
+    const float t = (a < A / 2) ? step2 + inc * static_cast<float>(a) : end - inc * static_cast<float>(A - 1 - a);
+    const float d0 = cf.depthRange[0], d1 = cf.depthRange[1];
+    ms->rsi_z.push_back(ms->dm.log_transform ? powf(static_cast<float>(static_cast<double>(d1) - d0 + 1.0), t) - 1.0f + d0 : t * (d1 - d0) + d0);
+  }
   // ---- depth table: world depth of each of the 128 bins (A4/A5) ----
   ms->ztab.resize(kBins);
   const float znear = cf.zNear.empty() ? 0.001f : cf.zNear.back();
@@ -329,7 +350,7 @@ int ensure_net1(adanerf_ctx* c, int prec) {
   if (c->net1[prec].w.p) return ADANERF_OK;
   PackedNet pn;
   std::string err;
-  NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1};
+  NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1, c->ray_samples};
   if (!pack_shading_net(c->net1_host, sh, elem_of(prec), &pn, &err)) return fail(c, ADANERF_EIO, "model1.onnx: " + err);
   return upload_net(c, pn, &c->net1[prec]);
 }
@@ -406,13 +427,18 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
   a.rays_out = d_rays;
   dim3 grid((n_rays + 127) / 128), block(256);
   const bool full = c->fp0 == 10 && c->fd0 == 4;
+  if (c->generic0) {      // any other topology / raySampleInput: run-time-shaped fp32 kernel, whatever sampling_mode asks for
+    if (sel) return fail(c, ADANERF_EINVAL, "fused selection is not available on the generic sampling kernel");
+    HIP_TRY(c, launch_sample_mlp_gen(a, c->gen0, full, c->topo0.width, grid.x, c->stream));
+    return ADANERF_OK;
+  }
   if (c->sampling_mode == 1) {
     HIP_TRY(c, launch_sample_mlp_f32(a, full, grid.x, c->stream));
   } else if (c->sampling_mode == 2) {
     if (!c->net0_f16.w.p) {
       PackedNet pn;
       std::string err;
-      NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1};
+      NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1, c->ray_samples};
       if (!pack_sampling_net(c->net0_host, sh, Elem::F16, &pn, &err)) return fail(c, ADANERF_EIO, "model0.onnx: " + err);
       int rc = upload_net(c, pn, &c->net0_f16);
       if (rc) return rc;
@@ -507,6 +533,7 @@ constexpr int kShadeWaves = ADN_SHADE_WAVES;
 int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, const int32_t* d_total, int max_samples, int prec,
                      float* d_raw, const float* d_z = nullptr) {
   if (max_samples <= 0) return ADANERF_OK;
+  if (c->generic1) prec = ADANERF_PREC_FP32;      // other topologies run on the fp32 engine whatever precision is asked for
   int rc = ensure_net1(c, prec);
   if (rc) return rc;
   ShadeArgs a{};
@@ -519,7 +546,11 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
   a.max_samples = max_samples;
   a.raw_out = d_raw;
   if (c->fp1 != 10 || c->fd1 != 4) return fail(c, ADANERF_EUNSUPPORTED, "shading net posEncArgs must be 10-4");
-  if (prec == ADANERF_PREC_FP32) {
+  if (c->generic1) {
+    if (!c->shade_gen_grid) HIP_TRY(c, shade_mlp_gen_grid(c->info.compute_units, c->topo1.width, &c->shade_gen_grid));
+    const int tiles = (max_samples + 127) / 128;
+    HIP_TRY(c, launch_shade_mlp_gen(a, c->gen1, c->topo1.width, std::min(tiles, c->shade_gen_grid), c->stream));
+  } else if (prec == ADANERF_PREC_FP32) {
     if (!c->shade_grid[2]) HIP_TRY(c, shade_mlp_f32_grid(c->info.compute_units, &c->shade_grid[2]));
     const int tiles = (max_samples + 127) / 128;
     HIP_TRY(c, launch_shade_mlp_f32(a, std::min(tiles, c->shade_grid[2]), c->stream));
@@ -630,13 +661,27 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   TensorMap& n0 = c->net0_host;
   if (!read_onnx_initializers(join_path(model_dir, "model0.onnx"), &n0, &err)) return bail(ADANERF_EIO, err);
   if (!read_onnx_initializers(join_path(model_dir, "model1.onnx"), &c->net1_host, &err)) return bail(ADANERF_EIO, err);
-  NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1};
+  c->ray_samples = ms.ray_samples;
+  NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1, c->ray_samples};
   PackedNet p0, p1;
   if (!pack_sampling_net(n0, sh, Elem::F32, &p0, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
+  c->topo0 = p0.topo;
+  c->generic0 = !p0.topo.is_default(false);
   PackedNet p0s;
-  if (!pack_sampling_net(n0, sh, Elem::F16_SPLIT, &p0s, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
+  if (!c->generic0 && !pack_sampling_net(n0, sh, Elem::F16_SPLIT, &p0s, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
   c->sampling_mode = opt->sampling_mode;
-  if (!pack_shading_net(c->net1_host, sh, elem_of(opt->precision), &p1, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
+  {   // topology of the shading net first (fp32 packing accepts every supported topology)
+    PackedNet probe;
+    if (!pack_shading_net(c->net1_host, sh, Elem::F32, &probe, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
+    c->topo1 = probe.topo;
+    c->generic1 = !probe.topo.is_default(true);
+    if (c->generic1 || opt->precision == ADANERF_PREC_FP32) p1 = std::move(probe);
+    else if (!pack_shading_net(c->net1_host, sh, elem_of(opt->precision), &p1, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
+  }
+  // the run-time-shaped fp32 kernels are instantiated for these widths (k_generic_f32.hip.hpp)
+  auto width_ok = [](int w) { return w == 64 || w == 128 || w == 256; };
+  if (c->generic0 && !width_ok(c->topo0.width)) return bail(ADANERF_EUNSUPPORTED, "model0.onnx: layer width " + std::to_string(c->topo0.width) + " (64, 128 or 256 supported)");
+  if (c->generic1 && !width_ok(c->topo1.width)) return bail(ADANERF_EUNSUPPORTED, "model1.onnx: layer width " + std::to_string(c->topo1.width) + " (64, 128 or 256 supported)");
 
   // ---- device ----
   int n_dev = 0;
@@ -658,10 +703,17 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     return bail(ADANERF_EDEVICE, "ztab upload failed");
   c->sp.ztab = reinterpret_cast<const float*>(c->ztab.p);
   if ((rc = upload_net(c, p0, &c->net0))) return bail(rc, c->err);
-  if ((rc = upload_net(c, p0s, &c->net0_split))) return bail(rc, c->err);
+  if (!c->generic0 && (rc = upload_net(c, p0s, &c->net0_split))) return bail(rc, c->err);
+  if (c->ray_samples > 0) {
+    if ((rc = dev_alloc(c, &c->rsi_z, ms.rsi_z.size() * sizeof(float)))) return bail(rc, c->err);
+    if (hipMemcpy(c->rsi_z.p, ms.rsi_z.data(), ms.rsi_z.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+      return bail(ADANERF_EDEVICE, "raySampleInput depth table upload failed");
+  }
+  c->gen0 = GenericTopo{c->topo0.depth, -1, c->ray_samples, p0.rsi_w_off, reinterpret_cast<const float*>(c->rsi_z.p), c->cfg.depthRange[1]};
+  c->gen1 = GenericTopo{c->topo1.depth, c->topo1.skip, 0, 0, nullptr, 0.f};
   if ((rc = dev_alloc(c, &c->overflow, 64))) return bail(rc, c->err);
   if (hipMemset(c->overflow.p, 0, 64) != hipSuccess) return bail(ADANERF_EDEVICE, "hipMemset failed");
-  if ((rc = upload_net(c, p1, &c->net1[opt->precision]))) return bail(rc, c->err);
+  if ((rc = upload_net(c, p1, &c->net1[c->generic1 ? ADANERF_PREC_FP32 : opt->precision]))) return bail(rc, c->err);
   if ((rc = ensure_batch_buffers(c, c->info.batch_rays, c->info.num_samples))) return bail(rc, c->err);
   *out = c;
   return ADANERF_OK;
@@ -697,7 +749,7 @@ int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precis
   if (!cfg.load(model_dir, &err)) return fail(nullptr, ADANERF_EIO, err);
   if (cfg.posEncArgs.size() != 2) return fail(nullptr, ADANERF_EIO, "posEncArgs missing");
   NetShape sh{static_cast<int>(cfg.posEncArgs[0][0]), static_cast<int>(cfg.posEncArgs[0][1]), static_cast<int>(cfg.posEncArgs[1][0]),
-              static_cast<int>(cfg.posEncArgs[1][1])};
+              static_cast<int>(cfg.posEncArgs[1][1]), cfg.raySampleInput.empty() ? 0 : cfg.raySampleInput[0]};
   TensorMap tm;
   if (!read_onnx_initializers(join_path(model_dir, net == 0 ? "model0.onnx" : "model1.onnx"), &tm, &err)) return fail(nullptr, ADANERF_EIO, err);
   PackedNet pn;
@@ -711,18 +763,27 @@ int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precis
     if (*bias_floats < pn.bias.size()) return fail(nullptr, ADANERF_EINVAL, "bias_out too small");
     std::memcpy(bias_out, pn.bias.data(), pn.bias.size() * sizeof(float));
   }
+  const bool rsi = net == 0 && pn.topo.ray_samples > 0;     // one more record: the raySampleInput block of layer 0
+  const int32_t n_rec = static_cast<int32_t>(pn.w_off.size()) + (rsi ? 1 : 0);
   if (layer_out) {
-    if (*n_layers < static_cast<int32_t>(pn.w_off.size())) return fail(nullptr, ADANERF_EINVAL, "layer_out too small");
+    if (*n_layers < n_rec) return fail(nullptr, ADANERF_EINVAL, "layer_out too small");
     for (size_t i = 0; i < pn.w_off.size(); ++i) {
       layer_out[4 * i + 0] = static_cast<int32_t>(pn.w_off[i]);
       layer_out[4 * i + 1] = static_cast<int32_t>(pn.b_off[i]);
       layer_out[4 * i + 2] = pn.slots[i];
       layer_out[4 * i + 3] = pn.mtiles[i];
     }
+    if (rsi) {
+      const size_t i = pn.w_off.size();
+      layer_out[4 * i + 0] = static_cast<int32_t>(pn.rsi_w_off);
+      layer_out[4 * i + 1] = pn.topo.ray_samples;
+      layer_out[4 * i + 2] = pe_slots(sh.fp0);
+      layer_out[4 * i + 3] = pn.mtiles[0];
+    }
   }
   *weights_bytes = pn.weights.size();
   *bias_floats = pn.bias.size();
-  *n_layers = static_cast<int32_t>(pn.w_off.size());
+  *n_layers = n_rec;
   return ADANERF_OK;
 }
 
@@ -735,7 +796,7 @@ int adanerf_destroy(adanerf_ctx* c) {
   for (int32_t* p : c->pinned_totals) (void)hipHostFree(p);
   DevBuf* bufs[] = {&c->net0_split.w, &c->net0_split.b, &c->net0_f16.w, &c->net0_f16.b, &c->overflow, &c->net0.w, &c->net0.b, &c->net1[0].w, &c->net1[0].b, &c->net1[1].w, &c->net1[1].b, &c->net1[2].w, &c->net1[2].b,
                     &c->ztab, &c->rays, &c->oracle, &c->ray_offsets, &c->ray_counts, &c->selbin, &c->selw, &c->block_total,
-                    &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw, &c->sample_z};
+                    &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw, &c->sample_z, &c->rsi_z};
   for (DevBuf* b : bufs) dev_free(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -769,8 +830,10 @@ int adanerf_ray_features(adanerf_ctx* c, int32_t first_ray, int32_t n_rays, floa
   if (first_ray < 0 || n_rays < 0 || first_ray + n_rays > c->info.rays_local) return fail(c, ADANERF_EINVAL, "ray range outside this context's rays");
   if (n_rays == 0) return ADANERF_OK;
   dim3 grid((n_rays + 255) / 256), block(256);
-  if (c->fp0 == 10) hipLaunchKernelGGL((ray_features_kernel<10, 4>), grid, block, 0, c->stream, c->rg, first_ray, n_rays, d_feat, d_rays);
-  else hipLaunchKernelGGL((ray_features_kernel<2, 2>), grid, block, 0, c->stream, c->rg, first_ray, n_rays, d_feat, d_rays);
+  const float* rz = reinterpret_cast<const float*>(c->rsi_z.p);
+  const float d1 = c->cfg.depthRange[1];
+  if (c->fp0 == 10) hipLaunchKernelGGL((ray_features_kernel<10, 4>), grid, block, 0, c->stream, c->rg, first_ray, n_rays, d_feat, d_rays, c->ray_samples, rz, d1);
+  else hipLaunchKernelGGL((ray_features_kernel<2, 2>), grid, block, 0, c->stream, c->rg, first_ray, n_rays, d_feat, d_rays, c->ray_samples, rz, d1);
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;
 }
@@ -976,7 +1039,7 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     const bool pdf = c->info.sampler_mode == ADANERF_SAMPLER_PDF;
     // adaptive selection in the epilogue of the sampling kernel: the [R,128] oracle values never reach HBM
-    const bool fused = !pdf && thr > 0.f && use_pair_select(c, N) && c->sampling_mode != 1 && !(c->opt.flags & ADANERF_FLAG_KEEP_ORACLE);
+    const bool fused = !pdf && thr > 0.f && use_pair_select(c, N) && c->sampling_mode != 1 && !c->generic0 && !(c->opt.flags & ADANERF_FLAG_KEEP_ORACLE);
     if (fused) {
       const SelectOut so = select_out(c, N, thr, cnt);
       rc = launch_sample_mlp(c, first, n, nullptr, rays, &so);

@@ -114,8 +114,11 @@ __global__ __launch_bounds__(256) void sample_mlp_kernel(SampleArgs a) {
 }
 
 // Debug/parity: explicit oracle-net input features in the reference's column order.
+// ray_samples > 0 (raySampleInput): A more blocks of 3 + 6 FP columns, the points p + d z_a encoded as the reference does
+// (src/features.py:876-888: encode(x / d1), identity part scaled back by d1).
 template <int FP, int FD>
-__global__ __launch_bounds__(256) void ray_features_kernel(RayGenParams g, int first_ray, int n_rays, float* feat, float* rays_out) {
+__global__ __launch_bounds__(256) void ray_features_kernel(RayGenParams g, int first_ray, int n_rays, float* feat, float* rays_out,
+                                                           int ray_samples, const float* rsi_z, float rsi_d1) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rays) return;
   int col, row;
@@ -125,7 +128,20 @@ __global__ __launch_bounds__(256) void ray_features_kernel(RayGenParams g, int f
   unit3(nds, u);
   if (feat) {
     constexpr int ND = 3 + 6 * FD, NP = 3 + 6 * FP;
-    float* f = feat + static_cast<size_t>(i) * (ND + NP);
+    float* f = feat + static_cast<size_t>(i) * (ND + NP + ray_samples * NP);
+    for (int a = 0; a < ray_samples; ++a) {
+      float* fa = f + ND + NP + a * NP;
+      for (int c = 0; c < 3; ++c) {
+        const float x = __fadd_rn(p[c], __fmul_rn(nds[c], rsi_z[a])) / rsi_d1;
+        fa[c] = __fmul_rn(x, rsi_d1);
+        for (int bnd = 0; bnd < FP; ++bnd) {
+          float sn, co;
+          sincosf(x * static_cast<float>(1 << bnd), &sn, &co);
+          fa[3 + 6 * bnd + c] = sn;
+          fa[3 + 6 * bnd + 3 + c] = co;
+        }
+      }
+    }
     for (int c = 0; c < 3; ++c) {
       f[c] = u[c];
       f[ND + c] = p[c];

@@ -9,10 +9,17 @@
 namespace adanerf {
 struct SampleArgs;
 struct ShadeArgs;
+struct GenericTopo;
 
 // sample_mlp_kernel<10,4> (full = true) or <2,2>; grid = ceil(n_rays / 128) workgroups of 256 threads
 hipError_t launch_sample_mlp_f32(const SampleArgs& a, bool full, unsigned grid, hipStream_t stream);
 // persistent grid of shade_mlp32_kernel<10,4> for a device with `compute_units` CUs
 hipError_t shade_mlp_f32_grid(int compute_units, int* grid);
 hipError_t launch_shade_mlp_f32(const ShadeArgs& a, int grid, hipStream_t stream);
+
+// Generic-topology kernels (k_generic_f32.hip.hpp): width 64 / 128 / 256, run-time depth / skip / raySampleInput.
+// full: 10-4 oracle encoding (else 2-2).  hipErrorInvalidValue for a width without an instantiation.
+hipError_t launch_sample_mlp_gen(const SampleArgs& a, const GenericTopo& t, bool full, int width, unsigned grid, hipStream_t stream);
+hipError_t shade_mlp_gen_grid(int compute_units, int width, int* grid);
+hipError_t launch_shade_mlp_gen(const ShadeArgs& a, const GenericTopo& t, int width, int grid, hipStream_t stream);
 }  // namespace adanerf

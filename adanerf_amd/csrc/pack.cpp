@@ -162,17 +162,62 @@ void emit(const VLayer& L, Elem elem, PackedNet* out) {
 
 }  // namespace
 
+namespace {
+
+int count_layers(const TensorMap& m, const std::string& prefix) {
+  int n = 0;
+  while (m.count(prefix + std::to_string(n) + ".weight")) ++n;
+  return n;
+}
+
+bool fail(std::string* err, const std::string& msg) {
+  if (err) *err = msg;
+  return false;
+}
+
+// raySampleInput part of the sampling net's first layer: K-major fragments [a][s4][m][lane][4] (fp32 engine only), so the
+// kernel can walk the A extra points in a run-time loop with all MT accumulators live.
+void emit_ray_samples(const VLayer& L, int A, int fp, int col_base, PackedNet* out) {
+  const int QP = pe_slots(fp), MT = L.rows / 32, n_pt = 3 + 6 * fp;
+  out->rsi_w_off = static_cast<uint32_t>(out->weights.size() / 16);
+  const size_t base = out->weights.size();
+  out->weights.resize(base + static_cast<size_t>(A) * (QP / 4) * MT * 64 * 16);
+  uint8_t* dst = out->weights.data() + base;
+  for (int a = 0; a < A; ++a)
+    for (int s4 = 0; s4 < QP / 4; ++s4)
+      for (int m = 0; m < MT; ++m)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int row = 32 * m + (lane & 31), h = lane >> 5;
+          const size_t frag = ((static_cast<size_t>(a) * (QP / 4) + s4) * MT + m) * 64 + lane;
+          for (int e = 0; e < 4; ++e) {
+            const int c = pe_col(fp, 4 * s4 + e, h);
+            const float v = c < 0 ? 0.f : L.w[static_cast<size_t>(row) * L.cols + col_base + a * n_pt + c];
+            std::memcpy(dst + frag * 16 + 4 * e, &v, 4);
+          }
+        }
+}
+
+}  // namespace
+
 bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, PackedNet* out, std::string* err) {
   *out = PackedNet();
   out->elem = elem;
   const int n_dir = 3 + 6 * sh.fd0, n_pos = 3 + 6 * sh.fp0;
-  const int n_in = n_dir + n_pos;
-  for (int i = 0; i < 8; ++i) {
+  const int n_in = n_dir + n_pos + sh.ray_samples * n_pos;
+  NetTopology& T = out->topo;
+  T.depth = count_layers(net0, "layers.");
+  if (T.depth < 2 || T.depth > kMaxDepth) return fail(err, "sampling net: " + std::to_string(T.depth) + " layers (2.." + std::to_string(kMaxDepth) + " supported)");
+  T.width = find(net0, "layers.0.weight", err)->rows();     // exists: depth >= 2
+  T.ray_samples = sh.ray_samples;
+  if (T.width % 32 != 0 || T.width < 32 || T.width > 512) return fail(err, "sampling net: width " + std::to_string(T.width) + " (multiples of 32 up to 512 supported)");
+  if (!T.is_default(false) && elem != Elem::F32)
+    return fail(err, "sampling net: only the 8 x 256 topology without raySampleInput runs on the 16-bit engines");
+  for (int i = 0; i < T.depth; ++i) {
     const Tensor* W = find(net0, "layers." + std::to_string(i) + ".weight", err);
     const Tensor* B = find(net0, "layers." + std::to_string(i) + ".bias", err);
     if (!W || !B) return false;
-    const int n_out = (i == 7) ? kBins : 256;
-    const int k = (i == 0) ? n_in : 256;
+    const int n_out = (i == T.depth - 1) ? kBins : T.width;
+    const int k = (i == 0) ? n_in : T.width;      // BaseNet skip specs (src/models.py:44-66) are not used by any config: plain chain
     if (W->rows() != n_out) {
       if (err) *err = "layers." + std::to_string(i) + ".weight: expected " + std::to_string(n_out) + " rows";
       return false;
@@ -184,9 +229,10 @@ bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, Pac
       add_pe_slots(&L, sh.fd0, 0);        // [dir PE | pos PE]  (src/features.py:868-874)
       add_pe_slots(&L, sh.fp0, n_dir);
     } else {
-      add_act_slots(&L, 256, 0);
+      add_act_slots(&L, T.width, 0);
     }
     emit(L, elem, out);
+    if (i == 0 && sh.ray_samples > 0) emit_ray_samples(L, sh.ray_samples, sh.fp0, n_dir + n_pos, out);
   }
   return true;
 }
@@ -195,62 +241,79 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
   *out = PackedNet();
   out->elem = elem;
   const int n_pos = 3 + 6 * sh.fp1, n_dir = 3 + 6 * sh.fd1;
-  for (int i = 0; i < 8; ++i) {
+  NetTopology& T = out->topo;
+  T.depth = count_layers(net1, "pts_linears.");
+  if (T.depth < 1 || T.depth > kMaxDepth) return fail(err, "shading net: " + std::to_string(T.depth) + " trunk layers (1.." + std::to_string(kMaxDepth) + " supported)");
+  T.width = find(net1, "pts_linears.0.weight", err)->rows();   // exists: depth >= 1
+  if (T.width % 64 != 0 || T.width < 64 || T.width > 512) return fail(err, "shading net: width " + std::to_string(T.width) + " (multiples of 64 up to 512 supported)");
+  const int Wd = T.width;
+  T.skip = -1;
+  for (int i = 1; i < T.depth; ++i) {
+    const Tensor* W = find(net1, "pts_linears." + std::to_string(i) + ".weight", err);
+    if (!W) return false;
+    if (W->cols() == Wd + n_pos) {          // cat([input_pts, h]) in front of layer i  <=>  i - 1 in skips (src/models.py:226-228)
+      if (T.skip >= 0) return fail(err, "shading net: more than one skip connection");
+      T.skip = i - 1;
+    }
+  }
+  if (!T.is_default(true) && elem != Elem::F32)
+    return fail(err, "shading net: only the 8 x 256 / skip 4 topology runs on the 16-bit engine");
+  for (int i = 0; i < T.depth; ++i) {
     const std::string nm = "pts_linears." + std::to_string(i);
     const Tensor* W = find(net1, nm + ".weight", err);
     const Tensor* B = find(net1, nm + ".bias", err);
     if (!W || !B) return false;
-    const int k = (i == 0) ? n_pos : (i == 5 ? n_pos + 256 : 256);
-    if (W->rows() != 256) {
-      if (err) *err = nm + ".weight: expected 256 rows";
+    const int k = (i == 0) ? n_pos : (i == T.skip + 1 ? n_pos + Wd : Wd);
+    if (W->rows() != Wd) {
+      if (err) *err = nm + ".weight: expected " + std::to_string(Wd) + " rows";
       return false;
     }
     VLayer L;
-    init_layer(&L, 256, k);
+    init_layer(&L, Wd, k);
     if (!set_rows(&L, 0, W, B, k, err, nm)) return false;
     if (i == 0) {
       add_pe_slots(&L, sh.fp1, 0);
-    } else if (i == 5) {                   // cat([input_pts, h])  (src/models.py:260-261)
+    } else if (i == T.skip + 1) {          // cat([input_pts, h])  (src/models.py:260-261)
       add_pe_slots(&L, sh.fp1, 0);
-      add_act_slots(&L, 256, n_pos);
+      add_act_slots(&L, Wd, n_pos);
     } else {
-      add_act_slots(&L, 256, 0);
+      add_act_slots(&L, Wd, 0);
     }
     emit(L, elem, out);
   }
-  {   // feature_linear rows 0..255, alpha_linear as row 256 (tile 8, row 0)
+  {   // feature_linear rows 0..W-1, alpha_linear as row W (tile W/32, row 0)
     const Tensor* WF = find(net1, "feature_linear.weight", err);
     const Tensor* BF = find(net1, "feature_linear.bias", err);
     const Tensor* WA = find(net1, "alpha_linear.weight", err);
     const Tensor* BA = find(net1, "alpha_linear.bias", err);
     if (!WF || !BF || !WA || !BA) return false;
     VLayer L;
-    init_layer(&L, 288, 256);
-    if (!set_rows(&L, 0, WF, BF, 256, err, "feature_linear")) return false;
-    if (WF->rows() != 256 || WA->rows() != 1) {
+    init_layer(&L, Wd + 32, Wd);
+    if (!set_rows(&L, 0, WF, BF, Wd, err, "feature_linear")) return false;
+    if (WF->rows() != Wd || WA->rows() != 1) {
       if (err) *err = "feature_linear/alpha_linear: unexpected row count";
       return false;
     }
-    if (!set_rows(&L, 256, WA, BA, 256, err, "alpha_linear")) return false;
-    add_act_slots(&L, 256, 0);
+    if (!set_rows(&L, Wd, WA, BA, Wd, err, "alpha_linear")) return false;
+    add_act_slots(&L, Wd, 0);
     emit(L, elem, out);
   }
   {   // views_linears.0 on cat([feature, input_views])  (src/models.py:266-270)
     const Tensor* W = find(net1, "views_linears.0.weight", err);
     const Tensor* B = find(net1, "views_linears.0.bias", err);
     if (!W || !B) return false;
-    if (W->rows() != 128) {
-      if (err) *err = "views_linears.0.weight: expected 128 rows";
+    if (W->rows() != Wd / 2) {
+      if (err) *err = "views_linears.0.weight: expected " + std::to_string(Wd / 2) + " rows";
       return false;
     }
     VLayer L;
-    init_layer(&L, 128, 256 + n_dir);
-    if (!set_rows(&L, 0, W, B, 256 + n_dir, err, "views_linears.0")) return false;
-    add_act_slots(&L, 256, 0);
-    add_pe_slots(&L, sh.fd1, 256);
+    init_layer(&L, Wd / 2, Wd + n_dir);
+    if (!set_rows(&L, 0, W, B, Wd + n_dir, err, "views_linears.0")) return false;
+    add_act_slots(&L, Wd, 0);
+    add_pe_slots(&L, sh.fd1, Wd);
     emit(L, elem, out);
   }
-  {   // rgb_linear 128 -> 3 (tile 0 rows 0..2)
+  {   // rgb_linear W/2 -> 3 (tile 0 rows 0..2)
     const Tensor* W = find(net1, "rgb_linear.weight", err);
     const Tensor* B = find(net1, "rgb_linear.bias", err);
     if (!W || !B) return false;
@@ -259,9 +322,9 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
       return false;
     }
     VLayer L;
-    init_layer(&L, 32, 128);
-    if (!set_rows(&L, 0, W, B, 128, err, "rgb_linear")) return false;
-    add_act_slots(&L, 128, 0);
+    init_layer(&L, 32, Wd / 2);
+    if (!set_rows(&L, 0, W, B, Wd / 2, err, "rgb_linear")) return false;
+    add_act_slots(&L, Wd / 2, 0);
     emit(L, elem, out);
   }
   return true;

@@ -13,6 +13,17 @@ namespace adanerf {
 enum class Elem { F32, BF16, F16, F16_SPLIT };
 constexpr float kSplitScale = 2048.0f;
 
+// Topology of an exported network, read off its initializers (the reference's BaseNet / NeRF classes,
+// src/models.py:18-82, 199-250; the viewer takes it from the ONNX graph as well, not from config.ini).
+struct NetTopology {
+  int depth = 8;           // Linear layers of the trunk (sampling net: all of them)
+  int width = 256;         // hidden width W
+  int skip = -1;           // NeRF trunk: layer skip + 1 takes cat([input_pts, h]); -1 = none
+  int ray_samples = 0;     // sampling net: raySampleInput points in layer 0's input
+  bool is_default(bool shading) const { return depth == 8 && width == 256 && ray_samples == 0 && skip == (shading ? 4 : -1); }
+};
+constexpr int kMaxDepth = 8;    // w_off / b_off tables hold depth + 3 entries (kMaxLayers = 12)
+
 // One packed network: every layer's A fragments back to back plus the per-tile bias blocks.
 //   fp32 engine   : float  w[layer][m][s4][lane][4]   (slot q = 4 s4 + e)
 //   16-bit engine : uint16 w[layer][m][s ][lane][8]   (slot q = 8 s  + e)
@@ -26,18 +37,25 @@ struct PackedNet {
   std::vector<uint32_t> b_off;       // per layer, in floats
   std::vector<int> slots;            // per layer: input slots per lane-half
   std::vector<int> mtiles;           // per layer: 32-row output tiles
+  NetTopology topo;
+  uint32_t rsi_w_off = 0;            // fp32, ray_samples > 0: 16-byte offset of layer 0's raySampleInput fragments, [a][s4][m][lane][4]
 };
 
 struct NetShape {
   int fp0 = 10, fd0 = 4;   // posEncArgs[0]  (oracle net input encoding)
   int fp1 = 10, fd1 = 4;   // posEncArgs[1]  (shading net input encoding)
+  int ray_samples = 0;     // raySampleInput[0]: extra encoded points along the ray in the oracle net's input
 };
 
-// layers.{0..7}.{weight,bias}: [dir PE | pos PE] -> 256 x7 -> 128  (src/models.py:18-82,183-195)
+
+// layers.{0..D-1}.{weight,bias}: [dir PE | pos PE | raySampleInput points] -> W x (D-1) -> 128  (src/models.py:18-82,183-195).
+// Every shipped config is 8 x 256 without extra points; other depths / widths (W % 32 == 0, W <= 512, D in 2..8) and the
+// raySampleInput input pack for Elem::F32 only (the generic fp32-MFMA kernels): the 16-bit engines are specialised.
 bool pack_sampling_net(const TensorMap& net0, const NetShape& shape, Elem elem, PackedNet* out, std::string* err);
 
-// pts_linears.{0..7}, feature_linear(+alpha_linear as row 256), views_linears.0, rgb_linear
-// (src/models.py:199-277).  Layer order in the blob: 0..7, feature+alpha, views, rgb.
+// pts_linears.{0..D-1}, feature_linear(+alpha_linear as row W), views_linears.0, rgb_linear
+// (src/models.py:199-277).  Layer order in the blob: 0..D-1, feature+alpha, views, rgb.  Other than 8 x 256 / skip 4
+// (W % 64 == 0, W <= 512, D in 1..8, one skip or none): Elem::F32 only, as above.
 bool pack_shading_net(const TensorMap& net1, const NetShape& shape, Elem elem, PackedNet* out, std::string* err);
 
 uint16_t f32_to_bf16(float f);

@@ -306,7 +306,10 @@ int adanerf_host_parse_model(const char* model_dir, const adanerf_options* opt, 
  *   weights_out  packed 16-byte fragments        (*weights_bytes)
  *   bias_out     packed bias blocks, fp32        (*bias_floats)
  *   layer_out    per layer {w_off (16-B units), b_off (floats), slots per lane-half, 32-row tiles}
- *                as int32[4] each                (*n_layers) */
+ *                as int32[4] each                (*n_layers); a sampling net with raySampleInput = A > 0 has one more
+ *                record {w_off of layer 0's K-major block for the A extra points, A, slots per point, tiles}.
+ * Topologies other than 8 x 256 (/ skip 4) and raySampleInput pack for ADANERF_PREC_FP32 only (they run on the
+ * run-time-shaped fp32 kernels); the 16-bit precisions then return ADANERF_EIO with a message. */
 int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precision, void* weights_out,
                               size_t* weights_bytes, float* bias_out, size_t* bias_floats, int32_t* layer_out,
                               int32_t* n_layers);

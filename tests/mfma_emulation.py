@@ -155,3 +155,60 @@ def run_shading_net(net: PackedNet, x, dpe, fp=10, fd=4):
     v = net.layer(9, np.concatenate([f[:, :128], dirs], axis=1), True)
     rgb = net.layer(10, v, False)           # rows 0..2 -> half 0, slots 0..2
     return np.stack([rgb[0, 0], rgb[0, 1], rgb[0, 2], alpha], axis=1)
+
+
+# ---- any topology, fp32 fragments (the run-time-shaped kernels of k_generic_f32.hip.hpp) -------------------
+
+def run_sampling_net_generic(net: PackedNet, dir_unit, p, nds, fp, fd, rsi_z=None, rsi_d1=1.0):
+    """depth = number of layer records (minus the raySampleInput record); layer 0 optionally extended by the K-major
+    block of the A extra points p + nds z_a (encode(x / d1), identity slots scaled back by d1)."""
+    assert net.precision == 2
+    lay = net.lay
+    has_rsi = rsi_z is not None and len(rsi_z) > 0
+    depth = lay.shape[0] - (1 if has_rsi else 0)
+    act0 = np.concatenate([pe_eval(dir_unit, fd), pe_eval(p, fp)], axis=1)
+    if not has_rsi:
+        act = net.layer(0, act0, True)
+    else:
+        pre = net.layer(0, act0, False)                                   # bias + first part, slots [2, 16 MT, n]
+        w_off, A, QP, MT = [int(v) for v in lay[depth]]
+        frag = net.w[w_off * 16:(w_off + A * (QP // 4) * MT * 64) * 16].view(np.float32).reshape(A, QP // 4, MT, 64, 4)
+        n = p.shape[0]
+        D = np.zeros((MT, 32, n), dtype=np.float32)
+        for a in range(A):
+            x = ((p + nds * np.float32(rsi_z[a])) / np.float32(rsi_d1)).astype(np.float32)
+            t = pe_eval(x, fp)
+            t[0, 3 * fp] *= np.float32(rsi_d1)
+            t[1, 3 * fp] *= np.float32(rsi_d1)
+            t[0, 3 * fp + 1] *= np.float32(rsi_d1)
+            for m in range(MT):
+                for h in range(2):
+                    Am = frag[a, :, m, h * 32:(h + 1) * 32, :].transpose(1, 0, 2).reshape(32, QP)
+                    D[m] += Am @ t[h]
+        for m in range(MT):
+            for hh in range(2):
+                for r in range(16):
+                    pre[hh, 16 * m + r] += D[m, (r & 3) + 8 * (r >> 2) + 4 * hh]
+        act = np.maximum(pre, 0)
+    for l in range(1, depth - 1):
+        act = net.layer(l, act, True)
+    out = net.layer(depth - 1, act, False)
+    n = out.shape[2]
+    orc = np.zeros((n, 128), dtype=np.float32)
+    for h in range(2):
+        for q in range(64):
+            orc[:, 32 * (q >> 4) + 8 * ((q & 15) >> 2) + 4 * h + (q & 3)] = out[h, q]
+    return orc
+
+
+def run_shading_net_generic(net: PackedNet, x, dpe, depth, width, skip, fp=10, fd=4):
+    assert net.precision == 2 and net.lay.shape[0] == depth + 3
+    pts, dirs = pe_eval(x, fp), pe_eval(dpe, fd)
+    h = net.layer(0, pts, True)
+    for l in range(1, depth):
+        h = net.layer(l, np.concatenate([pts, h], axis=1) if l == skip + 1 else h, True)
+    f = net.layer(depth, h, False)                                # feature (+ alpha tile)
+    alpha = f[0, width // 2]
+    v = net.layer(depth + 1, np.concatenate([f[:, :width // 2], dirs], axis=1), True)
+    rgb = net.layer(depth + 2, v, False)
+    return np.stack([rgb[0, 0], rgb[0, 1], rgb[0, 2], alpha], axis=1)

@@ -9,8 +9,9 @@ import numpy as np
 import pytest
 
 import adanerf_oracle as O
-from conftest import ROOT, case_weights, load_case
-from mfma_emulation import PackedNet, pack_weights, run_sampling_net, run_shading_net
+from conftest import ROOT, TOPOLOGY_CASES, case_weights, load_case
+from mfma_emulation import (PackedNet, pack_weights, run_sampling_net, run_sampling_net_generic, run_shading_net,
+                            run_shading_net_generic)
 
 import adanerf_amd
 from adanerf_amd import renderer as R
@@ -106,7 +107,10 @@ def test_error_codes_and_messages(lib, tmp_path):
     assert lib.adanerf_host_parse_model(d.encode(), C.byref(o2), C.byref(info)) == -4
     o3 = _opts(threshold=0.0, num_samples=128)
     assert lib.adanerf_host_parse_model(d.encode(), C.byref(o3), C.byref(info)) == 0 and info.dense == 1
+    # raySampleInput: A extra points in the oracle input (accepted: n_in0 grows by A * 63), nonsense values rejected
     open(os.path.join(d, "config.ini"), "w").write(cfg.replace("raySampleInput = [0, 0]", "raySampleInput = [128, 0]"))
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == 0 and info.n_in0 == 90 + 128 * 63
+    open(os.path.join(d, "config.ini"), "w").write(cfg.replace("raySampleInput = [0, 0]", "raySampleInput = [-3, 0]"))
     assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == -4
     open(os.path.join(d, "config.ini"), "w").write(cfg.replace("posEncArgs = [10-4, 10-4]", "posEncArgs = [6-3, 10-4]"))
     assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == -4
@@ -186,6 +190,50 @@ def test_packed_sampling_net_reproduces_oracle(lib, tmp_path):
                 assert w.size == 880 * 1024          # sample16_frags<10, 4>() in k_sampling16.hip.hpp
             orc = run_sampling_net(PackedNet(w, b, lay, precision), u, z["p"][:n], fp, fd)
             np.testing.assert_allclose(orc, z["oracle_out"][:n], rtol=0, atol=atol)
+
+
+@pytest.mark.parametrize("name", TOPOLOGY_CASES)
+def test_generic_topologies_pack_and_reproduce_the_reference(lib, tmp_path, name):
+    """networks the reference's model classes built in other shapes (6 x 128 skip 2; 2 x 128 with 3 x 256
+    skip 1; 4 x 128 with raySampleInput = 128) load, pack into fp32 MFMA fragments (topology read off the initializers)
+    and -- replayed through the kernels' dataflow in numpy -- reproduce the reference's own sampling-network outputs
+    and the oracle's shading outputs.  The 16-bit packings refuse these shapes with a message."""
+    z, meta, sc = load_case(name)
+    wts = case_weights(meta)
+    d, _, _ = _model_dir(tmp_path, sc, wts, name=name)
+    lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+    info = R.Info()
+    o = _opts(width=meta["w"], height=meta["h"])
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == 0 and info.n_in0 == sc.n_in0
+    syn = meta["syn"]
+    fp, fd = sc.pos_enc[0]
+    n = 48
+    nds = z["nds"][:n]
+    u = (nds / np.sqrt(np.sum(nds * nds, -1, keepdims=True))).astype(np.float32)
+    w, b, lay = pack_weights(lib, d, 0, 2)
+    assert lay.shape[0] == syn["layers"][0] + (1 if sc.ray_sample_input else 0)
+    assert [int(v) for v in lay[:syn["layers"][0], 3]] == [syn["widths"][0] // 32] * (syn["layers"][0] - 1) + [4]
+    rsi_z = O.ray_sample_depths(sc) if sc.ray_sample_input else None
+    orc = run_sampling_net_generic(PackedNet(w, b, lay, 2), u, z["p"][:n], nds, fp, fd, rsi_z, sc.depth_range[1])
+    np.testing.assert_allclose(orc, z["oracle_out"][:n], rtol=0, atol=1e-4)
+    # shading net on a few of the fixture's samples
+    count = z["sel_count"].astype(np.int32)
+    off, sray, sbin, sw = O.compact(count, z["sel_bins"], z["sel_weight"])
+    feat = O.shading_inputs(z["p"], z["nds"], sray[:n], O.to_world_depth(O.bin_t(sbin[:n].astype(np.int64)), sc), sc)
+    ref = O.shading_mlp(feat, wts.net1)
+    w1, b1, lay1 = pack_weights(lib, d, 1, 2)
+    depth, skips = O.shading_topology(wts.net1, 63)
+    out = run_shading_net_generic(PackedNet(w1, b1, lay1, 2), feat[:, 0:3], feat[:, 63:66], depth, syn["widths"][1], skips[0] if skips else -1)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-4)
+    # the 16-bit engines are specialised to 8 x 256 (/ skip 4) without raySampleInput
+    f = lib.adanerf_host_pack_weights
+    wb, bf, nl = C.c_size_t(0), C.c_size_t(0), C.c_int32(0)
+    for net in (0, 1):
+        default = (syn["layers"][net], syn["widths"][net]) == (8, 256) and (net == 1 or not sc.ray_sample_input) and (net == 0 or syn["skip1"] == 4)
+        rc = f(d.encode(), net, 0 if net else 3, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl))
+        assert (rc == 0) == default, (net, rc)
+        if not default:
+            assert b"16-bit" in lib.adanerf_last_error(None)
 
 
 def test_product_path_fails_loudly_without_gpu(lib, tmp_path):
