@@ -3,6 +3,7 @@
 // Device code only (gfx950, wave64); part of kernels.hip.hpp.
 #pragma once
 #include "k_common.hip.hpp"
+#include "tuning.hpp"
 #include "k_select_pair.hip.hpp"
 
 namespace adanerf {
@@ -15,10 +16,7 @@ namespace adanerf {
 // entry of the block-total scan.  Small on purpose: a wave's serial loop over its rays is the critical path of a
 // small batch (an 83 200-ray shard of an 8-GPU frame), and more, shorter waves also schedule better on a whole
 // frame (measured 0.207 ms at 256 rays, 0.167 ms at 64 for 640 000 rays).
-#ifndef ADN_SEL_RPB
-#define ADN_SEL_RPB 64
-#endif
-constexpr int kSelRaysPerBlock = ADN_SEL_RPB;
+using tune::kSelRaysPerBlock;
 static_assert(kSelRaysPerBlock == 32 || kSelRaysPerBlock == 64, "segment must fit one wave");
 constexpr int kSelSegShift = kSelRaysPerBlock == 64 ? 6 : 5;
 

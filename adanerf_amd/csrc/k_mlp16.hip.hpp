@@ -4,6 +4,7 @@
 #pragma once
 #include "k_common.hip.hpp"
 #include "k_mlp_f32.hip.hpp"
+#include "tuning.hpp"
 
 namespace adanerf {
 
@@ -52,50 +53,8 @@ struct Fp16 {
 // across the barrier (never vmcnt(0) in the loop).  Each wave keeps the current chunk's 8
 // fragments in registers and re-fills fragment i from the NEXT chunk right after the MFMA that
 // consumed it, so LDS latency hides behind the other 7 MFMAs.
-// Timing-ablation switches for tools/ablate.sh (results become WRONG; never defined in the shipped build):
-//   1: no chunk boundary (no wait, no barrier, no DMA)   2: no LDS re-fill of the fragment registers
-//   4: no bias read (acc starts at 0)                    8: no ReLU/convert epilogue
-//  16: boundary without the DMA issue                   32: boundary without wait + barrier
-//  64: (sampling kernel) no cross-tile software pipeline of bias reads / epilogue
-// 128: (sampling kernels) v_sin_f32 instead of the libm-grade sincosf in the oracle-feature encoding
-// ADN_ABLATE applies to shade_mlp16_kernel, ADN_ABLATE_S to sample_mlp16x3_kernel.
-#ifndef ADN_ABLATE
-#define ADN_ABLATE 0
-#endif
-#ifndef ADN_ABLATE_S
-#define ADN_ABLATE_S 0
-#endif
-// Ring geometry.  CF = fragments (KiB) per chunk = MFMAs per wave between barriers; RS = ring slots.
-// At boundary k a wave waits for its own pieces of chunk k+1, so RS-3 further chunks stay in flight.
-#ifndef ADN_BUFDMA
-#define ADN_BUFDMA 1   // LDS-DMA through buffer_load ... lds (descriptor + scalar byte offset, lane * 16 as the only VGPR
-                       // operand) instead of global_load_lds with a 64-bit VALU address per piece: shading 3.82 -> 3.77 ms
-#endif
-#ifndef ADN_CF
-#define ADN_CF 16
-#endif
-#ifndef ADN_RS
-#define ADN_RS 4
-#endif
-#ifndef ADN_CF_S
-#define ADN_CF_S 16
-#endif
-#ifndef ADN_RS_S
-#define ADN_RS_S 6
-#endif
-// Fragments held in registers per wave (= re-fill distance in MFMAs) in the 2-waves-per-SIMD kernels, which live at the
-// 256-register cap: 2 leaves the shading kernel spill-free (4: 6 spilled dwords, 3.77 vs 3.73 ms; 8: 4.43 ms).  The
-// one-wave-per-SIMD split sampling kernel keeps a whole chunk (ADN_NR_S).
-#ifndef ADN_NR
-#define ADN_NR 4
-#endif
-#ifndef ADN_DMA_GRP
-#define ADN_DMA_GRP 0   // -1: every wave DMA-copies CF / WAVES pieces per chunk; 0 / 1: only waves 0-3 / 4-7 do (CF / 4 pieces each)
-#endif
-#ifndef ADN_STAGGER
-#define ADN_STAGGER 1   // 1: waves 4-7 of an 8-wave workgroup synchronise half a chunk later than waves 0-3 (ws_sync)
-#endif
-constexpr int kRegFrags = ADN_NR;
+// Ring geometry, register ring depth, stagger / DMA grouping and the timing-ablation bits: tuning.hpp.
+using tune::kRegFrags;
 constexpr int kShadeFrags16 = 32 + 4 * 128 + 160 + 2 * 128 + 144 + 72 + 8;   // 1184 per pass (FP=10, FD=4)
 constexpr int kShadeBiasFloats = 8 * 256 + 288 + 128 + 32;                     // 2496
 
@@ -106,7 +65,7 @@ struct WStream {
   static constexpr int kRegs = NR;   // fragments held in registers = re-fill distance
   static constexpr int kChunk = CF;  // fragments per chunk
   static constexpr int kChunkBytes = CF * 1024;
-#if ADN_BUFDMA && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
   __amdgpu_buffer_rsrc_t rsrc;   // raw buffer descriptor of the stream
 #endif
   const char* gbase;     // stream start (global)
@@ -119,7 +78,7 @@ struct WStream {
   uint32_t rd_next;      // LDS byte address of (next chunk, this lane)
   uint32_t lds_base;     // LDS byte address of the ring
   uint32_t grp;          // 0: this wave synchronises at chunk position 0, 1: at position CF / 2 (see ws_sync)
-  uint32_t issuer;       // this wave issues LDS-DMA pieces (all waves, or one group only: ADN_DMA_GRP)
+  uint32_t issuer;       // this wave issues LDS-DMA pieces (all waves, or one group only: tune::kDmaGroup)
   bool stag;             // the workgroup runs its two wave groups half a chunk apart (compile-time constant per kernel)
   u32x4 R[NR];           // register ring: fragment p (position inside the chunk) lives in R[p % NR]
 };
@@ -134,15 +93,11 @@ __device__ __forceinline__ void ws_issue(WStream<CF, RS, LPW, NR>& st, uint32_t 
 #pragma unroll
   for (int i = 0; i < LPW; ++i) {
     const uint32_t dst = st.lds_base + slot * (CF * 1024) + st.wave_off + i * 1024;
-#if ADN_BUFDMA && defined(__HIP_DEVICE_COMPILE__)
-    // buffer form: descriptor + wave-uniform byte offset in SGPRs, lane * 16 as the only VGPR operand (no 64-bit VALU
-    // address per piece)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // buffer form (buffer_load_dwordx4 ... lds): descriptor + wave-uniform byte offset in SGPRs, lane * 16 as the only VGPR
+    // operand -- no 64-bit VALU address per piece (global_load_lds measured 1.3 % slower)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (__attribute__((address_space(3))) void*)static_cast<uintptr_t>(dst), 16,
                                              static_cast<int>(st.lane_off), static_cast<int>(st.goff + st.wave_off + i * 1024), 0, 0);
-#else
-    const char* src = st.gbase + st.goff + st.wave_off + i * 1024 + st.lane_off;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)static_cast<uintptr_t>(dst), 16, 0, 0);
 #endif
   }
   st.goff += CF * 1024;
@@ -152,30 +107,21 @@ __device__ __forceinline__ void ws_issue(WStream<CF, RS, LPW, NR>& st, uint32_t 
 // Synchronisation point k of the ring: own pieces of chunk k+1 have landed (<= (RS-3) LPW younger DMAs outstanding);
 // barrier => chunk k+1 is complete in LDS for every wave and every wave has consumed chunk k-1 (its MFMAs were issued
 // before the barrier, so its ds_reads returned) => refill the slot of chunk k-1 with chunk k+RS-1.
-// Waves of group 0 reach it at fragment position 0 of chunk k, waves of group 1 at position CF / 2 of chunk k (ADN_STAGGER):
+// Waves of group 0 reach it at fragment position 0 of chunk k, waves of group 1 at position CF / 2 of chunk k (tune::kStagger):
 // the two waves that share a SIMD (wave i and wave i + 4 of an 8-wave workgroup) then run half an output tile apart, so
 // one of them is issuing MFMAs while the other is in its bias-read / epilogue / DMA-issue phase, instead of both hitting
 // those phases in the same cycles (a workgroup barrier per chunk otherwise keeps all eight waves in lockstep).  Both
 // groups see the same guarantees: a wave of group 1 is at most half a chunk ahead, i.e. still inside chunk k.
 // see ws_position
-#ifndef ADN_PAD
-#define ADN_PAD 11   // s_nop argument: wait states - 1 on the short side of a branch that follows a tile's last MFMA
-#endif
-__device__ __forceinline__ void ws_skip_pad() { asm volatile("s_nop %0" ::"n"(ADN_PAD) : "memory"); }
+__device__ __forceinline__ void ws_skip_pad() {
+  if (tune::kSkipPad >= 0) asm volatile("s_nop %0" ::"n"(tune::kSkipPad < 0 ? 0 : tune::kSkipPad) : "memory");
+}
 
-#ifndef ADN_STAG_DBG
-#define ADN_STAG_DBG 0   // hazard-hunting variants of the group-1 synchronisation (tools/ablate.sh); 0 in the shipped build
-#endif
 template <int ABL, int CF, int RS, int LPW, int NR>
 __device__ __forceinline__ void ws_sync(WStream<CF, RS, LPW, NR>& st, bool pad) {
   static_assert(RS >= 3 && (RS - 2) * LPW < 64, "vmcnt is a 6-bit counter");
   if (ABL & 1) return;
-  if (!(ABL & 32)) {
-    if ((ADN_STAG_DBG == 1 && st.grp) || ADN_STAG_DBG == 5) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (ADN_STAG_DBG == 6 && st.grp) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier\n\ts_sleep 8" ::"n"((RS - 3) * LPW) : "memory");
-    else if (ADN_STAG_DBG == 2 && st.grp) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((RS - 3) * LPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 3) * LPW) : "memory");   // 32: no wait/barrier
-  }
+  if (!(ABL & 32)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 3) * LPW) : "memory");   // 32: no wait/barrier
   // slot of chunk k-1: group 0 is still "in" it (ws_advance follows), group 1 has moved on to chunk k
   const uint32_t slot = (st.grp == 0) ? st.slot_cur : (st.slot_cur == 0 ? RS - 1 : st.slot_cur - 1);
   if (!(ABL & 16)) {                                                                                                      // 16: no DMA
@@ -206,16 +152,14 @@ __device__ __forceinline__ void ws_advance(WStream<CF, RS, LPW, NR>& st) {
 // the compiler may have moved behind the branch); mid-tile, the next consumer of the accumulator is the next MFMA of the chain.
 template <int ABL, int CF, int RS, int LPW, int NR>
 __device__ __forceinline__ void ws_position(WStream<CF, RS, LPW, NR>& st, int f, bool tile_start) {
-  const bool pad = ADN_STAG_DBG != 8 && (tile_start || ADN_STAG_DBG == 9);
+  const bool pad = tile_start;
   if (f == 0) {
     if (ABL & 1) return;
     if (st.grp == 0) ws_sync<ABL>(st, pad);
-    else if (ADN_STAG_DBG == 4) asm volatile("s_barrier" ::: "memory");
     else if (pad) ws_skip_pad();
     ws_advance(st);
   } else if (f == CF / 2 && st.stag) {
     if (st.grp != 0) ws_sync<ABL>(st, pad);
-    else if (ADN_STAG_DBG == 4) asm volatile("s_barrier" ::: "memory");
     else if (pad) ws_skip_pad();
   }
 }
@@ -241,7 +185,7 @@ __device__ __forceinline__ void ws_start(WStream<CF, RS, LPW, NR>& st, const voi
   st.issuer = issuer;
   st.gbase = reinterpret_cast<const char*>(gbase);
   st.gbytes = gbytes;
-#if ADN_BUFDMA && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
   st.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(gbase), 0, static_cast<int>(gbytes), 0x00020000);
 #endif
   st.goff = 0;
@@ -349,7 +293,7 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 acc;
-    if (ADN_ABLATE & 4) {
+    if (tune::kAblateShade & 4) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     } else {
@@ -358,17 +302,17 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int f = (FPOS + m * KS + s) % CF;     // position inside the chunk; compile-time after unrolling
-      ws_position<ADN_ABLATE>(st, f, s == 0);
+      ws_position<tune::kAblateShade>(st, f, s == 0);
       const uint32_t* src = (s < S1) ? (in1 + 4 * s) : (in2 + 4 * (s - S1));
       u32x4 b = {src[0], src[1], src[2], src[3]};
       acc = ET::mfma(st.R[f % WS::kRegs], b, acc);
-      ws_refill<ADN_ABLATE>(st, f);
+      ws_refill<tune::kAblateShade>(st, f);
     }
     if (KEEP_F32_TILE == kKeepAllF32) {
       keep[m] = acc;
     } else if (KEEP_F32_TILE == m) {
       *keep = acc;
-    } else if (ADN_ABLATE & 8) {
+    } else if (tune::kAblateShade & 8) {
       asm volatile("" ::"v"(acc));
 #pragma unroll
       for (int g = 0; g < 8; ++g) asm volatile("" : "=v"(out[8 * m + g]));
@@ -433,15 +377,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
   static_assert(FP == 10 && FD == 4, "fragment positions below assume the 10-4 shading encoding");
   static_assert(WAVES == 4 || WAVES == 8, "chunk = 8 fragments");
   constexpr int QP = pe_slots(FP), QD = pe_slots(FD);
-  constexpr bool kOneGroupDma = ADN_DMA_GRP >= 0 && WAVES == 8;
-  constexpr int TILE = WAVES * 32, CF = ADN_CF, RS = ADN_RS, LPW = kOneGroupDma ? CF / 4 : CF / WAVES;
+  constexpr bool kOneGroupDma = tune::kDmaGroup >= 0 && WAVES == 8;
+  constexpr int TILE = WAVES * 32, CF = tune::kChunkFrags, RS = tune::kRingSlots, LPW = kOneGroupDma ? CF / 4 : CF / WAVES;
   constexpr int kRingBytes = CF * RS * 1024;
   static_assert(CF % WAVES == 0 && CF % kRegFrags == 0 && kShadeFrags16 % CF == 0 && CF % 8 == 0 && CF <= 32, "chunk geometry");
   typedef WStream<CF, RS, LPW> WS;
-#ifndef ADN_STASH
-#define ADN_STASH 1   // 1: PE slots computed once per tile and parked in LDS; 0: sample re-loaded at layers 5 / view
-#endif
-  constexpr int kStashBytes = ADN_STASH ? WAVES * (QP / 8 + QD / 8) * 1024 : 0;
+  constexpr int kStashBytes = WAVES * (QP / 8 + QD / 8) * 1024;      // PE slots computed once per tile and parked in LDS
   __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kShadeBiasFloats * 4 + kStashBytes];
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
@@ -458,14 +399,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
     for (int i = threadIdx.x; i < kShadeBiasFloats; i += blockDim.x) lds_bias[i] = a.net.bias[i];
   }
   __syncthreads();
-#ifndef ADN_PRIO
-#define ADN_PRIO 0   // 1 / 2: static s_setprio 1 for waves 4-7 / 0-3 (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-#endif
-  if (ADN_PRIO == 1 && (wave >> 2) == 1) __builtin_amdgcn_s_setprio(1);
-  if (ADN_PRIO == 2 && (wave >> 2) == 0) __builtin_amdgcn_s_setprio(1);
   WS st;
-  ws_start(st, a.net.w, kShadeFrags16 * 1024, lds, kOneGroupDma ? (wave & 3) : (ADN_STAG_DBG == 7 ? (wave ^ 4) : wave), lane,
-           (ADN_STAGGER && WAVES == 8) ? (wave >> 2) : -1, !kOneGroupDma || (wave >> 2) == ADN_DMA_GRP);
+  ws_start(st, a.net.w, kShadeFrags16 * 1024, lds, kOneGroupDma ? (wave & 3) : wave, lane,
+           (tune::kStagger && WAVES == 8) ? (wave >> 2) : -1, !kOneGroupDma || (wave >> 2) == tune::kDmaGroup);
 
   // LDS byte address of the bias blocks of this lane-half
   const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
@@ -478,12 +414,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
       load_sample(a, s, total, x, dpe);
       uint32_t pts[QP / 2];
       pe_pack<ET, FP>(x, h, pts);
-      if (ADN_STASH) {
-        uint32_t dirs[QD / 2];
-        pe_pack<ET, FD>(dpe, h, dirs);
-        lds_stash_write<QP / 8>(stash, pts);
-        lds_stash_write<QD / 8>(stash + (QP / 8) * 1024, dirs);
-      }
+      uint32_t dirs[QD / 2];
+      pe_pack<ET, FD>(dpe, h, dirs);
+      lds_stash_write<QP / 8>(stash, pts);
+      lds_stash_write<QD / 8>(stash + (QP / 8) * 1024, dirs);
       layer_16<ET, WS, QP / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, lane, pts, pts, hA);
     }
 #pragma unroll 1
@@ -492,16 +426,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
       layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l + 1] * 4, lane, hB, hB, hA);
     }
     {
-      // the skip connection re-loads the sample and re-evaluates the 32 position slots instead of
-      // holding 16 (+6) VGPRs across layers 1-4 (30 v_sin per lane vs ~600 MFMA issue slots)
+      // the skip connection takes the 32 position slots back from the LDS stash instead of holding 16 VGPRs across layers 1-4
       uint32_t pts[QP / 2];
-      if (ADN_STASH) {
-        lds_stash_read<QP / 8>(stash, pts);
-      } else {
-        float x[3], dpe[3];
-        load_sample(a, s, total, x, dpe);
-        pe_pack<ET, FP>(x, h, pts);
-      }
+      lds_stash_read<QP / 8>(stash, pts);
       layer_16<ET, WS, QP / 8, 16, 8, true, 0>(st, bias0 + bo[5] * 4, lane, pts, hA, hB);   // cat([pts, h])
     }
     layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[6] * 4, lane, hB, hB, hA);
@@ -511,13 +438,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
     const float alpha = alpha_tile[0];
     {
       uint32_t dirs[QD / 2];
-      if (ADN_STASH) {
-        lds_stash_read<QD / 8>(stash + (QP / 8) * 1024, dirs);
-      } else {
-        float x[3], dpe[3];
-        load_sample(a, s, total, x, dpe);
-        pe_pack<ET, FD>(dpe, h, dirs);
-      }
+      lds_stash_read<QD / 8>(stash + (QP / 8) * 1024, dirs);
       layer_16<ET, WS, 16, QD / 8, 4, true, (32 + 4 * 128 + 160 + 2 * 128 + 144) % CF>(st, bias0 + bo[9] * 4, lane, hA, dirs, hB);             // cat([feature, dir])
     }
     f32x16 rgb_tile;

@@ -14,9 +14,6 @@ namespace adanerf {
 // identical selections on 100 % of rays -- at 3/16 of the fp32-MFMA cycle count.
 // kSplitScale (2^11) is defined in pack.hpp
 
-#ifndef ADN_NR_S
-#define ADN_NR_S 16  // fragment registers of the split sampling kernel = a whole chunk (measured 4: 1.42, 8: 1.37, 16: 1.32 ms)
-#endif
 
 __device__ __forceinline__ void split_pack(float v0, float v1, uint32_t* hi, uint32_t* lo) {
   f32x2 v = {v0, v1};
@@ -49,14 +46,14 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
   // Software pipeline across output tiles (one wave per SIMD: nothing else hides these latencies):
   //  - the bias block of tile m+1 is requested right after tile m's accumulators are initialised,
   //  - the epilogue of tile m-1 is spread, one accumulator pair per k-step, over tile m's MFMAs.
-  constexpr bool PIPE = !(ADN_ABLATE_S & 64);
+  constexpr bool PIPE = !(tune::kAblateSample & 64);
   BiasRegs br;
   f32x16 pacc, pcross;   // previous tile's accumulators (PIPE)
-  if (!(ADN_ABLATE_S & 4)) lds_bias_issue(bias_addr, br);
+  if (!(tune::kAblateSample & 4)) lds_bias_issue(bias_addr, br);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 acc, cross;
-    if (ADN_ABLATE_S & 4) {
+    if (tune::kAblateSample & 4) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     } else {
@@ -67,16 +64,16 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
     for (int r = 0; r < 16; ++r) cross[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const int f = (FPOS + 2 * (m * KS + s)) % ADN_CF_S;   // compile-time after unrolling; always even
-      ws_position<ADN_ABLATE_S>(st, f, s == 0);
+      const int f = (FPOS + 2 * (m * KS + s)) % tune::kChunkFragsSampling;   // compile-time after unrolling; always even
+      ws_position<tune::kAblateSample>(st, f, s == 0);
       const u32x4 bh = {in_hi[4 * s], in_hi[4 * s + 1], in_hi[4 * s + 2], in_hi[4 * s + 3]};
       const u32x4 bl = {in_lo[4 * s], in_lo[4 * s + 1], in_lo[4 * s + 2], in_lo[4 * s + 3]};
       acc = Fp16::mfma(st.R[f % WS::kRegs], bh, acc);
       cross = Fp16::mfma(st.R[f % WS::kRegs], bl, cross);
       cross = Fp16::mfma(st.R[(f + 1) % WS::kRegs], bh, cross);
-      ws_refill<ADN_ABLATE_S>(st, f);
-      ws_refill<ADN_ABLATE_S>(st, f + 1);
-      if (PIPE && m > 0 && !(ADN_ABLATE_S & 8)) {
+      ws_refill<tune::kAblateSample>(st, f);
+      ws_refill<tune::kAblateSample>(st, f + 1);
+      if (PIPE && m > 0 && !(tune::kAblateSample & 8)) {
         // KS >= 2: spread the 8 pairs over the first k-steps (all 8 in step 0/1 when KS < 8)
         constexpr int PER = (KS >= 8) ? 1 : (8 + KS - 1) / KS;
 #pragma unroll
@@ -86,7 +83,7 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
         }
       }
     }
-    if ((ADN_ABLATE_S & 8) && !LAST) {
+    if ((tune::kAblateSample & 8) && !LAST) {
       asm volatile("" ::"v"(acc), "v"(cross));
 #pragma unroll
       for (int g = 0; g < 8; ++g) asm volatile("" : "=v"(out_hi[8 * m + g]), "=v"(out_lo[8 * m + g]));
@@ -108,11 +105,11 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
 template <int FP, int FD>
 __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
   constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP;
-  constexpr int WAVES = 4, CF = ADN_CF_S, RS = ADN_RS_S, LPW = CF / WAVES, TILE = WAVES * 32;
+  constexpr int WAVES = 4, CF = tune::kChunkFragsSampling, RS = tune::kRingSlotsSampling, LPW = CF / WAVES, TILE = WAVES * 32;
   constexpr int F0 = 2 * (Q0 / 8) * 8;                  // layer-0 fragments (hi + lo')
   constexpr int FRAGS = F0 + 6 * 256 + 128;
-  static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % WAVES == 0 && CF % ADN_NR_S == 0 && CF <= 32, "chunk geometry");
-  typedef WStream<CF, RS, LPW, ADN_NR_S> WS;
+  static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % WAVES == 0 && CF % tune::kRegFragsSampling == 0 && CF <= 32, "chunk geometry");
+  typedef WStream<CF, RS, LPW, tune::kRegFragsSampling> WS;
   constexpr int kRingBytes = CF * RS * 1024, kBiasFloats = 7 * 256 + 128;
   __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kBiasFloats * 4 + WAVES * kPairLdsBytesPerWave];
   const int lane = lane_id();
@@ -147,8 +144,8 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
     uint32_t aH[64], aL[64], bH[64], bL[64];
     {
       float t[Q0];
-      pe_eval<FD, !(ADN_ABLATE_S & 128)>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
-      pe_eval<FP, !(ADN_ABLATE_S & 128)>(p, h, t + QD);
+      pe_eval<FD, !(tune::kAblateSample & 128)>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
+      pe_eval<FP, !(tune::kAblateSample & 128)>(p, h, t + QD);
 #pragma unroll
       for (int q = 0; q < Q0 / 2; ++q) split_pack(t[2 * q], t[2 * q + 1], &aH[q], &aL[q]);
     }
@@ -210,7 +207,7 @@ constexpr int sample16_frags() { return ((pe_slots(FD) + pe_slots(FP)) / 8) * 8 
 template <int FP, int FD>
 __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
   constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP;
-  constexpr bool kOneGroupDma = ADN_DMA_GRP >= 0;
+  constexpr bool kOneGroupDma = tune::kDmaGroup >= 0;
   constexpr int WAVES = 8, CF = 16, RS = 4, LPW = kOneGroupDma ? CF / 4 : CF / WAVES, TILE = WAVES * 32;   // 880 fragments = 55 chunks of 16
   constexpr int F0 = (Q0 / 8) * 8, FRAGS = sample16_frags<FP, FD>();
   static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % WAVES == 0 && CF % kRegFrags == 0 && CF <= 32, "chunk geometry");
@@ -230,8 +227,8 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
   }
   __syncthreads();
   WS st;
-  ws_start(st, a.net16.w, FRAGS * 1024, lds, kOneGroupDma ? (wave & 3) : wave, lane, ADN_STAGGER ? (wave >> 2) : -1,
-           !kOneGroupDma || (wave >> 2) == ADN_DMA_GRP);
+  ws_start(st, a.net16.w, FRAGS * 1024, lds, kOneGroupDma ? (wave & 3) : wave, lane, tune::kStagger ? (wave >> 2) : -1,
+           !kOneGroupDma || (wave >> 2) == tune::kDmaGroup);
   const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
   const uint32_t* bo = a.net16.b_off;
 
@@ -254,8 +251,8 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
     uint32_t hA[64], hB[64];
     {
       float t[Q0];
-      pe_eval<FD, !(ADN_ABLATE_S & 128)>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
-      pe_eval<FP, !(ADN_ABLATE_S & 128)>(p, h, t + QD);
+      pe_eval<FD, !(tune::kAblateSample & 128)>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
+      pe_eval<FP, !(tune::kAblateSample & 128)>(p, h, t + QD);
       uint32_t in0[Q0 / 2];
 #pragma unroll
       for (int q = 0; q < Q0 / 2; ++q) in0[q] = Fp16::pack(t[2 * q], t[2 * q + 1]);

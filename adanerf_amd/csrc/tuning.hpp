@@ -1,0 +1,103 @@
+// Build-time tuning constants of the MLP engines, in one place.  The shipped library is built with the defaults
+// below.  tools/ablate.sh builds experiment variants with -DADN_EXPERIMENT -DADN_<NAME>=<value> (ring geometry sweeps,
+// timing ablations for the tables in profiles/); without ADN_EXPERIMENT the -D overrides are ignored.
+#pragma once
+
+namespace adanerf {
+namespace tune {
+
+
+#if defined(ADN_EXPERIMENT)
+#define ADN_OVERRIDABLE 1
+#else
+#define ADN_OVERRIDABLE 0
+#endif
+
+// ---- LDS weight ring of the 16-bit engines (k_mlp16.hip.hpp) ---------------------------------------------------------
+// CF = fragments (KiB) per chunk = MFMAs per wave between two synchronisation points; RS = ring slots.  At
+// synchronisation point k a wave waits for its own pieces of chunk k+1, so RS-3 further chunks stay in flight.
+#if ADN_OVERRIDABLE && defined(ADN_CF)
+constexpr int kChunkFrags = ADN_CF;
+#else
+constexpr int kChunkFrags = 16;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_RS)
+constexpr int kRingSlots = ADN_RS;
+#else
+constexpr int kRingSlots = 4;
+#endif
+// the split-precision sampling kernel (one wave per SIMD) has its own geometry
+#if ADN_OVERRIDABLE && defined(ADN_CF_S)
+constexpr int kChunkFragsSampling = ADN_CF_S;
+#else
+constexpr int kChunkFragsSampling = 16;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_RS_S)
+constexpr int kRingSlotsSampling = ADN_RS_S;
+#else
+constexpr int kRingSlotsSampling = 6;
+#endif
+// Fragments held in registers per wave (= LDS prefetch distance in MFMAs).  Two waves per SIMD (256-register cap): 4
+// (2: 3.71-3.82 ms, 8: 3.66-3.76 ms with 4 spilled registers, against 3.58-3.62 on the same box).  The one-wave-per-SIMD
+// split sampling kernel keeps a whole chunk (4: 1.42, 8: 1.37, 16: 1.32 ms).
+#if ADN_OVERRIDABLE && defined(ADN_NR)
+constexpr int kRegFrags = ADN_NR;
+#else
+constexpr int kRegFrags = 4;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_NR_S)
+constexpr int kRegFragsSampling = ADN_NR_S;
+#else
+constexpr int kRegFragsSampling = 16;
+#endif
+// 8-wave workgroups: waves 4-7 synchronise half a chunk after waves 0-3, so the two waves of a SIMD run half an output
+// tile apart (ws_sync); -1 / 0 / 1: every wave / only waves 0-3 / only waves 4-7 DMA-copy the weight pieces.
+#if ADN_OVERRIDABLE && defined(ADN_STAGGER)
+constexpr bool kStagger = ADN_STAGGER != 0;
+#else
+constexpr bool kStagger = true;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_DMA_GRP)
+constexpr int kDmaGroup = ADN_DMA_GRP;
+#else
+constexpr int kDmaGroup = 0;
+#endif
+// s_nop argument (wait states - 1) on the short side of a branch that follows a tile's last MFMA (ws_position);
+// -1: no padding (profiles/r02_stagger_hazard.md: wrong results in some variants)
+#if ADN_OVERRIDABLE && defined(ADN_PAD)
+constexpr int kSkipPad = ADN_PAD;
+#else
+constexpr int kSkipPad = 11;
+#endif
+
+// ---- selection (k_compact.hip.hpp) -----------------------------------------------------------------------------------
+// Rays per workgroup of the wave-per-ray select_kernel (4 waves x kSelRaysPerBlock / 4 rays) = rays per segment total
+#if ADN_OVERRIDABLE && defined(ADN_SEL_RPB)
+constexpr int kSelRaysPerBlock = ADN_SEL_RPB;
+#else
+constexpr int kSelRaysPerBlock = 64;
+#endif
+
+// ---- timing ablations (results become WRONG; tools/ablate.sh, tables in profiles/*ablation*.md) ------------------------
+//   1: no chunk boundary (no wait, no barrier, no DMA)   2: no LDS re-fill of the fragment registers
+//   4: no bias read (acc starts at 0)                    8: no ReLU/convert epilogue
+//  16: boundary without the DMA issue                   32: boundary without wait + barrier
+//  64: (sampling kernel) no cross-tile software pipeline of bias reads / epilogue
+// 128: (sampling kernels) v_sin_f32 instead of the libm-grade sincosf in the oracle-feature encoding
+// kAblateShade applies to shade_mlp16_kernel, kAblateSample to sample_mlp16x3_kernel.
+#if ADN_OVERRIDABLE && defined(ADN_ABLATE)
+constexpr int kAblateShade = ADN_ABLATE;
+#else
+constexpr int kAblateShade = 0;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_ABLATE_S)
+constexpr int kAblateSample = ADN_ABLATE_S;
+#else
+constexpr int kAblateSample = 0;
+#endif
+
+
+#undef ADN_OVERRIDABLE
+
+}  // namespace tune
+}  // namespace adanerf
