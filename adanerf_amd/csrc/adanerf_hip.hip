@@ -672,6 +672,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     if (!pack_shading_net(c->net1_host, sh, Elem::F32, &probe, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
     c->topo1 = probe.topo;
     c->generic1 = !probe.topo.is_default(true);
+    if (c->generic1) c->info.precision = ADANERF_PREC_FP32;      // what actually runs; the caller asked for opt->precision
     if (c->generic1 || opt->precision == ADANERF_PREC_FP32) p1 = std::move(probe);
     else if (!pack_shading_net(c->net1_host, sh, elem_of(opt->precision), &p1, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
   }

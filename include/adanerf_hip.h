@@ -120,7 +120,8 @@ typedef struct adanerf_info {
   float   threshold;
   int32_t dense;            /* threshold == 0: all 128 bins, no selection */
   int32_t use_ndc;
-  int32_t precision;
+  int32_t precision;        /* the shading engine that runs: options.precision, or ADANERF_PREC_FP32 for a topology other
+                               than 8 x 256 / skip 4 (run-time-shaped fp32 kernels) */
   int32_t compute_units;
   float   fov, focal;
   float   view_cell_center[3];

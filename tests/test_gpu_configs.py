@@ -313,6 +313,8 @@ def test_generic_topologies_match_the_reference(name, tmp_path_factory):
     with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, meta["w"], meta["h"]), precision="bf16") as r:     # bf16 asked for:
         r.set_camera(z["pose"], z["rot"])                                                                     # the generic nets run in fp32
         assert r.info.n_in0 == sc.n_in0
+        if "rsi" not in name:
+            assert r.info.precision == R.PREC_FP32          # reported: what runs, not what was asked for
         orc = run_rows(r, meta, lambda f, n, b: r.sample_mlp(f, n, b, None), 128)
         feat = run_rows(r, meta, lambda f, n, b: r.ray_features(f, n, b, None), sc.n_in0)
     n = z["oracle_in"].shape[0]

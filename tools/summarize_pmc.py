@@ -3,11 +3,11 @@
 traffic estimate per launch with the gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE and
 WRITE_SIZE are in KiB; FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled).
 
-The guide leaves WRITE_SIZE uncalibrated ("calibrate on a known byte count in your own access pattern").  Two kernels
-of this path write a byte count that is known exactly: shade_mlp16_kernel stores one float4 per sample (config3_dense:
-20 480 000 x 16 B = 320 000 KiB, WRITE_SIZE reports 1 280 000 KiB) and composite_kernel stores 12 + 4 B per ray
-(config2: 2 500 KiB, WRITE_SIZE reports 10 000 KiB): WRITE_SIZE over-reports these stores 4.00x.  Both figures are kept:
-hbm_bytes_per_launch_uncalibrated = 2 FETCH + WRITE (guide corrections only) and hbm_bytes_per_launch = 2 FETCH + WRITE / 4."""
+The guide leaves WRITE_SIZE uncalibrated ("calibrate on a known byte count in your own access pattern").  Three kernels
+of this path store an exactly known byte count, and WRITE_SIZE reproduces each to the KiB, so it is used as reported:
+shade_mlp16_kernel, one float4 per sample (config 2: 4 539 214 x 16 B = 70 925 KiB, reported 70 925.2; config 3 dense:
+81 920 000 x 16 B = 1 280 000 KiB, reported 1 280 000.0); composite_kernel, 12 + 4 B per ray (640 000 rays = 10 000 KiB,
+reported 10 000.0)."""
 import collections
 import csv
 import glob
@@ -35,10 +35,9 @@ for k, d in vals.items():
     m = {c: sum(v) / len(v) for c, v in d.items()}
     rec = {"counters": m, "launches_sampled": max(len(v) for v in d.values()), "mean_duration_ns_under_pmc": sum(dur[k]) / len(dur[k])}
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
-        rec["hbm_bytes_per_launch_uncalibrated"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
-        rec["hbm_bytes_per_launch"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"] / 4.0) * 1024.0
-        rec["hbm_bytes_note"] = ("(2 x FETCH_SIZE + WRITE_SIZE / 4) KiB: gfx950 FETCH_SIZE counts 64 B per 128-B request; WRITE_SIZE reads 4.00x "
-                                 "the exactly known stores of shade_mlp16_kernel / composite_kernel (see tools/summarize_pmc.py)")
+        rec["hbm_bytes_per_launch"] = (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0
+        rec["hbm_bytes_note"] = ("(2 x FETCH_SIZE + WRITE_SIZE) KiB: gfx950 FETCH_SIZE counts 64 B per 128-B request; WRITE_SIZE checked against the "
+                                 "exactly known stores of shade_mlp16_kernel / composite_kernel (tools/summarize_pmc.py)")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
         cyc = m["GRBM_GUI_ACTIVE"] / 8.0          # summed over the 8 XCDs
         rec["kernel_cycles"] = cyc
