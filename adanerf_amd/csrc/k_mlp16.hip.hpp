@@ -5,6 +5,7 @@
 #include "k_common.hip.hpp"
 #include "k_mlp_f32.hip.hpp"
 #include "tuning.hpp"
+#include <utility>
 
 namespace adanerf {
 
@@ -284,11 +285,24 @@ __device__ __forceinline__ void epilogue_quad_16(const f32x16& acc, int m, int g
 }
 
 constexpr int kKeepAllF32 = -2;   // layer_16 KEEP_F32_TILE: every tile's raw accumulator goes to keep[m]
+
+#if ADN_OVERRIDABLE
+}  // namespace adanerf
+#include "x_handsched.hip.hpp"     // experiment builds only (-DADN_EXPERIMENT): HsLayer / HsLayer3, see profiles/r02_handsched.md
+namespace adanerf {
+#endif
+
 template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
 __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, const uint32_t* in1, const uint32_t* in2,
                                          uint32_t* out, f32x16* keep = nullptr) {
   constexpr int CF = WS::kChunk;
   constexpr int KS = S1 + S2;
+#if ADN_OVERRIDABLE
+  if constexpr (tune::kHandSched) {
+    HsLayer<ET, WS, S1, S2, MT, RELU, FPOS, KEEP_F32_TILE>::run(st, bias_addr, in1, in2, out, keep);
+    return;
+  }
+#endif
   // bias_addr: LDS byte address of this layer's bias block for THIS lane-half ([m][h][16] floats)
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -420,10 +434,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
       lds_stash_write<QD / 8>(stash + (QP / 8) * 1024, dirs);
       layer_16<ET, WS, QP / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, lane, pts, pts, hA);
     }
+#if ADN_OVERRIDABLE
+    if constexpr (tune::kHandSched) ws_settle(st);      // no LDS read in flight into a loop or over its back-edge (HsLayer)
+#endif
 #pragma unroll 1
     for (int l = 1; l <= 3; l += 2) {
       layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l] * 4, lane, hA, hA, hB);
       layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l + 1] * 4, lane, hB, hB, hA);
+  #if ADN_OVERRIDABLE
+    if constexpr (tune::kHandSched) ws_settle(st);      // no LDS read in flight over a loop back-edge (HsLayer)
+#endif
     }
     {
       // the skip connection takes the 32 position slots back from the LDS stash instead of holding 16 VGPRs across layers 1-4
@@ -443,6 +463,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
     }
     f32x16 rgb_tile;
     layer_16<ET, WS, 8, 0, 1, false, (32 + 4 * 128 + 160 + 2 * 128 + 144 + 72) % CF, 0>(st, bias0 + bo[10] * 4, lane, hB, hB, hA, &rgb_tile);
+#if ADN_OVERRIDABLE
+    if constexpr (tune::kHandSched) ws_settle(st);
+#endif
     if (h == 0 && s < total)
       *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(rgb_tile[0], rgb_tile[1], rgb_tile[2], alpha);
   }

@@ -40,12 +40,25 @@ __device__ __forceinline__ void epilogue_pair_16x3(const f32x16& acc, const f32x
   }
 }
 
+#if ADN_OVERRIDABLE
+}  // namespace adanerf
+#define ADN_HANDSCHED_PART2
+#include "x_handsched.hip.hpp"
+namespace adanerf {
+#endif
+
 template <class WS, int KS, int MT, bool LAST, int FPOS>
 __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane, const uint32_t* in_hi,
                                            const uint32_t* in_lo, uint32_t* out_hi, uint32_t* out_lo, float* out_f32) {
   // Software pipeline across output tiles (one wave per SIMD: nothing else hides these latencies):
   //  - the bias block of tile m+1 is requested right after tile m's accumulators are initialised,
   //  - the epilogue of tile m-1 is spread, one accumulator pair per k-step, over tile m's MFMAs.
+#if ADN_OVERRIDABLE
+  if constexpr (tune::kHandSchedSampling) {
+    HsLayer3<WS, KS, MT, LAST, FPOS>::run(st, bias_addr, in_hi, in_lo, out_hi, out_lo, out_f32);
+    return;
+  }
+#endif
   constexpr bool PIPE = !(tune::kAblateSample & 64);
   BiasRegs br;
   f32x16 pacc, pcross;   // previous tile's accumulators (PIPE)
@@ -150,13 +163,22 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
       for (int q = 0; q < Q0 / 2; ++q) split_pack(t[2 * q], t[2 * q + 1], &aH[q], &aL[q]);
     }
     layer_16x3<WS, Q0 / 8, 8, false, 0>(st, bias0 + bo[0] * 4, lane, aH, aL, bH, bL, nullptr);
+#if ADN_OVERRIDABLE
+    if constexpr (tune::kHandSchedSampling) ws_settle_acc(st);      // ... nor into a loop (the allocator may re-home the ring at the header)
+#endif
 #pragma unroll 1
     for (int l = 1; l <= 5; l += 2) {
       layer_16x3<WS, 16, 8, false, 0>(st, bias0 + bo[l] * 4, lane, bH, bL, aH, aL, nullptr);
       layer_16x3<WS, 16, 8, false, 0>(st, bias0 + bo[l + 1] * 4, lane, aH, aL, bH, bL, nullptr);
+#if ADN_OVERRIDABLE
+      if constexpr (tune::kHandSchedSampling) ws_settle_acc(st);      // no LDS read in flight over a loop back-edge (HsLayer3)
+#endif
     }
     float out[64];
     layer_16x3<WS, 16, 4, true, 0>(st, bias0 + bo[7] * 4, lane, bH, bL, nullptr, nullptr, out);
+#if ADN_OVERRIDABLE
+    if constexpr (tune::kHandSchedSampling) ws_settle_acc(st);
+#endif
 
     if (a.fused_select) {
       // A4 in the epilogue: the 128 raw outputs of ray j sit in lanes j and j + 32 (k_select_pair.hip.hpp)
@@ -258,13 +280,22 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
       for (int q = 0; q < Q0 / 2; ++q) in0[q] = Fp16::pack(t[2 * q], t[2 * q + 1]);
       layer_16<Fp16, WS, Q0 / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, lane, in0, in0, hA);
     }
+#if ADN_OVERRIDABLE
+    if constexpr (tune::kHandSched) ws_settle(st);
+#endif
 #pragma unroll 1
     for (int l = 1; l <= 5; l += 2) {
       layer_16<Fp16, WS, 16, 0, 8, true, F0 % CF>(st, bias0 + bo[l] * 4, lane, hA, hA, hB);
       layer_16<Fp16, WS, 16, 0, 8, true, F0 % CF>(st, bias0 + bo[l + 1] * 4, lane, hB, hB, hA);
+#if ADN_OVERRIDABLE
+      if constexpr (tune::kHandSched) ws_settle(st);      // no LDS read in flight over a loop back-edge (HsLayer)
+#endif
     }
     f32x16 out[4];
     layer_16<Fp16, WS, 16, 0, 4, false, F0 % CF, kKeepAllF32>(st, bias0 + bo[7] * 4, lane, hA, hA, hB, out);
+#if ADN_OVERRIDABLE
+    if constexpr (tune::kHandSched) ws_settle(st);
+#endif
     if (a.fused_select) {
       float x[64];
       float z = 0.f;

@@ -37,6 +37,32 @@ constexpr int kRingSlotsSampling = ADN_RS_S;
 #else
 constexpr int kRingSlotsSampling = 6;
 #endif
+// layer_16 / layer_16x3 with every LDS read and wait issued by hand (HsLayer, HsLayer3) instead of compiler-scheduled
+// re-fills (the compiler-scheduled forms remain as the experiment baseline)
+#if ADN_OVERRIDABLE && defined(ADN_HANDSCHED)
+constexpr bool kHandSched = ADN_HANDSCHED != 0;
+#else
+constexpr bool kHandSched = false;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_HANDSCHED_S)
+constexpr bool kHandSchedSampling = ADN_HANDSCHED_S != 0;
+#else
+constexpr bool kHandSchedSampling = false;
+#endif
+// Hand-scheduled layers: every step block starts with s_nop kHsStepNop.  The compiler separates a VALU write from an MFMA
+// that reads the register by 2 wait states (s_nop 1) but cannot see the MFMAs inside the asm blocks; without the nop the
+// split-precision kernel (B operands copied out of AGPRs right in front of a block) gave different results from run to
+// run (tools/probes/determinism.py).  kHsWaitZero: experiment knob, forces every counted LDS wait to 0.
+#if ADN_OVERRIDABLE && defined(ADN_HS_WAIT0)
+constexpr bool kHsWaitZero = ADN_HS_WAIT0 != 0;
+#else
+constexpr bool kHsWaitZero = false;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_HS_NOP)
+constexpr int kHsStepNop = ADN_HS_NOP;
+#else
+constexpr int kHsStepNop = 1;
+#endif
 // Fragments held in registers per wave (= LDS prefetch distance in MFMAs).  Two waves per SIMD (256-register cap): 4
 // (2: 3.71-3.82 ms, 8: 3.66-3.76 ms with 4 spilled registers, against 3.58-3.62 on the same box).  The one-wave-per-SIMD
 // split sampling kernel keeps a whole chunk (4: 1.42, 8: 1.37, 16: 1.32 ms).
@@ -48,7 +74,7 @@ constexpr int kRegFrags = 4;
 #if ADN_OVERRIDABLE && defined(ADN_NR_S)
 constexpr int kRegFragsSampling = ADN_NR_S;
 #else
-constexpr int kRegFragsSampling = 16;
+constexpr int kRegFragsSampling = kHandSchedSampling ? 8 : 16;      // hand-scheduled: 4 (hi, lo') pairs = 4 k-steps of 96 cycles ahead
 #endif
 // 8-wave workgroups: waves 4-7 synchronise half a chunk after waves 0-3, so the two waves of a SIMD run half an output
 // tile apart (ws_sync); -1 / 0 / 1: every wave / only waves 0-3 / only waves 4-7 DMA-copy the weight pieces.
