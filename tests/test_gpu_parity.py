@@ -582,6 +582,49 @@ def test_full_size_frame_properties(cases):
         assert O.psnr(rgb[sl][same], ref["rgb"][same]) > 55.0        # measured 60.1 / 62.3 dB
 
 
+@pytest.mark.parametrize("sampling", ["split", "fp16"])
+def test_full_size_launches_are_bit_identical(cases, sampling):
+    """The same launch three times at BASELINE size: sampling-net outputs, selections, shading-net outputs and the image must
+    not depend on timing.  (A missing wait state between a VALU write and an MFMA read, or an LDS read consumed before it
+    landed, shows up exactly like this -- and only at sizes that keep every CU busy; profiles/r02_handsched.md.)"""
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    w = h = 800
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling=sampling, keep_oracle=True) as r:
+        r.set_camera(z["pose"], z["rot"])
+        runs = []
+        for _ in range(3):
+            rgb, rgba, st = r.render_numpy()
+            tot = int(st.total_samples)
+            runs.append((rgb, r.buffer(R.BUF_ORACLE, np.float32, (w * h, 128)).copy(), r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (tot,)).copy(),
+                         r.buffer(R.BUF_RAW, np.float32, (tot, 4)).copy()))
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_uhd_frame_whole_and_batched(cases):
+    """3840 x 2160 (8.3 M rays, ~60 M samples): the largest frame a viewer is likely to ask for, whole (one 8.3 M-ray batch,
+    inline offset scan over 259 200 segment totals -> the separate scan kernel) and in the reference's 80 000-ray batches;
+    identical bytes, consistent counts / offsets, finite colours."""
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    w, h = 3840, 2160
+    outs = []
+    for bs in (-1, 80000):
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=bs), precision="bf16") as r:
+            r.set_camera(z["pose"], z["rot"])
+            rgb, rgba, st = r.render_numpy()
+            if bs < 0:
+                cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,))
+                off = r.buffer(R.BUF_RAY_OFFSETS, np.int32, (w * h,))
+                assert cnt.min() >= 1 and cnt.max() <= 8 and int(cnt.sum(dtype=np.int64)) == st.total_samples
+                assert np.array_equal(off[1:].astype(np.int64), np.cumsum(cnt.astype(np.int64))[:-1])
+            outs.append((rgba, int(st.total_samples), int(st.batches)))
+            assert np.isfinite(rgb).all() and (rgba[:, 3] == 255).all()
+    assert outs[0][1] == outs[1][1] and np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][2] == 1 and outs[1][2] == (w * h + 79999) // 80000
+    record("uhd_frame", samples=outs[0][1], samples_per_ray=outs[0][1] / (w * h))
+
+
 def test_errors_are_reported_not_thrown(cases):
     z, meta, sc, wts, d = cases["classroom_n8_thr02"]
     with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, 32, 32)) as r:
