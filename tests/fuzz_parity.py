@@ -37,7 +37,12 @@ def bins_of(r, n_rays, n_max):
 
 
 def one_case(rng, idx):
-    kind = rng.choice(["classroom", "barbershop", "random", "ndc", "pdf"], p=[0.35, 0.2, 0.2, 0.15, 0.1])
+    kinds = ["classroom", "barbershop", "random", "ndc", "pdf"]
+    probs = [0.35, 0.2, 0.2, 0.15, 0.1]
+    if os.environ.get("FUZZ_ROUND2"):       # round-2 features: oracle transforms, multiplier modes, other topologies, raySampleInput
+        kinds += ["transform", "mult", "topo", "rsi", "pdf_ce"]
+        probs = [0.1, 0.05, 0.05, 0.05, 0.05, 0.2, 0.1, 0.2, 0.1, 0.1]
+    kind = rng.choice(kinds, p=probs)
     if kind == "classroom":
         z, meta, sc = load_case("classroom_n8_thr02"); wts = case_weights(meta)
     elif kind == "barbershop":
@@ -46,14 +51,36 @@ def one_case(rng, idx):
         z, meta, sc = load_case("ndc_synthetic_n8"); wts = case_weights(meta)
     elif kind == "pdf":                              # DONeRF inverse-CDF sampler + classic compositing
         z, meta, sc = load_case("classroom_pdf_n8"); wts = case_weights(meta)
+    elif kind in ("transform", "mult"):              # losses[0] / accumulationMult variants on the shipped weights
+        z, meta, sc = load_case("classroom_n8_thr02"); wts = case_weights(meta)
+    elif kind == "pdf_ce":
+        z, meta, sc = load_case("classroom_pdf_ce_n8"); wts = case_weights(meta)
+    elif kind in ("topo", "rsi"):                    # any exportable topology / raySampleInput (generic fp32 kernels)
+        z, meta, sc = load_case("synthetic_fixed8")
+        rsi = int(rng.choice([1, 3, 8, 32])) if kind == "rsi" else 0
+        sc = dataclasses.replace(sc, ray_sample_input=rsi)
+        layers = (int(rng.integers(2, 9)), int(rng.integers(2, 9))) if kind == "topo" or rng.random() < 0.5 else (8, 8)
+        widths = (int(rng.choice([64, 128, 256])), int(rng.choice([64, 128, 256]))) if kind == "topo" or rng.random() < 0.5 else (256, 256)
+        skip1 = int(rng.integers(-1, layers[1] - 1)) if layers[1] > 2 else -1
+        if kind == "rsi" and layers == (8, 8) and widths == (256, 256):
+            skip1 = 4
+        wts = O.synthetic_weights(int(rng.integers(1 << 30)), n_in0=sc.n_in0, oracle_bias=float(rng.uniform(-0.3, 0.5)),
+                                  oracle_scale=float(rng.uniform(0.2, 1.0)), layers=layers, widths=widths, skip1=skip1)
     else:
         z, meta, sc = load_case("synthetic_fixed8")
         wts = O.synthetic_weights(int(rng.integers(1 << 30)), oracle_bias=float(rng.uniform(-0.3, 0.5)), oracle_scale=float(rng.uniform(0.2, 1.0)))
     n_max = int(rng.choice([1, 2, 3, 4, 8, 8, 8, 12, 16, 24, 32]))
     thr = float(rng.choice([0.02, 0.05, 0.1, 0.15, 0.2, 0.3, 0.5, 0.9]))
-    if rng.random() < 0.08 and kind not in ("ndc", "pdf"):
+    if kind == "transform":
+        l0 = str(rng.choice(["BCEWithLogitsLoss", "CrossEntropyLoss", "CrossEntropyLossWeighted"]))
+        thr = float(rng.choice([0.4, 0.5, 0.55, 0.6, 0.7])) if l0.startswith("BCE") else float(rng.choice([0.004, 0.012, 0.02, 0.05]))
+        sc = dataclasses.replace(sc, losses0=l0)
+    if kind == "mult":
+        sc = dataclasses.replace(sc, accumulation_mult=str(rng.choice(["weights", "", "alpha"])),
+                                 losses0=str(rng.choice(["NeRFWeightMultiplicationLoss", "NeRFWeightMultiplicationLoss", "MSE"])))
+    if rng.random() < 0.08 and kind not in ("ndc", "pdf", "pdf_ce", "transform"):
         n_max, thr = 128, 0.0                     # dense mode
-    if kind == "pdf":
+    if kind in ("pdf", "pdf_ce"):
         n_max, thr = int(rng.choice([2, 4, 8, 16, 32])), sc.threshold
     sc = dataclasses.replace(sc, num_samples=n_max, threshold=thr)
     w = int(rng.integers(1, 97)); h = int(rng.integers(1, 65))
@@ -109,7 +136,7 @@ def one_case(rng, idx):
     if err32 > 5e-4:
         ok = False; msg.append("fp32 rgb err %.2e" % err32)
     rgb16 = out["bf16"][0]
-    if kind == "pdf":
+    if kind in ("pdf", "pdf_ce"):
         # classic compositing gives the LAST sample of a ray the distance 1e10 (src/nerf_raymarch_common.py:36): its alpha
         # is a step function of the sign of its density, so a bf16-sized error on a density near zero turns a transparent
         # ray opaque.  The bound is therefore on the 97th percentile of the per-ray error in this mode.
