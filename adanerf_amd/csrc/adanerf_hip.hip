@@ -286,6 +286,7 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   for (int i = 0; i < 3; ++i) {
     g.center[i] = cf.viewcellCenter[i];
     I.view_cell_center[i] = cf.viewcellCenter[i];
+    I.view_cell_size[i] = cf.viewcellSize[i];
     r2 += (static_cast<double>(cf.viewcellSize[i]) / 2.0) * (static_cast<double>(cf.viewcellSize[i]) / 2.0);
   }
   // radius = ||view_cell_size / 2||_2 (src/features.py:761); the reference squares the float64 norm

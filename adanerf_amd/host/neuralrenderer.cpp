@@ -19,6 +19,35 @@ NeuralRenderer::~NeuralRenderer() {
   }
 }
 
+int NeuralRenderer::batchesPerFrame() const {
+  const long long rays = static_cast<long long>(info_.width) * info_.height, b = info_.batch_rays > 0 ? info_.batch_rays : rays;
+  return static_cast<int>((rays + b - 1) / (b > 0 ? b : 1));
+}
+
+static adanerf_options options_of(const Settings& settings) {
+  adanerf_options opt;
+  std::memset(&opt, 0, sizeof(opt));
+  opt.width = static_cast<int32_t>(settings.width);
+  opt.height = static_cast<int32_t>(settings.height);
+  opt.batch_rays = static_cast<int32_t>(settings.batch_size);
+  opt.num_samples = settings.num_samples;
+  opt.threshold = settings.threshold;
+  opt.shard_world = 1;
+  return opt;
+}
+
+bool NeuralRenderer::initHostOnly() {
+  const adanerf_options opt = options_of(settings);
+  if (adanerf_host_parse_model(settings.model_path.c_str(), &opt, &info_) != ADANERF_OK) {
+    err = adanerf_last_error(nullptr);
+    return false;
+  }
+  camera.setPosition(info_.view_cell_center);
+  camera.setViewCell(info_.view_cell_size);
+  render_oracle = settings.render_oracle;
+  return true;
+}
+
 bool NeuralRenderer::init() {
   std::cout << "Model Path: " << settings.model_path << std::endl;
   adanerf_options opt;
@@ -76,6 +105,7 @@ bool NeuralRenderer::init() {
       }
   }
   camera.setPosition(info_.view_cell_center);   // Camera::init: pos = view-cell centre (camera.cpp:49)
+  camera.setViewCell(info_.view_cell_size);
   if (world > 1 && adanerf_set_profiling(ctx, 1) != ADANERF_OK) {
     err = adanerf_last_error(ctx);
     return false;

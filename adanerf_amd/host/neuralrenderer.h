@@ -15,8 +15,11 @@ class NeuralRenderer {
   ~NeuralRenderer();
 
   bool init();
+  bool initHostOnly();               // --dry-run: parse the model directory on the host only (no device), for input replay
   bool render();                     // one frame; logs every 100 frames like imagegenerator.cpp:379-393
   void switchRenderOracle() { render_oracle = !render_oracle; }   // neuralrenderer.h: the 'O' key toggle
+  bool renderingOracle() const { return render_oracle; }
+  int batchesPerFrame() const;       // ceil(rays / batch_rays)
   bool writeImageToFile();           // out.bmp in the model directory (neuralrenderer.cpp:184-222)
   const adanerf_info& info() const { return info_; }
   const std::string& error() const { return err; }

@@ -10,6 +10,7 @@ const char* Settings::usage() {
          "               [-nb|--numberOfBatches N] [-w|--writeImages] [-d|--debug]\n"
          "               [--frames N] [--precision bf16|fp16|fp32] [--yaw DEG] [--pitch DEG]\n"
          "               [--samples N] [--threshold T] [--oracle]\n"
+         "               [--script FILE] [--log-camera] [--dry-run]     input replay: one line of events per frame\n"
          "               [--gpus N] [--same-device]\n";
 }
 
@@ -73,6 +74,13 @@ bool Settings::init(int argc, char** argv, std::string* err) {
       same_device = true;
     } else if (a == "--oracle") {
       render_oracle = true;
+    } else if (a == "--script") {
+      if (!need(i, 1)) return false;
+      script = argv[++i];
+    } else if (a == "--log-camera") {
+      log_camera = true;
+    } else if (a == "--dry-run") {
+      dry_run = true;
     } else if (a == "-h" || a == "--help") {
       *err = usage();
       return false;

@@ -19,6 +19,9 @@ class Settings {
   float threshold = -1.f;
   int gpus = 1;                 // --gpus N: one context per GPU in this process, strips exchanged with peer copies over xGMI
   bool same_device = false;     // --same-device: all N contexts on device 0 (exercises the N-GPU path on a 1-GPU box)
+  std::string script;           // --script FILE: replay input events, one line per frame (inputhandler.h)
+  bool log_camera = false;      // --log-camera: print position / yaw / pitch / view per frame
+  bool dry_run = false;         // --dry-run: replay the script without a device (no rendering)
   bool render_oracle = false;   // --oracle: the viewer's 'O' key (inputhandler.cpp:76), sampling-network debug view
 
   // returns false and fills err on a malformed command line

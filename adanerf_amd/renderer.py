@@ -43,7 +43,7 @@ class Info(C.Structure):
                 ("num_samples", C.c_int32), ("threshold", C.c_float), ("dense", C.c_int32), ("use_ndc", C.c_int32),
                 ("precision", C.c_int32), ("compute_units", C.c_int32), ("fov", C.c_float), ("focal", C.c_float),
                 ("view_cell_center", C.c_float * 3), ("view_cell_radius", C.c_float), ("depth_range", C.c_float * 2),
-                ("max_depth", C.c_float), ("sampler_mode", C.c_int32)]
+                ("max_depth", C.c_float), ("sampler_mode", C.c_int32), ("view_cell_size", C.c_float * 3)]
 
 
 class Stats(C.Structure):

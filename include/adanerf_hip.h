@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ADANERF_ABI_VERSION 1
+#define ADANERF_ABI_VERSION 2   /* 2: adanerf_info.view_cell_size appended */
 
 enum {
   ADANERF_OK = 0,
@@ -129,6 +129,7 @@ typedef struct adanerf_info {
   float   depth_range[2];
   float   max_depth;
   int32_t sampler_mode;     /* ADANERF_SAMPLER_* (from rayMarchSampler[1]) */
+  float   view_cell_size[3];/* dataset_info.txt view_cell_size (the viewer's camera speed: max(size / 2), camera.cpp:47) */
 } adanerf_info;
 
 /* per-frame statistics: the fields the reference logs every 100 frames

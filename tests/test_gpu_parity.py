@@ -698,6 +698,56 @@ def test_headless_cli_matches_library(cases, tmp_path):
     assert diff.max() <= 1 and (diff == 0).mean() > 0.99     # the CLI builds its rotation in float64 -> a few LSB flips
 
 
+def _bmp_pixels(path, w, h):
+    bmp = open(path, "rb").read()
+    off = int.from_bytes(bmp[10:14], "little")
+    row_bytes = (w * 3 + 3) & ~3
+    px = np.frombuffer(bmp[off:off + row_bytes * h], dtype=np.uint8).reshape(h, row_bytes)[:, :w * 3].reshape(h, w, 3)
+    return px[::-1, :, ::-1].reshape(-1, 3)                                       # bottom-up BGR -> top-down RGB
+
+
+@pytest.mark.parametrize("end_in_oracle_view", [False, True])
+def test_headless_cli_scripted_input_session(cases, tmp_path, end_in_oracle_view):
+    """SURVEY 8f N3, input handling: a session of key / mouse events replayed through the C++ InputHandler and Camera
+    (one script line per frame), rendered; the last frame (out.bmp) must be what the library renders from the pose the
+    session ended in -- in the image view or, after an 'O' key, the sampling-network view."""
+    import subprocess
+    from adanerf_amd import build as B
+    exe = B.build_cli()
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    md = str(tmp_path / "model")
+    O.write_model_dir(md, sc, wts)
+    w, h = 96, 72
+    lines = ["+w"] * 1 + [""] * 20 + ["-w +a", "", "", "-a b+ 10 10", "m 60 30", "b- 60 30"] + (["-o"] if end_in_oracle_view else []) + [""]
+    script = tmp_path / "session.txt"
+    script.write_text("\n".join(lines) + "\n")
+    out = subprocess.run([exe, md, "-s", str(w), str(h), "-w", "--script", str(script), "--log-camera"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    cam = [l.split() for l in out.stdout.splitlines() if l.startswith("camera ")]
+    assert len(cam) == len(lines)
+    last = cam[-1]
+    pos = np.array([float(last[3]), float(last[4]), float(last[5])], np.float32)
+    yaw, pitch = float(last[7]), float(last[9])
+    assert np.linalg.norm(pos - np.array(sc.view_cell_center, np.float32)) > 0.05
+    assert abs(yaw - (-80.0 - 50 * 0.15)) < 1e-4 and abs(pitch - (-20 * 0.15)) < 1e-4
+    assert last[11] == ("oracle" if end_in_oracle_view else "image")
+    img = _bmp_pixels(os.path.join(md, "out.bmp"), w, h)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, w, h), precision="bf16") as r:
+        r.set_camera(pos, O.camera_rotation(yaw, pitch))
+        if end_in_oracle_view:
+            image = r.empty((w * h, 4), np.uint8)
+            r.render_oracle(image)
+            rgba = image.numpy()
+        else:
+            _, rgba, _ = r.render_numpy()
+    diff = np.abs(img.astype(np.int16) - rgba[:, :3].astype(np.int16))
+    if end_in_oracle_view:
+        assert (diff.max(axis=1) == 0).mean() > 0.97        # a top-3 bin id flips where two oracle values are within rounding
+    else:
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.99    # the CLI builds its rotation in float64 -> a few LSB flips
+
+
 def test_profiling_api_accumulates_frames(cases):
     z, meta, sc, wts, d = cases["classroom_n8_thr02"]
     with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, 128, 96, batch_size=4096), precision="bf16") as r:

@@ -494,3 +494,98 @@ def test_cxx_loader_reads_the_reference_sample_dirs(lib, tmp_path, tag):
     zt = np.zeros(128, dtype=np.float32)
     assert lib.adanerf_host_depth_table(src.encode(), C.byref(o), zt.ctypes.data) == 0
     np.testing.assert_allclose(zt, O.to_world_depth(O.bin_t(np.arange(128)), sc), rtol=3e-7, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY 8f N3 (input handling half): the viewer's InputHandler / Camera movement, replayed from a script without a device
+# ---------------------------------------------------------------------------------------------
+
+def replay_reference_input(script, centre, size, n_batches):
+    """What adanerf_real_time_viewer does with these events, restated in float32 numpy:
+    inputhandler.cpp:19-104 (W/A/S/D/Q/E start / stop movement, O toggles the sampling-network view on key-up, ESC quits,
+    left-button drag -> Camera::MouseDrag), camera.cpp:47-49, 90-91 (speed_mult = max(view_cell_size / 2), start at the
+    view-cell centre with yaw -80, pitch 0), :128-141 (0.15 deg per pixel, pitch clamped to +-89), :143-158 (dir from
+    yaw / pitch, right = dir x (0,0,1) and up = right x dir, neither normalised), :160-185 (one step of
+    0.005 * speed_mult per axis and BATCH)."""
+    f32 = np.float32
+    pos = np.array(centre, f32)
+    yaw, pitch = f32(-80.0), f32(0.0)
+    speed = f32(0.005) * f32(max(s / 2 for s in size))
+    mv = dict(fwd=0, right=0, up=0)
+    keymap = dict(w=("fwd", 1), s=("fwd", -1), a=("right", -1), d=("right", 1), q=("up", 1), e=("up", -1))
+    left, last, oracle, log = False, (0, 0), False, []
+    for line in script:
+        tok = line.split("#")[0].split()
+        i = 0
+        quit_ = False
+        while i < len(tok):
+            t = tok[i]
+            if t in ("b+", "b-", "m"):
+                x, y = int(tok[i + 1]), int(tok[i + 2])
+                i += 3
+                if t == "b+":
+                    left, last = True, (x, y)
+                elif t == "b-":
+                    left = False
+                else:
+                    if left and (x, y) != last:
+                        yaw = f32(yaw - f32(x - last[0]) * f32(0.15))
+                        pitch = f32(np.clip(f32(pitch - f32(y - last[1]) * f32(0.15)), -89.0, 89.0))
+                    last = (x, y)
+                continue
+            i += 1
+            name = t[1:]
+            if name in keymap:
+                axis, sign = keymap[name]
+                mv[axis] = sign if t[0] == "+" else 0
+            elif t == "-o":
+                oracle = not oracle
+            elif t == "-esc":
+                quit_ = True
+        if quit_:
+            break
+        deg = f32(0.017453292519943295)
+        d = np.array([np.cos(yaw * deg) * np.cos(pitch * deg), np.sin(yaw * deg) * np.cos(pitch * deg), np.sin(pitch * deg)], f32)
+        d = (d / np.sqrt((d * d).sum(dtype=f32))).astype(f32)
+        r = np.array([d[1], -d[0], 0], f32)
+        u = np.cross(r, d).astype(f32)
+        for _ in range(n_batches):
+            for vec, k in ((d, "fwd"), (r, "right"), (u, "up")):
+                if mv[k]:
+                    pos = (pos + vec * speed * f32(mv[k])).astype(f32)
+        log.append((pos.copy(), float(yaw), float(pitch), oracle))
+    return log
+
+
+INPUT_SCRIPT = ["+w", "", "-w +d", "b+ 100 100", "m 140 90", "m 150 40   # still dragging", "b- 150 40 -d", "m 10 10", "-o", "+q +s",
+                "-q -o", "+e", "-e -s +a", "b+ 0 0 m 0 -700", "-a b- 0 0", "-esc", "+w"]
+
+
+@pytest.mark.parametrize("n_batches", [1, 3])
+def test_input_replay_moves_the_camera_like_the_viewer(tmp_path, n_batches):
+    import subprocess
+    from adanerf_amd import build as B
+    exe = B.build_cli()
+    z, meta, sc = load_case("classroom_n8_thr02")
+    md = str(tmp_path / "model")
+    O.write_model_dir(md, sc, case_weights(meta))
+    script = tmp_path / "input.txt"
+    script.write_text("\n".join(INPUT_SCRIPT) + "\n")
+    out = subprocess.run([exe, md, "-s", "60", "40", "-nb", str(n_batches), "--script", str(script), "--log-camera", "--dry-run"],
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = [l.split() for l in out.stdout.splitlines() if l.startswith("camera ")]
+    want = replay_reference_input(INPUT_SCRIPT, sc.view_cell_center, sc.view_cell_size, n_batches)
+    assert len(got) == len(want) == 15                         # the ESC line ends the session, the line behind it never runs
+    for g, (pos, yaw, pitch, oracle) in zip(got, want):
+        np.testing.assert_allclose([float(g[3]), float(g[4]), float(g[5])], pos, rtol=0, atol=2e-6)
+        assert abs(float(g[7]) - yaw) < 1e-4 and abs(float(g[9]) - pitch) < 1e-4
+        assert g[11] == ("oracle" if oracle else "image")
+    assert want[13][2] == 89.0 and float(got[13][9]) == 89.0      # the 700-pixel drag runs into the pitch clamp
+    assert any(w[3] for w in want) and not want[-1][3]
+    bad = subprocess.run([exe, md, "--script", str(script), "--dry-run", "--log-camera", "-s", "8", "8", "--frames", "1", "--bogus"],
+                         capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0
+    script.write_text("+w\n+zz\n")
+    bad = subprocess.run([exe, md, "-s", "8", "8", "--script", str(script), "--dry-run"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "malformed script line 2" in bad.stdout
