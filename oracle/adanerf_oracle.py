@@ -17,6 +17,7 @@ Each function cites the reference file:line it restates (paths relative to
 """
 from __future__ import annotations
 
+import dataclasses
 import math
 import os
 import struct
@@ -80,6 +81,10 @@ class Scene:
     sampler: str = "FromClassifiedDepthAdaptive"
     losses0: str = "NeRFWeightMultiplicationLoss"    # losses[0]: BCEWithLogitsLoss -> sigmoid on the oracle output
     ray_sample_input: int = 0                        # raySampleInput[0]: extra encoded points along the ray in the oracle input
+    # sampler == "CoarseFine" (vanilla NeRF): inFeatures [RayMarchFromPoses, RayMarchFromCoarse],
+    # rayMarchSampler [LinearlySpacedZNearZFar, none]; num_samples_coarse uniform samples for net 0 (a NeRF net as well),
+    # num_samples more from its weights for net 1
+    num_samples_coarse: int = 0
 
     @property
     def radius(self) -> float:
@@ -89,6 +94,8 @@ class Scene:
     @property
     def n_in0(self) -> int:
         fp, fd = self.pos_enc[0]      # src/features.py:738-740
+        if self.sampler == "CoarseFine":
+            return 3 + 6 * fp + 3 + 6 * fd        # src/features.py:622 (a RayMarch feature set in front of net 0 too)
         return (self.ray_sample_input * 3 + 3) * (2 * fp + 1) + 3 + 6 * fd
 
     @property
@@ -313,6 +320,18 @@ def synthetic_weights(seed: int, n_in0: int = 90, n_in1_pos: int = 63, n_in1_dir
     return Weights(n0, n1)
 
 
+def synthetic_coarse_fine_weights(seed: int, pos_enc=((10, 4), (10, 4)), alpha_bias: float = 0.0, layers: Tuple[int, int] = (8, 8),
+                                 widths: Tuple[int, int] = (256, 256), skips: Tuple[int, int] = (4, 4)) -> Weights:
+    """Two NeRF nets (src/models.py:199-277) for the coarse/fine mode: net 0 and net 1 both take [PE(pos) | PE(dir)]."""
+    nets = []
+    for i in range(2):
+        fp, fd = pos_enc[i]
+        w = synthetic_weights(seed + 7919 * i, n_in1_pos=3 + 6 * fp, n_in1_dir=3 + 6 * fd, alpha_bias=alpha_bias,
+                              layers=(2, layers[i]), widths=(64, widths[i]), skip1=skips[i])
+        nets.append(w.net1)
+    return Weights(nets[0], nets[1])
+
+
 def write_model_dir(path: str, scene: Scene, weights: Weights) -> None:
     """Writes config.ini / dataset_info.txt / model{0,1}.onnx in the exported format
     (minimal 19-key config form of sample_pavillon_16/config.ini; dataset_info.txt as
@@ -325,11 +344,18 @@ def write_model_dir(path: str, scene: Scene, weights: Weights) -> None:
         f.write("losses = [%s, MSE]\n" % scene.losses0)
         f.write("posEnc = [nerf, nerf]\n")
         f.write("posEncArgs = [%d-%d, %d-%d]\n" % (scene.pos_enc[0] + scene.pos_enc[1]))
-        f.write("inFeatures = [SpherePosDir, RayMarchFromPoses]\n")
-        f.write("outFeatures = [Raw, RGBARayMarch]\n")
-        f.write("rayMarchSampler = [none, %s]\n" % sampler)
-        f.write("rayMarchNormalization = [InverseSqrtDistCentered, %s]\n" % scene.normalization)
-        f.write("numRaymarchSamples = [%d, %d]\n" % (scene.num_samples, scene.num_samples))
+        if scene.sampler == "CoarseFine":
+            f.write("inFeatures = [RayMarchFromPoses, RayMarchFromCoarse]\n")
+            f.write("outFeatures = [RGBARayMarch, RGBARayMarch]\n")
+            f.write("rayMarchSampler = [LinearlySpacedZNearZFar, none]\n")
+            f.write("rayMarchNormalization = [%s, %s]\n" % (scene.normalization, scene.normalization))
+            f.write("numRaymarchSamples = [%d, %d]\n" % (scene.num_samples_coarse, scene.num_samples))
+        else:
+            f.write("inFeatures = [SpherePosDir, RayMarchFromPoses]\n")
+            f.write("outFeatures = [Raw, RGBARayMarch]\n")
+            f.write("rayMarchSampler = [none, %s]\n" % sampler)
+            f.write("rayMarchNormalization = [InverseSqrtDistCentered, %s]\n" % scene.normalization)
+            f.write("numRaymarchSamples = [%d, %d]\n" % (scene.num_samples, scene.num_samples))
         f.write("rayMarchSamplingStep = [0.0078125, 0.0078125]\n")
         f.write("rayMarchSamplingNoise = [0.0, 0.0]\n")
         f.write("raySampleInput = [%d, 0]\n" % scene.ray_sample_input)
@@ -685,6 +711,86 @@ def sample_pdf(orc: np.ndarray, n: int, losses0: str = "BCEWithLogitsLoss") -> n
     return out[:, 1:-1]
 
 
+def coarse_depths(scene: Scene) -> np.ndarray:
+    """LinearlySpacedZNearZFar.generate(det) (src/nerf_raymarch_common.py:310-325): t = linspace(0,1,N+1)[:-1] + 0.5/N,
+    near (1-t) + far t with zNear/zFar of net 0, then depth_transform.to_world over the depth range -> [N] world depths."""
+    n = scene.num_samples_coarse
+    t = (np.linspace(0.0, 1.0, n + 1, dtype=F32)[:-1] + F32(0.5 / n)).astype(F32)
+    zw = (F32(scene.z_near) * (F32(1.0) - t) + F32(scene.z_far) * t).astype(F32)
+    return to_world_depth(zw, scene)
+
+
+def classic_weights(raw: np.ndarray, z: np.ndarray, rays_d: np.ndarray) -> np.ndarray:
+    """The `weights` output of nerf_raw2outputs (src/nerf_raymarch_common.py:33-52): alpha_k T_k, [R,N]."""
+    raw = raw.astype(F32)
+    dists = np.concatenate([z[:, 1:] - z[:, :-1], np.full((z.shape[0], 1), 1e10, dtype=F32)], -1).astype(F32)
+    dists = (dists * np.sqrt(np.sum(rays_d * rays_d, -1, keepdims=True, dtype=F32))).astype(F32)
+    alpha = (F32(1.0) - np.exp(-np.maximum(raw[..., 3], F32(0)) * dists, dtype=F32)).astype(F32)
+    # torch.cumprod / cumsum on CPU accumulate in double (acc_type<float, false>) and store float
+    trans = np.cumprod(np.concatenate([np.ones((alpha.shape[0], 1), np.float64), (F32(1.0) - alpha + F32(1e-10)).astype(np.float64)], -1),
+                       -1)[:, :-1].astype(F32)
+    return (alpha * trans).astype(F32)
+
+
+def sample_pdf_bins(bins: np.ndarray, weights: np.ndarray, n: int) -> np.ndarray:
+    """nerf_sample_pdf(bins, weights, n, det=True) (src/nerf_raymarch_common.py:160-192) as RayMarchFromCoarse.batch calls it
+    (src/features.py:653-654): bins [R,B] edges, weights [R,B-1]; u = linspace(0,1,n); -> [R,n] depths (ascending)."""
+    w = (weights.astype(F32) + F32(1e-5)).astype(F32)
+    pdf = (w / np.sum(w, -1, keepdims=True, dtype=F32)).astype(F32)
+    cdf = np.concatenate([np.zeros((pdf.shape[0], 1), F32), np.cumsum(pdf.astype(np.float64), -1).astype(F32)], -1)
+    u = np.linspace(0.0, 1.0, n, dtype=F32)
+    out = np.empty((cdf.shape[0], n), F32)
+    nb = cdf.shape[1]
+    for r in range(cdf.shape[0]):
+        inds = np.searchsorted(cdf[r], u, side="right")
+        below = np.maximum(inds - 1, 0)
+        above = np.minimum(inds, nb - 1)
+        c0, c1 = cdf[r][below], cdf[r][above]
+        denom = (c1 - c0).astype(F32)
+        denom = np.where(denom < F32(1e-5), F32(1.0), denom).astype(F32)
+        t = ((u - c0) / denom).astype(F32)
+        b0, b1 = bins[r][below], bins[r][above]
+        out[r] = (b0 + t * (b1 - b0)).astype(F32)
+    return out
+
+
+def render_coarse_fine(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: Scene, weights: Weights,
+                       chunk: int = 4096, keep: bool = False):
+    """Vanilla NeRF with hierarchical sampling: RayMarchFromPoses over LinearlySpacedZNearZFar depths ->
+    net 0 -> nerf_raw2outputs weights -> RayMarchFromCoarse (src/features.py:640-672: pdf over the interval mid-points
+    with weights[1:-1], merged and sorted with the coarse depths) -> net 1 -> nerf_raw2outputs.  The reference's own
+    RayMarchFromCoarse.postprocess cannot run (it unpacks five of nerf_raw2outputs' six values, src/features.py:688); its
+    arithmetic is the nerf_raw2outputs call it makes, which is what is restated (and pinned) here."""
+    assert scene.sampler == "CoarseFine" and not scene.use_ndc
+    nc, nf = scene.num_samples_coarse, scene.num_samples
+    zc1 = coarse_depths(scene)
+    acc: Dict[str, list] = {}
+    sc0 = dataclasses.replace(scene, pos_enc=(scene.pos_enc[0], scene.pos_enc[0]))      # shading_inputs reads pos_enc[1]
+    for s in range(0, dirs_cam.shape[0], chunk):
+        nds, _ = world_rays(dirs_cam[s:s + chunk], pose, rot, scene)
+        r = nds.shape[0]
+        p = np.repeat(pose.astype(F32)[None], r, 0)      # the rays start at the camera (src/features.py:426-428), not on the view-cell sphere
+        zc = np.repeat(zc1[None], r, 0)
+        sray = np.repeat(np.arange(r, dtype=np.int32), nc)
+        f0 = shading_inputs(p, nds, sray, zc.reshape(-1), sc0)
+        raw0 = shading_mlp(f0, weights.net0, 3 + 6 * scene.pos_enc[0][0])
+        w0 = classic_weights(raw0.reshape(r, nc, 4), zc, nds)
+        rgb0 = composite_classic(raw0.reshape(r, nc, 4), zc, nds)
+        mid = (F32(0.5) * (zc[:, 1:] + zc[:, :-1])).astype(F32)
+        zf = sample_pdf_bins(mid, w0[:, 1:-1], nf)
+        za = np.sort(np.concatenate([zc, zf], -1), -1).astype(F32)
+        sray = np.repeat(np.arange(r, dtype=np.int32), nc + nf)
+        f1 = shading_inputs(p, nds, sray, za.reshape(-1), scene)
+        raw1 = shading_mlp(f1, weights.net1, 3 + 6 * scene.pos_enc[1][0])
+        rgb, dm, am = composite_classic(raw1.reshape(r, nc + nf, 4), za, nds, aux=True)
+        item = dict(rgb=rgb, depth_map=dm, acc_map=am, count=np.full(r, nc + nf, np.int32))
+        if keep:
+            item.update(nds=nds, p=p, z_coarse=zc, raw0=raw0, weights0=w0, rgb_coarse=rgb0, z_fine=zf, z=za.reshape(-1), feat1=f1, raw=raw1)
+        for k, v in item.items():
+            acc.setdefault(k, []).append(v)
+    return {k: np.concatenate(v) for k, v in acc.items()}
+
+
 def composite_classic(raw: np.ndarray, z: np.ndarray, rays_d: np.ndarray, aux: bool = False):
     """nerf_raw2outputs, src/nerf_raymarch_common.py:19-68 (no noise, no white background, no oracle weights):
     alpha = 1 - exp(-relu(raw_a) * dist * |d|), dist = z[k+1] - z[k] (last 1e10), rgb = sigmoid(raw).
@@ -828,6 +934,8 @@ def render_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: 
     """TrainConfig.inference (src/train_data.py:278-299) over chunks
     (src/evaluate.py:206-241).  Returns dict with rgb [R,3], count [R] and, when ``keep``,
     every intermediate the golden fixtures hold."""
+    if scene.sampler == "CoarseFine":
+        return render_coarse_fine(dirs_cam, pose, rot, scene, weights, min(chunk, 4096), keep)
     out_rgb = []
     out_cnt = []
     out_depth = []

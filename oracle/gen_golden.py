@@ -10,6 +10,7 @@ BASELINE configs 1-3 into tests/golden/reference_cpu_timing.json (``--timing``).
 
 Usage:  python oracle/gen_golden.py [--timing]
 """
+import dataclasses
 import argparse
 import json
 import math
@@ -235,6 +236,79 @@ def save_case(name, scene, meta, dirs, pose, rot, ref, n_max, weights_tag):
     sz = os.path.getsize(os.path.join(GOLD, name + ".npz"))
     print("wrote %s.npz (%d KB)  rays=%d samples=%d mean=%.2f" %
           (name, sz // 1024, count.shape[0], int(count.sum()), float(count.mean())))
+
+
+def gen_coarse_fine(R, name="classroom_coarse_fine_16_24"):
+    """Vanilla NeRF with hierarchical sampling: inFeatures [RayMarchFromPoses, RayMarchFromCoarse].  The reference
+    cannot run this through TrainConfig.inference -- RayMarchFromCoarse.postprocess (src/features.py:688) unpacks five of the six
+    values nerf_raw2outputs returns -- so the fixture drives the same objects step by step, exactly as inference() would
+    (src/train_data.py:278-299): f_in[0].batch -> model 0 -> f_in[0].postprocess -> f_in[1].batch(prev_outs) -> model 1, and
+    then makes the nerf_raw2outputs call of that postprocess itself."""
+    if ONLY is not None and name not in ONLY:
+        return
+    torch = R.torch
+    K = R.features.FeatureSetKeyConstants
+    nc, nf = 16, 24
+    sc = dataclasses.replace(classroom_scene(nf, 0.0), sampler="CoarseFine", num_samples_coarse=nc, losses0="MSE", accumulation_mult="")
+    wts = O.synthetic_coarse_fine_weights(31, alpha_bias=1.5)
+    cfg = make_config(sc)
+    cfg.inFeatures = ["RayMarchFromPoses", "RayMarchFromCoarse"]
+    cfg.outFeatures = ["RGBARayMarch", "RGBARayMarch"]
+    cfg.activation = ["nerf", "nerf"]
+    cfg.skips = ["auto", "auto"]
+    cfg.losses = ["MSE", "MSE"]
+    cfg.numRaymarchSamples = [nc, nf]
+    cfg.rayMarchSampler = ["LinearlySpacedZNearZFar", "none"]
+    cfg.rayMarchNormalization = [sc.normalization, sc.normalization]
+    cfg.accumulationMult = None
+    f_in, f_out = R.features.FeatureSet.get_sets(cfg, "cpu")
+    w, h = 400, 400
+    view = SimpleNamespace(fov=sc.fov, focal=O.focal_from_fov(w, sc.fov), view_cell_center=list(sc.view_cell_center),
+                           view_cell_size=list(sc.view_cell_size))
+    di = SimpleNamespace(w=w, h=h, view=view, depth_max=sc.max_depth, depth_range=list(sc.depth_range),
+                         depth_range_warped=list(sc.depth_range),
+                         depth_transform=R.dt.LogTransform if sc.depth_transform == "log" else R.dt.LinearTransform,
+                         use_warped_depth_range=[False, False])
+    for f in f_in:
+        f.initialize(cfg, di, "cpu")
+    models = []
+    for i, net in enumerate([wts.net0, wts.net1]):
+        m = R.models.ModelSelection.getModel(cfg, f_in[i].n_feat, 4, "cpu", i)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in net.items()})
+        m.eval()
+        models.append(m)
+    pose = np.array(sc.view_cell_center, dtype=np.float32) + np.array([0.05, -0.1, 0.02], np.float32)
+    rot = O.camera_rotation(100.0, 5.0)
+    dirs = subset_dirs(w, h, sc.fov, 120, 150, 24, 16, 7)
+    batch = {"ImagePose": torch.from_numpy(pose[None].copy()), "ImageRotation": torch.from_numpy(rot[None].copy()),
+             "RayDirectionsSamples": torch.from_numpy(dirs[None].copy())}
+    with torch.no_grad():
+        d0 = f_in[0].batch(batch, prev_outs=[], is_inference=True)
+        d0[K.network_output] = models[0](d0[K.input_feature_batch])
+        f_in[0].postprocess(d0, batch)
+        d1 = f_in[1].batch(batch, prev_outs=[d0], is_inference=True)
+        d1[K.network_output] = models[1](d1[K.input_feature_batch])
+        n = dirs.shape[0]
+        zv = d1[K.nerf_input_feature_z_vals]
+        rgb, disp, accm, w1, depth_map, alpha = R.nrc.nerf_raw2outputs(d1[K.network_output].reshape(n, zv.shape[1], -1), zv,
+                                                                        d1[K.nerf_input_feature_ray_directions])
+    meta = dict(w=w, h=h, crop=[120, 150, 24, 16, 7], yaw=100.0, pitch=5.0, view_cell_center=list(sc.view_cell_center),
+                view_cell_size=list(sc.view_cell_size), depth_range=list(sc.depth_range), fov=sc.fov, max_depth=sc.max_depth,
+                num_samples=nf, num_samples_coarse=nc, threshold=0.0, z_near=sc.z_near, z_far=sc.z_far, use_ndc=False,
+                depth_transform=sc.depth_transform, pos_enc=[list(sc.pos_enc[0]), list(sc.pos_enc[1])], normalization=sc.normalization,
+                accumulation_mult="", sampler="CoarseFine", losses0="MSE", ray_sample_input=0,
+                weights="synthetic_coarse_fine:31:1.5")
+    np.savez_compressed(
+        os.path.join(GOLD, name + ".npz"), meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8),
+        pose=pose, rot=rot, ray_dirs=dirs.astype(np.float32),
+        nds=d0[K.nerf_input_feature_ray_directions].numpy().astype(np.float32), p=d0[K.nerf_input_feature_ray_origins].numpy().astype(np.float32),
+        z_coarse=d0[K.nerf_input_feature_z_vals].numpy().astype(np.float32), coarse_in=d0[K.input_feature_batch][:64].numpy().astype(np.float32),
+        coarse_out=d0[K.network_output].numpy().astype(np.float32), coarse_weights=d0[K.nerf_weights_output].numpy().astype(np.float32),
+        coarse_rgb=d0[K.postprocessed_network_output].numpy().astype(np.float32),
+        z_world=zv.numpy().astype(np.float32), shade_in=d1[K.input_feature_batch][:64].numpy().astype(np.float32),
+        shade_out=d1[K.network_output].numpy().astype(np.float32), rgb=rgb.numpy().astype(np.float32),
+        depth_map=depth_map.numpy().astype(np.float32), acc=accm.numpy().astype(np.float32))
+    print("wrote %s.npz  rays=%d  coarse %d + fine %d samples" % (name, n, nc, nf))
 
 
 def gen_selection_edge_cases(R):
@@ -473,6 +547,7 @@ def main():
 
     if not args.only:
         gen_selection_edge_cases(R)
+    gen_coarse_fine(R)
 
     if args.timing:
         timing = {"host": "build container", "threads": torch.get_num_threads(), "dtype": "fp32",

@@ -27,7 +27,8 @@ def load_case(name):
                  pos_enc=(tuple(meta["pos_enc"][0]), tuple(meta["pos_enc"][1])),
                  normalization=meta["normalization"], accumulation_mult=meta["accumulation_mult"],
                  sampler=meta.get("sampler", "FromClassifiedDepthAdaptive"),
-                 losses0=meta.get("losses0", "NeRFWeightMultiplicationLoss"), ray_sample_input=meta.get("ray_sample_input", 0))
+                 losses0=meta.get("losses0", "NeRFWeightMultiplicationLoss"), ray_sample_input=meta.get("ray_sample_input", 0),
+                 num_samples_coarse=meta.get("num_samples_coarse", 0))
     return z, meta, sc
 
 
@@ -37,6 +38,9 @@ def case_weights(meta):
     extracted from the exported ONNX initializers by oracle/gen_golden.py)."""
     import adanerf_oracle as O
     tag = meta["weights"]
+    if tag.startswith("synthetic_coarse_fine:"):       # two NeRF nets (vanilla coarse/fine mode): "synthetic_coarse_fine:<seed>:<alpha bias>"
+        _, seed, ab = tag.split(":")
+        return O.synthetic_coarse_fine_weights(int(seed), pos_enc=(tuple(meta["pos_enc"][0]), tuple(meta["pos_enc"][1])), alpha_bias=float(ab))
     if tag == "synthetic":
         s = meta["syn"]
         return O.synthetic_weights(s["seed"], n_in0=s.get("n_in0", 90), oracle_bias=s["oracle_bias"],
@@ -69,4 +73,5 @@ PDF_CASES = ["classroom_pdf_n8", "ndc_pdf_n8", "classroom_pdf_ce_n8"]
 # fixtures that also carry the secondary compositing outputs (NeRFOutputDepth, accumulated opacity)
 # topologies other than 8 x 256 / skip 4, and the raySampleInput oracle input
 TOPOLOGY_CASES = ["syn_6x128_skip2", "syn_d2w128_d3w256_skip1", "syn_rsi128_4x128"]
+COARSE_FINE_CASES = ["classroom_coarse_fine_16_24"]      # vanilla NeRF, hierarchical sampling
 AUX_CASES = ["classroom_n8_aux", "ndc_n8_aux", "classroom_n8_mult_weights", "classroom_n8_bce_thr06", "ndc_pdf_n8", "classroom_pdf_ce_n8"]
