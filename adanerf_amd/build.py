@@ -10,7 +10,7 @@ LIBDIR = os.path.join(HERE, "lib")
 BINDIR = os.path.join(HERE, "bin")
 LIB_SOURCES = ["adanerf_hip.hip", "launch_f32.hip", "format.cpp", "pack.cpp"]
 KERNEL_HEADERS = ["kernels.hip.hpp", "k_common.hip.hpp", "k_mlp_f32.hip.hpp", "k_compact.hip.hpp", "k_select_pair.hip.hpp", "k_generic_f32.hip.hpp", "k_mlp16.hip.hpp",
-                  "k_sampling16.hip.hpp", "k_donerf.hip.hpp", "k_composite.hip.hpp", "launch_f32.hpp", "x_handsched.hip.hpp"]
+                  "k_sampling16.hip.hpp", "k_donerf.hip.hpp", "k_coarse_fine.hip.hpp", "k_composite.hip.hpp", "launch_f32.hpp", "x_handsched.hip.hpp"]
 LIB_DEPS = LIB_SOURCES + KERNEL_HEADERS + ["tuning.hpp", "layout.hpp", "format.hpp", "pack.hpp", os.path.join("..", "..", "include", "adanerf_hip.h")]
 ARCH = "gfx950"
 # -ffp-contract=off: the fused and the debug kernels must generate bit-identical rays.

@@ -73,6 +73,16 @@ struct adanerf_ctx {
   PackedDev net1[3];              // shading net per precision (packed lazily)
   TensorMap net1_host;
   DevBuf ztab;
+  // vanilla NeRF (ADANERF_SAMPLER_COARSE_FINE): model0.onnx is a NeRF net as well, evaluated at n_coarse uniform depths
+  bool coarse_fine = false;
+  int n_coarse = 0;
+  PackedDev netc[3];              // coarse net per precision (packed lazily)
+  NetTopology topoc;
+  bool genericc = false;
+  GenericTopo genc{};
+  ShadeParams spc{};              // its sample positions: uniform depth table, rayMarchNormalization[0]
+  DevBuf ztab_coarse, raw_coarse, key_coarse;
+  int shade_gen_grid_c = 0;
 
   // per-batch buffers
   int cap_rays = 0, cap_nmax = 0;
@@ -153,6 +163,10 @@ struct ModelSetup {
   std::vector<float> rsi_z;
   std::vector<float> ztab;
   DepthMap dm{};
+  bool coarse_fine = false;
+  int n_coarse = 0;
+  std::vector<float> ztab_coarse;
+  bool normalize0 = false;
 };
 
 Elem elem_of(int prec) {
@@ -180,12 +194,20 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   const Config& cf = ms->cfg;
 
   // ---- validate the configuration against the supported (north-star) path ----
-  if (cf.inFeatures.size() != 2 || cf.inFeatures[0] != "SpherePosDir" || cf.inFeatures[1] != "RayMarchFromPoses")
-    return bad(ADANERF_EUNSUPPORTED, "inFeatures must be [SpherePosDir, RayMarchFromPoses]");
+  const bool coarse_fine = cf.inFeatures.size() == 2 && cf.inFeatures[0] == "RayMarchFromPoses" && cf.inFeatures[1] == "RayMarchFromCoarse";
+  ms->coarse_fine = coarse_fine;
+  if (!coarse_fine && (cf.inFeatures.size() != 2 || cf.inFeatures[0] != "SpherePosDir" || cf.inFeatures[1] != "RayMarchFromPoses"))
+    return bad(ADANERF_EUNSUPPORTED, "inFeatures must be [SpherePosDir, RayMarchFromPoses] or [RayMarchFromPoses, RayMarchFromCoarse]");
   if (cf.posEnc.size() != 2 || cf.posEnc[0] != "nerf" || cf.posEnc[1] != "nerf" || cf.posEncArgs.size() != 2)
     return bad(ADANERF_EUNSUPPORTED, "posEnc must be [nerf, nerf] with two posEncArgs entries");
-  const bool pdf_mode = cf.rayMarchSampler.size() == 2 && cf.rayMarchSampler[1] == "FromClassifiedDepth";
-  if (cf.rayMarchSampler.size() != 2 || (!pdf_mode && !contains(cf.rayMarchSampler[1], "FromClassifiedDepthAdaptive")))
+  const bool pdf_mode = !coarse_fine && cf.rayMarchSampler.size() == 2 && cf.rayMarchSampler[1] == "FromClassifiedDepth";
+  if (coarse_fine) {
+    // RayMarchFromPoses without an oracle in front draws its depths from rayMarchSampler[0] (src/features.py:431-436)
+    if (cf.rayMarchSampler.empty() || cf.rayMarchSampler[0] != "LinearlySpacedZNearZFar")
+      return bad(ADANERF_EUNSUPPORTED, "coarse/fine: rayMarchSampler[0] must be LinearlySpacedZNearZFar");
+    if (cf.useNDC) return bad(ADANERF_EUNSUPPORTED, "coarse/fine: useNDC is not supported");
+    if (cf.numRaymarchSamples.size() != 2) return bad(ADANERF_EIO, "coarse/fine: numRaymarchSamples must be [Nc, Nf]");
+  } else if (cf.rayMarchSampler.size() != 2 || (!pdf_mode && !contains(cf.rayMarchSampler[1], "FromClassifiedDepthAdaptive")))
     return bad(ADANERF_EUNSUPPORTED, "rayMarchSampler[1] must be FromClassifiedDepthAdaptive[NoDepthRange] or FromClassifiedDepth");
   // The transform every sampler applies to the raw oracle outputs follows losses[0] (src/nerf_raymarch_common.py:624-630,
   // 686-690, 782-788).  A model directory without a losses key (the trimmed 19-key config.ini) is an AdaNeRF export
@@ -206,21 +228,29 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   ms->fd0 = static_cast<int>(cf.posEncArgs[0][1]);
   ms->fp1 = static_cast<int>(cf.posEncArgs[1][0]);
   ms->fd1 = static_cast<int>(cf.posEncArgs[1][1]);
+  if (coarse_fine && (ms->fp0 != 10 || ms->fd0 != 4)) return bad(ADANERF_EUNSUPPORTED, "coarse/fine: posEncArgs[0] must be 10-4");
   if (!((ms->fp0 == 10 && ms->fd0 == 4) || (ms->fp0 == 2 && ms->fd0 == 2)))
     return bad(ADANERF_EUNSUPPORTED, "posEncArgs[0] must be 10-4 or 2-2");
   if (ms->fp1 != 10 || ms->fd1 != 4) return bad(ADANERF_EUNSUPPORTED, "posEncArgs[1] must be 10-4");
   const bool ndc = cf.useNDC;
-  const bool no_range = contains(cf.rayMarchSampler[1], "NoDepthRange");
-  if (!pdf_mode && ndc != no_range) return bad(ADANERF_EUNSUPPORTED, "useNDC requires the NoDepthRange sampler and vice versa");
+  const bool no_range = !coarse_fine && contains(cf.rayMarchSampler[1], "NoDepthRange");
+  if (!pdf_mode && !coarse_fine && ndc != no_range) return bad(ADANERF_EUNSUPPORTED, "useNDC requires the NoDepthRange sampler and vice versa");
   std::string norm = cf.rayMarchNormalization.size() >= 2 ? cf.rayMarchNormalization[1] : std::string("None");
   if (norm != "InverseSqrtDistCentered" && norm != "None")
     return bad(ADANERF_EUNSUPPORTED, "rayMarchNormalization[1] must be InverseSqrtDistCentered or None");
   if (cf.depthTransform != "log" && cf.depthTransform != "linear")
     return bad(ADANERF_EUNSUPPORTED, "depthTransform must be log or linear");
+  if (coarse_fine) {
+    const std::string norm0 = cf.rayMarchNormalization.empty() ? std::string("None") : cf.rayMarchNormalization[0];
+    if (norm0 != "InverseSqrtDistCentered" && norm0 != "None")
+      return bad(ADANERF_EUNSUPPORTED, "rayMarchNormalization[0] must be InverseSqrtDistCentered or None");
+    ms->normalize0 = norm0 == "InverseSqrtDistCentered";
+  }
   if (cf.accumulationMult == "alpha") ms->mult_mode = 1;
   else if (cf.accumulationMult == "weights") ms->mult_mode = 2;
   else ms->mult_mode = 0;
-  if (!pdf_mode && !cf.losses.empty()) {
+  if (coarse_fine) ms->mult_mode = 0;
+  if (!pdf_mode && !coarse_fine && !cf.losses.empty()) {
     // losses[0] drives two things on the adaptive path (src/nerf_raymarch_common.py:686-690, src/features.py:503):
     // the transform applied to the oracle outputs before the threshold test (sigmoid / softmax for the BCE / CE losses)
     // and whether the kept oracle values reach compositing at all (only under NeRFWeightMultiplicationLoss).
@@ -229,10 +259,17 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
 
   int n_max = opt->num_samples > 0 ? opt->num_samples : cf.numRaymarchSamples.back();
   float thr = opt->threshold >= 0.f ? opt->threshold : cf.adaptiveSamplingThreshold;
-  if (pdf_mode) thr = 1.0f;   // unused by the inverse-CDF sampler; any positive value keeps the bin-centre depth table
+  if (pdf_mode || coarse_fine) thr = 1.0f;   // unused by the inverse-CDF samplers; any positive value keeps the bin-centre depth table
+  if (coarse_fine) {
+    // numRaymarchSamples = [Nc, Nf] (options.num_samples overrides Nf); every ray carries Nc + Nf samples through model1
+    ms->n_coarse = cf.numRaymarchSamples[0];
+    if (ms->n_coarse < 3 || ms->n_coarse > kMaxCoarse) return bad(ADANERF_EINVAL, "coarse/fine: numRaymarchSamples[0] must be in 3..128");
+    if (n_max < 1 || ms->n_coarse + n_max > 1024) return bad(ADANERF_EINVAL, "coarse/fine: numRaymarchSamples[1] must be >= 1 and Nc + Nf <= 1024");
+    n_max += ms->n_coarse;
+  }
   if (thr < 0.f) return bad(ADANERF_EUNSUPPORTED, "adaptiveSamplingThreshold < 0 is unsupported on the adaptive path (as in the reference)");
   if (thr == 0.f && n_max != kBins) return bad(ADANERF_EUNSUPPORTED, "adaptiveSamplingThreshold == 0 (dense) requires numRaymarchSamples == 128");
-  if (n_max < 1 || n_max > kBins) return bad(ADANERF_EINVAL, "numRaymarchSamples must be in 1..128");
+  if (!coarse_fine && (n_max < 1 || n_max > kBins)) return bad(ADANERF_EINVAL, "numRaymarchSamples must be in 1..128");
   if (opt->precision < 0 || opt->precision > 2) return bad(ADANERF_EINVAL, "precision must be ADANERF_PREC_{BF16,FP16,FP32}");
   if (opt->sampling_mode < 0 || opt->sampling_mode > 2) return bad(ADANERF_EINVAL, "sampling_mode must be ADANERF_SAMPLING_{SPLIT_FP16,FP32,FP16}");
 
@@ -256,12 +293,14 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   if (static_cast<int64_t>(I.batch_rays) * n_max > 0x7fffffffll)
     return bad(ADANERF_EINVAL, "batch_rays * num_samples exceeds 2^31 - 1; use a smaller batch (-bs)");
   I.n_in0 = (ms->ray_samples * 3 + 3) * (2 * ms->fp0 + 1) + 3 + 6 * ms->fd0;     // src/features.py:738-740
+  if (coarse_fine) I.n_in0 = 6 + 6 * (ms->fp0 + ms->fd0);                          // src/features.py:622
   I.n_in1 = 6 + 6 * (ms->fp1 + ms->fd1);
   I.num_samples = n_max;
   I.threshold = thr;
   I.dense = thr == 0.f;
   I.use_ndc = ndc;
-  I.sampler_mode = pdf_mode ? ADANERF_SAMPLER_PDF : ADANERF_SAMPLER_ADAPTIVE;
+  I.sampler_mode = coarse_fine ? ADANERF_SAMPLER_COARSE_FINE : (pdf_mode ? ADANERF_SAMPLER_PDF : ADANERF_SAMPLER_ADAPTIVE);
+  I.num_samples_coarse = ms->n_coarse;
   I.precision = opt->precision;
   I.fov = cf.fov;
   const double fov = cf.fov;
@@ -343,6 +382,18 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
     else z = t * (d1 - d0) + d0;                               // :57-58
     ms->ztab[k] = z;
   }
+  // coarse/fine: LinearlySpacedZNearZFar.generate (src/nerf_raymarch_common.py:310-325): t = linspace(0,1,Nc+1)[:-1] + 0.5/Nc,
+  // near (1-t) + far t with zNear[0] / zFar[0], then depth_transform.to_world over the depth range
+  for (int k = 0; k < ms->n_coarse; ++k) {
+    const int A = ms->n_coarse + 1;
+    const float inc = 1.0f / static_cast<float>(A - 1);
+    const float lin = (k < A / 2) ? inc * static_cast<float>(k) : 1.0f - inc * static_cast<float>(A - 1 - k);      // torch.linspace, fp32
+    const float t = lin + static_cast<float>(0.5 / ms->n_coarse);
+    const float zn = cf.zNear.empty() ? 0.001f : cf.zNear.front(), zf = cf.zFar.empty() ? 1.0f : cf.zFar.front();
+    const float zw = zn * (1.0f - t) + zf * t;
+    ms->ztab_coarse.push_back(cf.depthTransform == "log" ? powf(static_cast<float>(static_cast<double>(d1) - d0 + 1.0), zw) - 1.0f + d0
+                                                         : zw * (d1 - d0) + d0);
+  }
   return ADANERF_OK;
 }
 
@@ -357,6 +408,17 @@ int ensure_net1(adanerf_ctx* c, int prec) {
 }
 
 
+// coarse/fine: model0.onnx is a NeRF net with the encoding posEncArgs[0]
+int ensure_netc(adanerf_ctx* c, int prec) {
+  if (prec < 0 || prec > 2) return fail(c, ADANERF_EINVAL, "precision must be ADANERF_PREC_{BF16,FP16,FP32}");
+  if (c->netc[prec].w.p) return ADANERF_OK;
+  PackedNet pn;
+  std::string err;
+  NetShape sh{c->fp0, c->fd0, c->fp0, c->fd0, 0};
+  if (!pack_shading_net(c->net0_host, sh, elem_of(prec), &pn, &err)) return fail(c, ADANERF_EIO, "model0.onnx: " + err);
+  return upload_net(c, pn, &c->netc[prec]);
+}
+
 int ensure_batch_buffers(adanerf_ctx* c, int n_rays, int n_max) {
   if (n_rays <= c->cap_rays && n_max <= c->cap_nmax) return ADANERF_OK;
   n_rays = std::max(n_rays, c->cap_rays);
@@ -365,11 +427,18 @@ int ensure_batch_buffers(adanerf_ctx* c, int n_rays, int n_max) {
   const size_t nblk = (R + 31) / 32;     // segment totals: per 64 rays (select_kernel) or per 32 (pair selection)
   int rc;
   if ((rc = dev_alloc(c, &c->rays, R * 8 * sizeof(float)))) return rc;
-  if ((rc = dev_alloc(c, &c->oracle, R * kBins * sizeof(float)))) return rc;
   if ((rc = dev_alloc(c, &c->ray_offsets, R * sizeof(int32_t)))) return rc;
   if ((rc = dev_alloc(c, &c->ray_counts, R * sizeof(int32_t)))) return rc;
-  if ((rc = dev_alloc(c, &c->selbin, S))) return rc;
-  if ((rc = dev_alloc(c, &c->selw, S * sizeof(float)))) return rc;
+  if (c->coarse_fine) {      // no oracle values, no selection scratch; the coarse pass has its own keys and raw outputs
+    const size_t Sc = R * static_cast<size_t>(c->n_coarse);
+    if ((rc = dev_alloc(c, &c->key_coarse, Sc * sizeof(uint32_t)))) return rc;
+    if ((rc = dev_alloc(c, &c->raw_coarse, Sc * 4 * sizeof(float)))) return rc;
+    if ((rc = dev_alloc(c, &c->sample_z, S * sizeof(float)))) return rc;
+  } else {
+    if ((rc = dev_alloc(c, &c->oracle, R * kBins * sizeof(float)))) return rc;
+    if ((rc = dev_alloc(c, &c->selbin, S))) return rc;
+    if ((rc = dev_alloc(c, &c->selw, S * sizeof(float)))) return rc;
+  }
   if ((rc = dev_alloc(c, &c->block_total, nblk * sizeof(int32_t)))) return rc;
   if ((rc = dev_alloc(c, &c->block_offset, nblk * sizeof(int32_t)))) return rc;
   if ((rc = dev_alloc(c, &c->total, 64))) return rc;
@@ -529,14 +598,19 @@ int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max,
 constexpr int kShadeWaves = 8;   // one 8-wave workgroup per CU (two independent 4-wave workgroups measured 4.2-5.7 ms vs 3.8)
 
 int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, const int32_t* d_total, int max_samples, int prec,
-                     float* d_raw, const float* d_z = nullptr) {
+                     float* d_raw, const float* d_z = nullptr, bool coarse = false) {
   if (max_samples <= 0) return ADANERF_OK;
-  if (c->generic1) prec = ADANERF_PREC_FP32;      // other topologies run on the fp32 engine whatever precision is asked for
-  int rc = ensure_net1(c, prec);
+  // coarse: the first network of the vanilla-NeRF mode (model0.onnx as a NeRF net, uniform depth table)
+  const bool generic = coarse ? c->genericc : c->generic1;
+  const NetTopology& topo = coarse ? c->topoc : c->topo1;
+  const GenericTopo& gen = coarse ? c->genc : c->gen1;
+  int& gen_grid = coarse ? c->shade_gen_grid_c : c->shade_gen_grid;
+  if (generic) prec = ADANERF_PREC_FP32;      // other topologies run on the fp32 engine whatever precision is asked for
+  int rc = coarse ? ensure_netc(c, prec) : ensure_net1(c, prec);
   if (rc) return rc;
   ShadeArgs a{};
-  a.sp = c->sp;
-  a.net = c->net1[prec].params;
+  a.sp = coarse ? c->spc : c->sp;
+  a.net = coarse ? c->netc[prec].params : c->net1[prec].params;
   a.rays = d_rays;
   a.sample_key = d_key;
   a.sample_z = d_z;
@@ -544,10 +618,10 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
   a.max_samples = max_samples;
   a.raw_out = d_raw;
   if (c->fp1 != 10 || c->fd1 != 4) return fail(c, ADANERF_EUNSUPPORTED, "shading net posEncArgs must be 10-4");
-  if (c->generic1) {
-    if (!c->shade_gen_grid) HIP_TRY(c, shade_mlp_gen_grid(c->info.compute_units, c->topo1.width, &c->shade_gen_grid));
+  if (generic) {
+    if (!gen_grid) HIP_TRY(c, shade_mlp_gen_grid(c->info.compute_units, topo.width, &gen_grid));
     const int tiles = (max_samples + 127) / 128;
-    HIP_TRY(c, launch_shade_mlp_gen(a, c->gen1, c->topo1.width, std::min(tiles, c->shade_gen_grid), c->stream));
+    HIP_TRY(c, launch_shade_mlp_gen(a, gen, topo.width, std::min(tiles, gen_grid), c->stream));
   } else if (prec == ADANERF_PREC_FP32) {
     if (!c->shade_grid[2]) HIP_TRY(c, shade_mlp_f32_grid(c->info.compute_units, &c->shade_grid[2]));
     const int tiles = (max_samples + 127) / 128;
@@ -574,6 +648,31 @@ int launch_sample_pdf(adanerf_ctx* c, const float* d_oracle, int n_rays, int n, 
   if (n_rays <= 0) return ADANERF_OK;
   const int grid = std::min((n_rays + 3) / 4, c->info.compute_units * 8);
   hipLaunchKernelGGL(pdf_sample_kernel, dim3(grid), dim3(256), 0, c->stream, d_oracle, n_rays, n, c->transform, c->dm, d_off, d_cnt, d_key, d_w, d_z, d_total);
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+int launch_camera_rays(adanerf_ctx* c, int first_ray, int n_rays, float* d_rays) {
+  if (n_rays <= 0) return ADANERF_OK;
+  hipLaunchKernelGGL(camera_rays_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, c->stream, c->rg, first_ray, n_rays, d_rays);
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+int launch_sample_uniform(adanerf_ctx* c, int n_rays, int n, int32_t* d_off, int32_t* d_cnt, uint32_t* d_key, int32_t* d_total) {
+  if (n_rays <= 0) return ADANERF_OK;
+  const int64_t s = static_cast<int64_t>(n_rays) * n;
+  hipLaunchKernelGGL(uniform_sample_kernel, dim3(static_cast<unsigned>((s + 255) / 256)), dim3(256), 0, c->stream, n_rays, n, d_off, d_cnt, d_key, d_total);
+  HIP_TRY(c, hipGetLastError());
+  return ADANERF_OK;
+}
+
+int launch_sample_fine(adanerf_ctx* c, const float* d_raw_coarse, const float* d_rays, int n_rays, int32_t* d_off, int32_t* d_cnt,
+                       uint32_t* d_key, float* d_z, int32_t* d_total) {
+  if (n_rays <= 0) return ADANERF_OK;
+  hipLaunchKernelGGL(fine_sample_kernel, dim3((n_rays + kFineRaysPerBlock - 1) / kFineRaysPerBlock), dim3(kFineRaysPerBlock), 0, c->stream,
+                     reinterpret_cast<const float4*>(d_raw_coarse), reinterpret_cast<const float*>(c->ztab_coarse.p), d_rays, n_rays, c->n_coarse,
+                     c->info.num_samples - c->n_coarse, d_off, d_cnt, d_key, d_z, d_total);
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;
 }
@@ -654,6 +753,8 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   c->fd0 = ms.fd0;
   c->fp1 = ms.fp1;
   c->fd1 = ms.fd1;
+  c->coarse_fine = ms.coarse_fine;
+  c->n_coarse = ms.n_coarse;
 
   // ---- weights: parse + pack on the host before touching the device ----
   TensorMap& n0 = c->net0_host;
@@ -662,11 +763,20 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   c->ray_samples = ms.ray_samples;
   NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1, c->ray_samples};
   PackedNet p0, p1;
-  if (!pack_sampling_net(n0, sh, Elem::F32, &p0, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
-  c->topo0 = p0.topo;
-  c->generic0 = !p0.topo.is_default(false);
   PackedNet p0s;
-  if (!c->generic0 && !pack_sampling_net(n0, sh, Elem::F16_SPLIT, &p0s, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
+  if (c->coarse_fine) {       // model0.onnx is a NeRF net here (src/models.py:199-277); probe its topology with the fp32 packing
+    NetShape shc{c->fp0, c->fd0, c->fp0, c->fd0, 0};
+    if (!pack_shading_net(n0, shc, Elem::F32, &p0, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
+    c->topoc = p0.topo;
+    c->genericc = !p0.topo.is_default(true);
+    if (!c->genericc && opt->precision != ADANERF_PREC_FP32 && !pack_shading_net(n0, shc, elem_of(opt->precision), &p0, &err))
+      return bail(ADANERF_EIO, "model0.onnx: " + err);
+  } else {
+    if (!pack_sampling_net(n0, sh, Elem::F32, &p0, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
+    c->topo0 = p0.topo;
+    c->generic0 = !p0.topo.is_default(false);
+    if (!c->generic0 && !pack_sampling_net(n0, sh, Elem::F16_SPLIT, &p0s, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
+  }
   c->sampling_mode = opt->sampling_mode;
   {   // topology of the shading net first (fp32 packing accepts every supported topology)
     PackedNet probe;
@@ -679,6 +789,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   }
   // the run-time-shaped fp32 kernels are instantiated for these widths (k_generic_f32.hip.hpp)
   auto width_ok = [](int w) { return w == 64 || w == 128 || w == 256; };
+  if (c->genericc && !width_ok(c->topoc.width)) return bail(ADANERF_EUNSUPPORTED, "model0.onnx: layer width " + std::to_string(c->topoc.width) + " (64, 128 or 256 supported)");
   if (c->generic0 && !width_ok(c->topo0.width)) return bail(ADANERF_EUNSUPPORTED, "model0.onnx: layer width " + std::to_string(c->topo0.width) + " (64, 128 or 256 supported)");
   if (c->generic1 && !width_ok(c->topo1.width)) return bail(ADANERF_EUNSUPPORTED, "model1.onnx: layer width " + std::to_string(c->topo1.width) + " (64, 128 or 256 supported)");
 
@@ -701,8 +812,19 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   if (hipMemcpy(c->ztab.p, ms.ztab.data(), kBins * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
     return bail(ADANERF_EDEVICE, "ztab upload failed");
   c->sp.ztab = reinterpret_cast<const float*>(c->ztab.p);
-  if ((rc = upload_net(c, p0, &c->net0))) return bail(rc, c->err);
-  if (!c->generic0 && (rc = upload_net(c, p0s, &c->net0_split))) return bail(rc, c->err);
+  if (c->coarse_fine) {
+    if ((rc = upload_net(c, p0, &c->netc[c->genericc ? ADANERF_PREC_FP32 : opt->precision]))) return bail(rc, c->err);
+    if ((rc = dev_alloc(c, &c->ztab_coarse, kMaxCoarse * sizeof(float)))) return bail(rc, c->err);
+    if (hipMemcpy(c->ztab_coarse.p, ms.ztab_coarse.data(), ms.ztab_coarse.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+      return bail(ADANERF_EDEVICE, "coarse depth table upload failed");
+    c->spc = c->sp;
+    c->spc.normalize = ms.normalize0;
+    c->spc.ztab = reinterpret_cast<const float*>(c->ztab_coarse.p);
+    c->genc = GenericTopo{c->topoc.depth, c->topoc.skip, 0, 0, nullptr, 0.f};
+  } else {
+    if ((rc = upload_net(c, p0, &c->net0))) return bail(rc, c->err);
+    if (!c->generic0 && (rc = upload_net(c, p0s, &c->net0_split))) return bail(rc, c->err);
+  }
   if (c->ray_samples > 0) {
     if ((rc = dev_alloc(c, &c->rsi_z, ms.rsi_z.size() * sizeof(float)))) return bail(rc, c->err);
     if (hipMemcpy(c->rsi_z.p, ms.rsi_z.data(), ms.rsi_z.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
@@ -826,6 +948,7 @@ int adanerf_sync(adanerf_ctx* c) {
 int adanerf_ray_features(adanerf_ctx* c, int32_t first_ray, int32_t n_rays, float* d_feat, float* d_rays) {
   if (!c) return ADANERF_EINVAL;
   BIND(c);
+  if (c->coarse_fine) return fail(c, ADANERF_EUNSUPPORTED, "coarse/fine models have no sampling network");
   if (first_ray < 0 || n_rays < 0 || first_ray + n_rays > c->info.rays_local) return fail(c, ADANERF_EINVAL, "ray range outside this context's rays");
   if (n_rays == 0) return ADANERF_OK;
   dim3 grid((n_rays + 255) / 256), block(256);
@@ -840,6 +963,7 @@ int adanerf_ray_features(adanerf_ctx* c, int32_t first_ray, int32_t n_rays, floa
 int adanerf_sample_mlp(adanerf_ctx* c, int32_t first_ray, int32_t n_rays, float* d_oracle, float* d_rays) {
   if (!c) return ADANERF_EINVAL;
   BIND(c);
+  if (c->coarse_fine) return fail(c, ADANERF_EUNSUPPORTED, "coarse/fine models have no sampling network (adanerf_sample_uniform / adanerf_shade_mlp_coarse)");
   if (first_ray < 0 || n_rays < 0 || first_ray + n_rays > c->info.rays_local) return fail(c, ADANERF_EINVAL, "ray range outside this context's rays");
   return launch_sample_mlp(c, first_ray, n_rays, d_oracle, d_rays);
 }
@@ -887,6 +1011,37 @@ int adanerf_shade_mlp_z(adanerf_ctx* c, const float* d_rays, const uint32_t* d_k
   BIND(c);
   if (!d_rays || !d_key || !d_raw || max_samples < 0) return fail(c, ADANERF_EINVAL, "bad argument");
   return launch_shade_mlp(c, d_rays, d_key, d_total, max_samples, precision < 0 ? c->info.precision : precision, d_raw, d_z);
+}
+
+int adanerf_sample_uniform(adanerf_ctx* c, int32_t first_ray, int32_t n_rays, float* d_rays, int32_t* d_off, int32_t* d_cnt, uint32_t* d_key,
+                           int32_t* d_total) {
+  if (!c) return ADANERF_EINVAL;
+  BIND(c);
+  if (!c->coarse_fine) return fail(c, ADANERF_EUNSUPPORTED, "adanerf_sample_uniform: not a coarse/fine model");
+  if (!d_rays || !d_off || !d_cnt || !d_key || !d_total) return fail(c, ADANERF_EINVAL, "NULL buffer");
+  if (first_ray < 0 || n_rays < 0 || first_ray + n_rays > c->info.rays_local) return fail(c, ADANERF_EINVAL, "ray range outside this context's rays");
+  int rc = launch_camera_rays(c, first_ray, n_rays, d_rays);
+  return rc ? rc : launch_sample_uniform(c, n_rays, c->n_coarse, d_off, d_cnt, d_key, d_total);
+}
+
+int adanerf_shade_mlp_coarse(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, const int32_t* d_total, int32_t max_samples,
+                             int32_t precision, float* d_raw) {
+  if (!c) return ADANERF_EINVAL;
+  BIND(c);
+  if (!c->coarse_fine) return fail(c, ADANERF_EUNSUPPORTED, "adanerf_shade_mlp_coarse: not a coarse/fine model");
+  if (!d_rays || !d_key || !d_raw || max_samples < 0) return fail(c, ADANERF_EINVAL, "bad argument");
+  return launch_shade_mlp(c, d_rays, d_key, d_total, max_samples, precision < 0 ? c->info.precision : precision, d_raw, nullptr, true);
+}
+
+int adanerf_sample_from_coarse(adanerf_ctx* c, const float* d_raw_coarse, const float* d_rays, int32_t n_rays, int32_t* d_off, int32_t* d_cnt,
+                               uint32_t* d_key, float* d_z, int32_t* d_total) {
+  if (!c) return ADANERF_EINVAL;
+  BIND(c);
+  if (!c->coarse_fine) return fail(c, ADANERF_EUNSUPPORTED, "adanerf_sample_from_coarse: not a coarse/fine model");
+  if (!d_raw_coarse || !d_rays || !d_off || !d_cnt || !d_key || !d_z || !d_total) return fail(c, ADANERF_EINVAL, "NULL buffer");
+  if (n_rays < 0 || static_cast<int64_t>(n_rays) * c->info.num_samples > 0x7fffffffll || n_rays >= (1 << 25))
+    return fail(c, ADANERF_EINVAL, "n_rays out of range");
+  return launch_sample_fine(c, d_raw_coarse, d_rays, n_rays, d_off, d_cnt, d_key, d_z, d_total);
 }
 
 int adanerf_sample_pdf(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, int32_t n, int32_t* d_off, int32_t* d_cnt, uint32_t* d_key,
@@ -974,6 +1129,7 @@ int adanerf_render_oracle(adanerf_ctx* c, void* d_rgba8) {
   if (!c) return ADANERF_EINVAL;
   BIND(c);
   if (!d_rgba8) return fail(c, ADANERF_EINVAL, "NULL buffer");
+  if (c->coarse_fine) return fail(c, ADANERF_EUNSUPPORTED, "coarse/fine models have no sampling network to view");
   const int R = c->info.rays_local, B = c->info.batch_rays;
   int rc = ensure_batch_buffers(c, std::min(B, std::max(R, 1)), c->info.num_samples);
   if (rc) return rc;
@@ -1027,6 +1183,7 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
   float* rays = reinterpret_cast<float*>(c->rays.p);
   float* oracle = reinterpret_cast<float*>(c->oracle.p);
   int32_t* off = reinterpret_cast<int32_t*>(c->ray_offsets.p);
+  const bool cfm = c->coarse_fine;
   int32_t* cnt = reinterpret_cast<int32_t*>(c->ray_counts.p);
   uint32_t* key = reinterpret_cast<uint32_t*>(c->sample_key.p);
   float* sw = reinterpret_cast<float*>(c->sample_w.p);
@@ -1036,19 +1193,33 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     const int first = b * B, n = std::min(B, R - first);
     hipEvent_t* ev = record ? &c->events[c->events_used] : nullptr;
     if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    const bool pdf = c->info.sampler_mode == ADANERF_SAMPLER_PDF;
+    const bool pdf = c->info.sampler_mode == ADANERF_SAMPLER_PDF || cfm;      // explicit sample depths + classic compositing
+    if (cfm) {
+      // vanilla NeRF: camera rays, Nc uniform samples, coarse network ("sample_mlp" in the statistics: the first network)
+      uint32_t* keyc = reinterpret_cast<uint32_t*>(c->key_coarse.p);
+      float* rawc = reinterpret_cast<float*>(c->raw_coarse.p);
+      if ((rc = launch_camera_rays(c, first, n, rays))) return rc;
+      if ((rc = launch_sample_uniform(c, n, c->n_coarse, off, cnt, keyc, total))) return rc;
+      if ((rc = launch_shade_mlp(c, rays, keyc, total, n * c->n_coarse, c->info.precision, rawc, nullptr, true))) return rc;
+      if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+      // weights -> pdf -> Nf more depths, merged with the Nc coarse ones ("compact")
+      if ((rc = launch_sample_fine(c, rawc, rays, n, off, cnt, key, reinterpret_cast<float*>(c->sample_z.p), total))) return rc;
+    }
     // adaptive selection in the epilogue of the sampling kernel: the [R,128] oracle values never reach HBM
     const bool fused = !pdf && thr > 0.f && use_pair_select(c, N) && c->sampling_mode != 1 && !c->generic0 && !(c->opt.flags & ADANERF_FLAG_KEEP_ORACLE);
-    if (fused) {
+    if (cfm) {
+      rc = ADANERF_OK;
+    } else if (fused) {
       const SelectOut so = select_out(c, N, thr, cnt);
       rc = launch_sample_mlp(c, first, n, nullptr, rays, &so);
     } else {
       rc = launch_sample_mlp(c, first, n, oracle, rays);
     }
     if (rc) return rc;
-    if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+    if (ev && !cfm) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     float* sz = reinterpret_cast<float*>(c->sample_z.p);
-    if (pdf) rc = launch_sample_pdf(c, oracle, n, N, off, cnt, key, sw, sz, total);
+    if (cfm) rc = ADANERF_OK;
+    else if (pdf) rc = launch_sample_pdf(c, oracle, n, N, off, cnt, key, sw, sz, total);
     else if (fused) rc = launch_expand(c, n, N, kPairSegShift, off, cnt, key, sw, total);
     else rc = launch_compact(c, oracle, n, N, thr, off, cnt, key, sw, total);
     if (rc) return rc;
@@ -1204,6 +1375,7 @@ int adanerf_get_buffer(adanerf_ctx* c, int32_t which, void** d_out, size_t* byte
     case ADANERF_BUF_RAW: b = &c->raw; break;
     case ADANERF_BUF_TOTAL: b = &c->total; break;
     case ADANERF_BUF_SAMPLE_Z: b = &c->sample_z; break;
+    case ADANERF_BUF_RAW_COARSE: b = &c->raw_coarse; break;
     default: return fail(c, ADANERF_EINVAL, "unknown buffer id");
   }
   *d_out = b->p;

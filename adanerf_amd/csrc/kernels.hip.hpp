@@ -15,4 +15,5 @@
 #include "k_mlp16.hip.hpp"
 #include "k_sampling16.hip.hpp"
 #include "k_donerf.hip.hpp"
+#include "k_coarse_fine.hip.hpp"
 #include "k_composite.hip.hpp"

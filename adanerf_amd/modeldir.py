@@ -49,7 +49,8 @@ def write_onnx_initializers(path: str, tensors: Dict[str, np.ndarray]) -> None:
 def write_model_dir(path: str, scene: dict, net0: Dict[str, np.ndarray], net1: Dict[str, np.ndarray]) -> None:
     """scene keys: view_cell_center[3], view_cell_size[3], depth_range[2], fov, max_depth, num_samples,
     threshold; optional use_ndc, depth_transform ('log'), pos_enc (((10,4),(10,4))), normalization,
-    z_near, z_far, accumulation_mult."""
+    z_near, z_far, accumulation_mult; num_samples_coarse > 0 writes a vanilla-NeRF directory (inFeatures [RayMarchFromPoses,
+    RayMarchFromCoarse], numRaymarchSamples [num_samples_coarse, num_samples]; net0 is then a NeRF net as well)."""
     os.makedirs(path, exist_ok=True)
     ndc = bool(scene.get("use_ndc", False))
     enc = scene.get("pos_enc", ((10, 4), (10, 4)))
@@ -58,10 +59,18 @@ def write_model_dir(path: str, scene: dict, net0: Dict[str, np.ndarray], net1: D
     with open(os.path.join(path, "config.ini"), "w") as f:
         f.write("posEnc = [nerf, nerf]\n")
         f.write("posEncArgs = [%d-%d, %d-%d]\n" % (enc[0][0], enc[0][1], enc[1][0], enc[1][1]))
-        f.write("inFeatures = [SpherePosDir, RayMarchFromPoses]\noutFeatures = [Raw, RGBARayMarch]\n")
-        f.write("rayMarchSampler = [none, %s]\n" % sampler)
-        f.write("rayMarchNormalization = [InverseSqrtDistCentered, %s]\n" % scene.get("normalization", "InverseSqrtDistCentered"))
-        f.write("numRaymarchSamples = [%d, %d]\n" % (n, n))
+        nc = int(scene.get("num_samples_coarse", 0))
+        if nc > 0:
+            norm = scene.get("normalization", "InverseSqrtDistCentered")
+            f.write("inFeatures = [RayMarchFromPoses, RayMarchFromCoarse]\noutFeatures = [RGBARayMarch, RGBARayMarch]\n")
+            f.write("rayMarchSampler = [LinearlySpacedZNearZFar, none]\n")
+            f.write("rayMarchNormalization = [%s, %s]\n" % (norm, norm))
+            f.write("numRaymarchSamples = [%d, %d]\n" % (nc, n))
+        else:
+            f.write("inFeatures = [SpherePosDir, RayMarchFromPoses]\noutFeatures = [Raw, RGBARayMarch]\n")
+            f.write("rayMarchSampler = [none, %s]\n" % sampler)
+            f.write("rayMarchNormalization = [InverseSqrtDistCentered, %s]\n" % scene.get("normalization", "InverseSqrtDistCentered"))
+            f.write("numRaymarchSamples = [%d, %d]\n" % (n, n))
         f.write("rayMarchSamplingStep = [0.0078125, 0.0078125]\nrayMarchSamplingNoise = [0.0, 0.0]\nraySampleInput = [0, 0]\n")
         f.write("depthTransform = %s\n" % scene.get("depth_transform", "log"))
         f.write("zNear = [%r, %r]\nzFar = [%r, %r]\n" % (scene.get("z_near", 0.001), scene.get("z_near", 0.001),
@@ -113,3 +122,14 @@ def random_init_weights(seed: int = 0, n_in0: int = 90, n_pos: int = 63, n_dir: 
                        "rgb_linear": (3, 128)}.items():
         n1[nm + ".weight"], n1[nm + ".bias"] = lin(o, k)
     return n0, n1
+
+
+def random_init_nerf_pair(seed: int = 0, alpha_bias: float = 1.0):
+    """Two seeded NeRF nets (8 x 256, skip 4, 10-4 encodings) for a vanilla-NeRF (coarse / fine) directory; the density
+    bias keeps a random-init net from being transparent everywhere."""
+    nets = []
+    for i in range(2):
+        _, n1 = random_init_weights(seed + 7919 * i)
+        n1["alpha_linear.bias"] = (n1["alpha_linear.bias"] + np.float32(alpha_bias)).astype(np.float32)
+        nets.append(n1)
+    return nets[0], nets[1]

@@ -21,8 +21,8 @@ from .build import library_path
 PREC_BF16, PREC_FP16, PREC_FP32 = 0, 1, 2
 _PREC = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "fp32": PREC_FP32, "f32": PREC_FP32}
 
-BUF_RAYS, BUF_ORACLE, BUF_RAY_OFFSETS, BUF_RAY_COUNTS, BUF_SAMPLE_KEY, BUF_SAMPLE_W, BUF_RAW, BUF_TOTAL, BUF_SAMPLE_Z = range(9)
-SAMPLER_ADAPTIVE, SAMPLER_PDF = 0, 1
+BUF_RAYS, BUF_ORACLE, BUF_RAY_OFFSETS, BUF_RAY_COUNTS, BUF_SAMPLE_KEY, BUF_SAMPLE_W, BUF_RAW, BUF_TOTAL, BUF_SAMPLE_Z, BUF_RAW_COARSE = range(10)
+SAMPLER_ADAPTIVE, SAMPLER_PDF, SAMPLER_COARSE_FINE = 0, 1, 2
 FLAG_KEEP_ORACLE, FLAG_WAVE_SELECT = 1, 2
 
 
@@ -43,7 +43,7 @@ class Info(C.Structure):
                 ("num_samples", C.c_int32), ("threshold", C.c_float), ("dense", C.c_int32), ("use_ndc", C.c_int32),
                 ("precision", C.c_int32), ("compute_units", C.c_int32), ("fov", C.c_float), ("focal", C.c_float),
                 ("view_cell_center", C.c_float * 3), ("view_cell_radius", C.c_float), ("depth_range", C.c_float * 2),
-                ("max_depth", C.c_float), ("sampler_mode", C.c_int32), ("view_cell_size", C.c_float * 3)]
+                ("max_depth", C.c_float), ("sampler_mode", C.c_int32), ("view_cell_size", C.c_float * 3), ("num_samples_coarse", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -56,7 +56,7 @@ class Stats(C.Structure):
 EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_last_error", "adanerf_set_camera",
            "adanerf_render", "adanerf_set_aux_outputs", "adanerf_assemble_strips", "adanerf_sync", "adanerf_set_stream", "adanerf_set_profiling",
            "adanerf_collect_stats", "adanerf_ray_features", "adanerf_sample_mlp",
-           "adanerf_compact", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_shade_mlp_z", "adanerf_sample_pdf",
+           "adanerf_compact", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_shade_mlp_z", "adanerf_sample_pdf", "adanerf_sample_uniform", "adanerf_shade_mlp_coarse", "adanerf_sample_from_coarse",
            "adanerf_composite", "adanerf_composite_classic", "adanerf_copy_result_sampling_network",
            "adanerf_render_oracle", "adanerf_gather_to", "adanerf_malloc",
            "adanerf_free", "adanerf_memcpy_h2d", "adanerf_memcpy_d2h", "adanerf_get_buffer"]
@@ -95,6 +95,9 @@ def load_library(path: Optional[str] = None):
     lib.adanerf_composite.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
     lib.adanerf_shade_mlp_z.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
     lib.adanerf_sample_pdf.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.adanerf_sample_uniform.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    lib.adanerf_shade_mlp_coarse.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    lib.adanerf_sample_from_coarse.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.adanerf_composite_classic.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     lib.adanerf_copy_result_sampling_network.argtypes = [vp, vp, i32, vp]
     lib.adanerf_render_oracle.argtypes = [vp, vp]
@@ -340,6 +343,18 @@ class NeuralRenderer:
     def sample_pdf(self, oracle, n_rays: int, n: int, ray_offsets, ray_counts, sample_key, sample_w, sample_z, total):
         self._check(self.lib.adanerf_sample_pdf(self.handle, _ptr(oracle), n_rays, n, _ptr(ray_offsets), _ptr(ray_counts),
                                                 _ptr(sample_key), _ptr(sample_w), _ptr(sample_z), _ptr(total)))
+
+    # vanilla NeRF (SAMPLER_COARSE_FINE): uniform coarse samples, the coarse network, the fine sampler
+    def sample_uniform(self, first_ray: int, n_rays: int, rays, ray_offsets, ray_counts, sample_key, total):
+        self._check(self.lib.adanerf_sample_uniform(self.handle, first_ray, n_rays, _ptr(rays), _ptr(ray_offsets), _ptr(ray_counts),
+                                                    _ptr(sample_key), _ptr(total)))
+
+    def shade_mlp_coarse(self, rays, sample_key, total, max_samples: int, raw_out, precision: int = -1):
+        self._check(self.lib.adanerf_shade_mlp_coarse(self.handle, _ptr(rays), _ptr(sample_key), _ptr(total), max_samples, precision, _ptr(raw_out)))
+
+    def sample_from_coarse(self, raw_coarse, rays, n_rays: int, ray_offsets, ray_counts, sample_key, sample_z, total):
+        self._check(self.lib.adanerf_sample_from_coarse(self.handle, _ptr(raw_coarse), _ptr(rays), n_rays, _ptr(ray_offsets), _ptr(ray_counts),
+                                                        _ptr(sample_key), _ptr(sample_z), _ptr(total)))
 
     def composite_classic(self, raw, sample_z, rays, n_rays: int, n: int, rgb_out=None, rgba8_out=None):
         self._check(self.lib.adanerf_composite_classic(self.handle, _ptr(raw), _ptr(sample_z), _ptr(rays), n_rays, n,

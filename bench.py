@@ -38,6 +38,9 @@ WORKLOADS = {
     # BASELINE configs[4]: 1920x1080 LLFF-NDC scene (2-2 oracle encoding, linear depth, no normalisation); no NDC
     # weights ship with the reference -> seeded random-init weights; sweep the threshold with --threshold
     "config5_ndc": (1920, 1080, 8, 0.2, "ndc_random_init"),
+    # vanilla NeRF with hierarchical sampling, the original paper's 64 coarse + 128 more samples per ray through two
+    # 8 x 256 networks (64 + 192 = 256 network evaluations per ray); random-init weights.  Not a BASELINE configuration.
+    "nerf_coarse_fine": (800, 800, 128, 1.0, "nerf_pair_random_init"),
 }
 
 
@@ -57,6 +60,11 @@ def build_model_dir(td, tag, n, thr):
         n0, n1 = M.random_init_weights(7, n_in0=30, oracle_bias=-0.55, oracle_scale=0.5)
         s = dict(view_cell_center=(0.0, 0.0, 0.0), view_cell_size=(2.0, 2.0, 1.0), depth_range=(0.9, 12.0), fov=1.0, max_depth=12.0)
         data = "synthetic rays; random-init weights (seed 7), NDC / linear depth / 2-2 oracle encoding"
+    elif tag == "nerf_pair_random_init":
+        n0, n1 = M.random_init_nerf_pair(3)
+        s = dict(view_cell_center=(0.783, -3.19, 1.39), view_cell_size=(0.7, 0.7, 0.2),
+                 depth_range=(0.1542200982570648, 8.358194804191589), fov=1.1386263370513916, max_depth=8.79825210571289)
+        data = "synthetic rays; two random-init NeRF nets (seed 3): vanilla NeRF, 64 coarse + 128 fine samples per ray"
     else:
         n0, n1 = M.random_init_weights(0)
         s = dict(view_cell_center=(0.783, -3.19, 1.39), view_cell_size=(0.7, 0.7, 0.2),
@@ -66,6 +74,8 @@ def build_model_dir(td, tag, n, thr):
                  fov=s["fov"], max_depth=s["max_depth"], num_samples=n, threshold=thr)
     if tag == "ndc_random_init":
         scene.update(use_ndc=True, depth_transform="linear", pos_enc=((2, 2), (10, 4)), normalization="None")
+    if tag == "nerf_pair_random_init":
+        scene.update(num_samples_coarse=64, accumulation_mult="")
     M.write_model_dir(td, scene, n0, n1)
     return scene, data
 

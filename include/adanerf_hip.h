@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ADANERF_ABI_VERSION 2   /* 2: adanerf_info.view_cell_size appended */
+#define ADANERF_ABI_VERSION 2   /* 2: adanerf_info.view_cell_size, .num_samples_coarse appended */
 
 enum {
   ADANERF_OK = 0,
@@ -71,8 +71,11 @@ enum {
 /* sample placement (config.ini rayMarchSampler[1]) */
 enum {
   ADANERF_SAMPLER_ADAPTIVE = 0, /* FromClassifiedDepthAdaptive[NoDepthRange]: AdaNeRF top-N / threshold selection */
-  ADANERF_SAMPLER_PDF = 1       /* FromClassifiedDepth: DONeRF inverse-CDF sampling of sigmoid(oracle), fixed N samples
+  ADANERF_SAMPLER_PDF = 1,      /* FromClassifiedDepth: DONeRF inverse-CDF sampling of sigmoid(oracle), fixed N samples
                                    per ray, classic sigma/delta compositing */
+  ADANERF_SAMPLER_COARSE_FINE = 2 /* inFeatures [RayMarchFromPoses, RayMarchFromCoarse]: vanilla NeRF.  model0.onnx is a NeRF net
+                                   too; numRaymarchSamples = [Nc, Nf]: Nc uniform depths, Nf more from the coarse weights,
+                                   Nc + Nf samples through model1, classic compositing */
 };
 
 /* arithmetic of the shading MLP's MFMA path */
@@ -130,6 +133,7 @@ typedef struct adanerf_info {
   float   max_depth;
   int32_t sampler_mode;     /* ADANERF_SAMPLER_* (from rayMarchSampler[1]) */
   float   view_cell_size[3];/* dataset_info.txt view_cell_size (the viewer's camera speed: max(size / 2), camera.cpp:47) */
+  int32_t num_samples_coarse; /* ADANERF_SAMPLER_COARSE_FINE: Nc (num_samples is then Nc + Nf); else 0 */
 } adanerf_info;
 
 /* per-frame statistics: the fields the reference logs every 100 frames
@@ -267,6 +271,25 @@ int adanerf_sample_pdf(adanerf_ctx* ctx, const float* d_oracle, int32_t n_rays, 
                        int32_t* d_ray_counts, uint32_t* d_sample_key, float* d_sample_w, float* d_sample_z,
                        int32_t* d_total);
 
+/* Vanilla NeRF, coarse pass (reference: updateRayMarchCoarse, include/cuda/adanerf_cuda_kernels.cuh:60-66; PyTorch:
+ * RayMarchFromPoses over LinearlySpacedZNearZFar, src/features.py:380-480, src/nerf_raymarch_common.py:295-331): rays of
+ * [batch_offset, batch_offset + n_rays) from the camera position (d_rays [n,8]) and Nc samples per ray at the model's uniform
+ * depth table (d_sample_key = ray << 7 | k, counts all Nc).  ADANERF_SAMPLER_COARSE_FINE contexts only. */
+int adanerf_sample_uniform(adanerf_ctx* ctx, int32_t batch_offset, int32_t n_rays, float* d_rays, int32_t* d_ray_offsets,
+                           int32_t* d_ray_counts, uint32_t* d_sample_key, int32_t* d_total);
+
+/* The coarse network (model0.onnx, a NeRF net in this mode) on samples made by adanerf_sample_uniform: as adanerf_shade_mlp. */
+int adanerf_shade_mlp_coarse(adanerf_ctx* ctx, const float* d_rays, const uint32_t* d_sample_key, const int32_t* d_total,
+                             int32_t max_samples, int32_t precision, float* d_raw);
+
+/* Vanilla NeRF, fine sampler (reference: updateRayMarchFromCoarse incl. nerf_raw_2_output_weights, adanerf_cuda_kernels.cuh:68-74,
+ * src/cuda/coarse_cuda_kernels.cu:29-383; PyTorch: RayMarchFromCoarse.batch, src/features.py:640-672): the coarse raw outputs
+ * [n_rays*Nc,4] -> nerf_raw2outputs weights -> nerf_sample_pdf over the interval mid-points with weights[1:-1], u =
+ * linspace(0,1,Nf) -> merged with the coarse depths, ascending.  d_sample_z [n_rays*(Nc+Nf)] world depths for
+ * adanerf_shade_mlp_z; counts are all Nc + Nf. */
+int adanerf_sample_from_coarse(adanerf_ctx* ctx, const float* d_raw_coarse, const float* d_rays, int32_t n_rays, int32_t* d_ray_offsets,
+                               int32_t* d_ray_counts, uint32_t* d_sample_key, float* d_sample_z, int32_t* d_total);
+
 /* Classic NeRF compositing over a fixed n samples per ray (reference: copyResultRaymarch / nerf_raw_2_output,
  * adanerf_cuda_kernels.cuh:23-24; PyTorch nerf_raw2outputs): alpha = 1 - exp(-relu(raw.a) * dz * |dir|). */
 int adanerf_composite_classic(adanerf_ctx* ctx, const float* d_raw, const float* d_sample_z, const float* d_rays,
@@ -293,7 +316,8 @@ enum {
   ADANERF_BUF_SAMPLE_W = 5,    /* [S] fp32 */
   ADANERF_BUF_RAW = 6,         /* [S,4] fp32 */
   ADANERF_BUF_TOTAL = 7,       /* [1] int32 */
-  ADANERF_BUF_SAMPLE_Z = 8     /* [S] fp32 (ADANERF_SAMPLER_PDF only) */
+  ADANERF_BUF_SAMPLE_Z = 8,    /* [S] fp32 (ADANERF_SAMPLER_PDF / _COARSE_FINE) */
+  ADANERF_BUF_RAW_COARSE = 9   /* [batch*Nc,4] fp32 (ADANERF_SAMPLER_COARSE_FINE) */
 };
 int adanerf_get_buffer(adanerf_ctx* ctx, int32_t which, void** d_out, size_t* bytes_out);
 

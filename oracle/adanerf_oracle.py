@@ -137,6 +137,11 @@ def load_scene(model_dir: str, num_samples: Optional[int] = None,
     )
     smp = _parse_list(kv.get("rayMarchSampler", "[none,FromClassifiedDepthAdaptive]"))
     sc.sampler = "FromClassifiedDepth" if smp[-1] == "FromClassifiedDepth" else "FromClassifiedDepthAdaptive"
+    if _parse_list(kv.get("inFeatures", "[SpherePosDir,RayMarchFromPoses]")) == ["RayMarchFromPoses", "RayMarchFromCoarse"]:
+        sc.sampler = "CoarseFine"      # vanilla NeRF: numRaymarchSamples = [Nc, Nf], zNear / zFar of net 0 place the coarse samples
+        sc.num_samples_coarse = int(_parse_list(kv["numRaymarchSamples"])[0])
+        sc.z_near = float(_parse_list(kv.get("zNear", "[0.001,0.001]"))[0])
+        sc.z_far = float(_parse_list(kv.get("zFar", "[1.0,1.0]"))[0])
     ls = _parse_list(kv.get("losses", "[NeRFWeightMultiplicationLoss,MSE]"))
     sc.losses0 = ls[0] if ls else "NeRFWeightMultiplicationLoss"
     rsi = _parse_list(kv.get("raySampleInput", "[0,0]"))

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import adanerf_oracle as O
-from conftest import AUX_CASES, MULT_CASES, ROOT, TOPOLOGY_CASES, case_weights, load_case, record
+from conftest import AUX_CASES, COARSE_FINE_CASES, MULT_CASES, ROOT, TOPOLOGY_CASES, case_weights, load_case, record
 
 import adanerf_amd
 from adanerf_amd import renderer as R
@@ -340,3 +340,90 @@ def test_generic_topologies_match_the_reference(name, tmp_path_factory):
         # the rsi case keeps the default 8 x 256 shading net: bf16 there is the 16-bit engine (55 dB class); generic nets are fp32
         assert O.psnr(rgb[same], ref["rgb"][same]) > (50.0 if (prec == "bf16" and "rsi" in name) else 60.0)
     assert abs(int(st.total_samples) - int(ref["count"].sum())) <= 0.01 * ref["count"].sum()
+
+
+# ---------------------------------------------------------------------------------------------
+# vanilla NeRF with hierarchical sampling (inFeatures [RayMarchFromPoses, RayMarchFromCoarse])
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", COARSE_FINE_CASES)
+def test_coarse_fine_stages_match_the_reference(name, tmp_path_factory):
+    """Every stage of the mode against the step-by-step run of the reference's own feature sets and models
+    (oracle/gen_golden.py gen_coarse_fine): camera rays, coarse network outputs at the uniform depths, the merged coarse +
+    fine depths, the fine network's outputs, colour."""
+    from test_gpu_parity import crop_rows
+    z, meta, sc = load_case(name)
+    wts = case_weights(meta)
+    d = _dir(tmp_path_factory, sc, wts, "cf_" + name)
+    nc, nf = sc.num_samples_coarse, sc.num_samples
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, meta["w"], meta["h"]), precision="fp32") as r:
+        r.set_camera(z["pose"], z["rot"])
+        assert r.info.sampler_mode == R.SAMPLER_COARSE_FINE and r.info.num_samples == nc + nf and r.info.num_samples_coarse == nc
+        assert r.info.n_in0 == 90
+        rows = crop_rows(meta)
+        nmax = max(n for _, n, _ in rows)
+        rays = r.empty((nmax, 8), np.float32)
+        off, cnt, tot = r.empty((nmax,), np.int32), r.empty((nmax,), np.int32), r.empty((1,), np.int32)
+        keyc, rawc = r.empty((nmax * nc,), np.uint32), r.empty((nmax * nc, 4), np.float32)
+        key, sz, raw = r.empty((nmax * (nc + nf),), np.uint32), r.empty((nmax * (nc + nf),), np.float32), r.empty((nmax * (nc + nf), 4), np.float32)
+        rgb = r.empty((nmax, 3), np.float32)
+        got = dict(rays=[], rawc=[], z=[], raw=[], rgb=[])
+        for first, n, stride in rows:
+            r.sample_uniform(first, n, rays, off, cnt, keyc, tot)
+            assert int(tot.numpy()[0]) == n * nc and (cnt.numpy()[:n] == nc).all()
+            r.shade_mlp_coarse(rays, keyc, tot, n * nc, rawc)
+            r.sample_from_coarse(rawc, rays, n, off, cnt, key, sz, tot)
+            assert int(tot.numpy()[0]) == n * (nc + nf) and (cnt.numpy()[:n] == nc + nf).all()
+            r.shade_mlp_z(rays, key, sz, tot, n * (nc + nf), raw)
+            r.composite_classic(raw, sz, rays, n, nc + nf, rgb, None)
+            got["rays"].append(rays.numpy()[:n:stride].copy())
+            got["rawc"].append(rawc.numpy()[:n * nc].reshape(n, nc, 4)[::stride].copy())
+            got["z"].append(sz.numpy()[:n * (nc + nf)].reshape(n, nc + nf)[::stride].copy())
+            got["raw"].append(raw.numpy()[:n * (nc + nf)].reshape(n, nc + nf, 4)[::stride].copy())
+            got["rgb"].append(rgb.numpy()[:n:stride].copy())
+        got = {k: np.concatenate(v) for k, v in got.items()}
+    np.testing.assert_allclose(got["rays"][:, 0:3], z["p"], rtol=0, atol=1e-7)          # the camera position
+    np.testing.assert_allclose(got["rays"][:, 4:7], z["nds"], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(got["rawc"].reshape(-1, 4), z["coarse_out"], rtol=1e-3, atol=1.5e-3)
+    zr = z["z_world"]
+    assert (np.diff(got["z"], axis=1) >= 0).all()                                         # merged in ascending order
+    rel = np.abs(got["z"] - zr) / zr
+    assert np.median(rel) < 2e-6 and (rel < 1e-4).mean() > 0.995                          # inverse CDF: ill-conditioned in empty bins
+    ok = (rel < 1e-5).all(axis=1)
+    record("coarse_fine_stages", rays_with_all_depths_equal=float(ok.mean()), median_rel_depth_err=float(np.median(rel)),
+           rgb_max_err=float(np.abs(got["rgb"][ok] - z["rgb"][ok]).max()))
+    assert ok.mean() > 0.9
+    np.testing.assert_allclose(got["raw"][ok].reshape(-1, 4), z["shade_out"].reshape(-1, nc + nf, 4)[ok].reshape(-1, 4), rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(got["rgb"][ok], z["rgb"][ok], rtol=0, atol=3e-4)
+
+
+@pytest.mark.parametrize("prec,min_psnr", [("fp32", 90.0), ("fp16", 58.0), ("bf16", 45.0)])      # measured 112 / 65.7 / 51.5 dB
+def test_coarse_fine_frames_match_the_oracle(prec, min_psnr, tmp_path_factory):
+    """Whole small frames of the mode (batched and not) against the oracle, incl. depth / accumulation maps; Nc = 24, Nf = 40."""
+    import dataclasses
+    z, meta, sc = load_case(COARSE_FINE_CASES[0])
+    sc = dataclasses.replace(sc, num_samples_coarse=24, num_samples=40)
+    wts = case_weights(meta)
+    d = _dir(tmp_path_factory, sc, wts, "cf_frame")
+    w, h = 72, 48
+    ref = O.render_rays(O.generate_ray_directions(w, h, sc.fov), z["pose"], z["rot"], sc, wts, w, h)
+    outs = []
+    for bs in (-1, 1000):
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=bs), precision=prec) as r:
+            r.set_camera(z["pose"], z["rot"])
+            depth, acc = r.empty((w * h,), np.float32), r.empty((w * h,), np.float32)
+            r.set_aux_outputs(depth, acc)
+            rgb, rgba, st = r.render_numpy()
+            assert st.total_samples == w * h * 64
+            outs.append((rgb, rgba, depth.numpy().copy(), acc.numpy().copy()))
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))                    # batching does not change a bit
+    rgb, rgba, depth, acc = outs[0]
+    # classic compositing: a sample's alpha is a steep function of its density where the density is near 0 (last sample: a step),
+    # so the low-precision bound is on the bulk of the rays (see test_pdf_frame_matches_oracle)
+    err = np.abs(rgb - ref["rgb"]).max(axis=1)
+    record("coarse_fine_frame", prec=prec, psnr_db=O.psnr(rgb, ref["rgb"]), q97=float(np.quantile(err, 0.97)), max_abs=float(err.max()))
+    if prec == "fp32":
+        assert err.max() < 5e-4 and np.abs(acc - ref["acc_map"]).max() < 5e-4
+        assert np.quantile(np.abs(depth - ref["depth_map"]) / np.maximum(ref["depth_map"], 1e-3), 0.99) < 1e-3
+    assert O.psnr(rgb, ref["rgb"]) > min_psnr
+    assert np.array_equal(rgba[:, :3], O.to_rgba8(rgb)[:, :3]) and (rgba[:, 3] == 255).all()

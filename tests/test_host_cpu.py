@@ -589,3 +589,32 @@ def test_input_replay_moves_the_camera_like_the_viewer(tmp_path, n_batches):
     script.write_text("+w\n+zz\n")
     bad = subprocess.run([exe, md, "-s", "8", "8", "--script", str(script), "--dry-run"], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "malformed script line 2" in bad.stdout
+
+
+def test_coarse_fine_model_directory_parses(lib, tmp_path):
+    """inFeatures [RayMarchFromPoses, RayMarchFromCoarse] (vanilla NeRF) is a supported model directory; what is
+    not supported about it is said, not guessed."""
+    import dataclasses
+    from conftest import COARSE_FINE_CASES
+    z, meta, sc = load_case(COARSE_FINE_CASES[0])
+    wts = case_weights(meta)
+    d = str(tmp_path / "cf")
+    O.write_model_dir(d, sc, wts)
+    info = R.Info()
+    opt = R._Options(width=80, height=60, batch_rays=-1, threshold=-1.0, shard_world=1)
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(opt), C.byref(info)) == 0, lib.adanerf_last_error(None)
+    assert info.sampler_mode == R.SAMPLER_COARSE_FINE and info.num_samples_coarse == 16 and info.num_samples == 40 and info.n_in0 == 90
+    # model0.onnx packs as a NeRF net (the shading-net layout), for every precision
+    for prec in (0, 1, 2):
+        wb, bf, nl = C.c_size_t(0), C.c_size_t(0), C.c_int32(0)
+        assert lib.adanerf_host_pack_weights(d.encode(), 1, prec, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl)) == 0
+        assert wb.value > 0 and nl.value == 11
+    for key, val, msg in [("rayMarchSampler", "[UnitSphereLinearOutsideLog, none]", "LinearlySpacedZNearZFar"), ("useNDC", "True", "useNDC"),
+                          ("numRaymarchSamples", "[2, 8]", "3..128"), ("numRaymarchSamples", "[64, 2000]", "1024")]:
+        bad = str(tmp_path / ("cf_bad_" + key + str(len(val))))
+        O.write_model_dir(bad, sc, wts)
+        ini = open(os.path.join(bad, "config.ini")).read()
+        ini = re.sub(r"^%s = .*$" % key, "%s = %s" % (key, val), ini, flags=re.M)
+        open(os.path.join(bad, "config.ini"), "w").write(ini)
+        rc = lib.adanerf_host_parse_model(bad.encode(), C.byref(opt), C.byref(info))
+        assert rc != 0 and msg in lib.adanerf_last_error(None).decode(), (key, val, lib.adanerf_last_error(None))
