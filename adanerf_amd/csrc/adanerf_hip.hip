@@ -680,8 +680,12 @@ int launch_sample_fine(adanerf_ctx* c, const float* d_raw_coarse, const float* d
 int launch_composite_classic(adanerf_ctx* c, const float* d_raw, const float* d_z, const float* d_rays, int n_rays, int n, float* d_rgb,
                              void* d_rgba8, float* d_depth = nullptr, float* d_acc = nullptr) {
   if (n_rays <= 0) return ADANERF_OK;
-  hipLaunchKernelGGL(composite_classic_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw),
-                     d_z, d_rays, n_rays, n, d_rgb, reinterpret_cast<uchar4*>(d_rgba8), d_depth, d_acc);
+  if (n > 32)      // long rays: one wave per ray, coalesced
+    hipLaunchKernelGGL(composite_classic_wave_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw),
+                       d_z, d_rays, n_rays, n, d_rgb, reinterpret_cast<uchar4*>(d_rgba8), d_depth, d_acc);
+  else
+    hipLaunchKernelGGL(composite_classic_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const float4*>(d_raw),
+                       d_z, d_rays, n_rays, n, d_rgb, reinterpret_cast<uchar4*>(d_rgba8), d_depth, d_acc);
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;
 }

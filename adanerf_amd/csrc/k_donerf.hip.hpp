@@ -3,6 +3,7 @@
 #pragma once
 #include "k_common.hip.hpp"
 #include "k_compact.hip.hpp"
+#include "k_composite.hip.hpp"      // wave_incl_prod_f32
 
 namespace adanerf {
 
@@ -115,6 +116,68 @@ __global__ __launch_bounds__(256) void composite_classic_kernel(const float4* __
     zk = zn;
   }
   if (depth_out) depth_out[r] = dm;       // src/nerf_raymarch_common.py:60-62
+  if (acc_out) acc_out[r] = am;
+  if (rgb_out) {
+    rgb_out[3 * static_cast<size_t>(r) + 0] = cr;
+    rgb_out[3 * static_cast<size_t>(r) + 1] = cg;
+    rgb_out[3 * static_cast<size_t>(r) + 2] = cb;
+  }
+  if (rgba8_out) {
+    uchar4 px;
+    px.x = static_cast<unsigned char>(fminf(fmaxf(cr, 0.f), 1.f) * 255.0f);
+    px.y = static_cast<unsigned char>(fminf(fmaxf(cg, 0.f), 1.f) * 255.0f);
+    px.z = static_cast<unsigned char>(fminf(fmaxf(cb, 0.f), 1.f) * 255.0f);
+    px.w = 255;
+    rgba8_out[r] = px;
+  }
+}
+
+// The same for long rays (n > 32: the vanilla-NeRF mode's 100+ samples per ray): one wave per ray, 64 samples per step with
+// coalesced loads, the transmittance carried from step to step and formed inside a step by a wave product scan (a different
+// association of the same fp32 products than the sequential loop: a few ulp).
+__global__ __launch_bounds__(256) void composite_classic_wave_kernel(const float4* __restrict__ raw, const float* __restrict__ sample_z,
+                                                                     const float* __restrict__ rays, int n_rays, int n,
+                                                                     float* __restrict__ rgb_out, uchar4* __restrict__ rgba8_out,
+                                                                     float* __restrict__ depth_out, float* __restrict__ acc_out) {
+  const int lane = lane_id();
+  const int r = blockIdx.x * 4 + (static_cast<int>(threadIdx.x) >> 6);
+  if (r >= n_rays) return;
+  const float4 d4 = reinterpret_cast<const float4*>(rays + static_cast<size_t>(r) * 8)[1];
+  const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d4.x, d4.x), __fmul_rn(d4.y, d4.y)), __fmul_rn(d4.z, d4.z)));
+  const size_t o = static_cast<size_t>(r) * n;
+  float cr = 0.f, cg = 0.f, cb = 0.f, dm = 0.f, am = 0.f, T = 1.f;
+  for (int base = 0; base < n; base += 64) {
+    const int k = base + lane;
+    float al = 0.f, zk = 0.f;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < n) {
+      v = raw[o + k];
+      zk = sample_z[o + k];
+      const float dist = __fmul_rn((k + 1 < n) ? __fsub_rn(sample_z[o + k + 1], zk) : 1e10f, dn);
+      al = __fsub_rn(1.0f, expf(-__fmul_rn(fmaxf(v.w, 0.f), dist)));
+    }
+    const float f = (k < n) ? __fadd_rn(__fsub_rn(1.0f, al), 1e-10f) : 1.0f;
+    const float p = wave_incl_prod_f32(f, lane);
+    float e = __shfl_up(p, 1);
+    if (lane == 0) e = 1.0f;
+    const float wt = __fmul_rn(al, __fmul_rn(T, e));
+    cr += wt * sigmoidf_dev(v.x);
+    cg += wt * sigmoidf_dev(v.y);
+    cb += wt * sigmoidf_dev(v.z);
+    dm += wt * zk;
+    am += wt;
+    T = __fmul_rn(T, __shfl(p, 63));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    cr += __shfl_xor(cr, off);
+    cg += __shfl_xor(cg, off);
+    cb += __shfl_xor(cb, off);
+    dm += __shfl_xor(dm, off);
+    am += __shfl_xor(am, off);
+  }
+  if (lane != 0) return;
+  if (depth_out) depth_out[r] = dm;
   if (acc_out) acc_out[r] = am;
   if (rgb_out) {
     rgb_out[3 * static_cast<size_t>(r) + 0] = cr;
