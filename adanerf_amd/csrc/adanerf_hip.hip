@@ -921,7 +921,8 @@ int adanerf_destroy(adanerf_ctx* c) {
   for (int32_t* p : c->pinned_totals) (void)hipHostFree(p);
   DevBuf* bufs[] = {&c->net0_split.w, &c->net0_split.b, &c->net0_f16.w, &c->net0_f16.b, &c->overflow, &c->net0.w, &c->net0.b, &c->net1[0].w, &c->net1[0].b, &c->net1[1].w, &c->net1[1].b, &c->net1[2].w, &c->net1[2].b,
                     &c->ztab, &c->rays, &c->oracle, &c->ray_offsets, &c->ray_counts, &c->selbin, &c->selw, &c->block_total,
-                    &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw, &c->sample_z, &c->rsi_z};
+                    &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw, &c->sample_z, &c->rsi_z,
+                    &c->netc[0].w, &c->netc[0].b, &c->netc[1].w, &c->netc[1].b, &c->netc[2].w, &c->netc[2].b, &c->ztab_coarse, &c->raw_coarse, &c->key_coarse};
   for (DevBuf* b : bufs) dev_free(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;

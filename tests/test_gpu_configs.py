@@ -427,3 +427,38 @@ def test_coarse_fine_frames_match_the_oracle(prec, min_psnr, tmp_path_factory):
         assert np.quantile(np.abs(depth - ref["depth_map"]) / np.maximum(ref["depth_map"], 1e-3), 0.99) < 1e-3
     assert O.psnr(rgb, ref["rgb"]) > min_psnr
     assert np.array_equal(rgba[:, :3], O.to_rgba8(rgb)[:, :3]) and (rgba[:, 3] == 255).all()
+
+
+def test_context_lifecycle_returns_all_device_memory(tmp_path_factory):
+    """Create / render / destroy contexts of every mode (adaptive, dense, DONeRF, coarse/fine, generic topology; all precisions,
+    profiling on and off) many times: the device's free memory must come back to where it started (adanerf_destroy frees every
+    buffer, packed network and event the context ever allocated)."""
+    import ctypes as C
+    import dataclasses
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    cases = []
+    for name in ("classroom_n8_thr02", "classroom_dense128", "classroom_pdf_n8", "classroom_coarse_fine_16_24", "syn_6x128_skip2"):
+        z, meta, sc = load_case(name)
+        wts = case_weights(meta)
+        cases.append((z, _dir(tmp_path_factory, sc, wts, "life_" + name)))
+
+    def cycle():
+        for z, d in cases:
+            for prec in ("bf16", "fp16", "fp32"):
+                with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, 160, 120, batch_size=7000), precision=prec) as r:
+                    r.set_camera(z["pose"], z["rot"])
+                    r.set_profiling(prec == "fp16")
+                    r.render_numpy()
+                    r.render_numpy()
+
+    cycle()                                   # first use: HIP's own caches (code objects, pools) fill up
+    base = free_bytes()
+    for _ in range(6):
+        cycle()
+    assert abs(free_bytes() - base) <= 8 << 20, (base, free_bytes())      # 90 contexts later: within 8 MiB
