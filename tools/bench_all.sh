@@ -18,3 +18,5 @@ run config4_thr01 --steps 30 --workload config4 --no-cpu-baseline
 run config3_dense --steps 5 --warmup 2 --workload config3_dense --no-cpu-baseline
 for t in 0.05 0.1 0.2 0.3 0.4; do run config5_ndc_fp16_thr$t --steps 20 --workload config5_ndc --precision fp16 --threshold $t --no-cpu-baseline; done
 run config2_orbit16 --steps 32 --orbit 16 --no-cpu-baseline
+run nerf_coarse_fine --steps 5 --warmup 2 --workload nerf_coarse_fine --no-cpu-baseline
+run config2_speed_mode --steps 30 --sampling fp16 --no-cpu-baseline
