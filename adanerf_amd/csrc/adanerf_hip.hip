@@ -88,6 +88,9 @@ struct adanerf_ctx {
   int cap_rays = 0, cap_nmax = 0;
   DevBuf rays, oracle, ray_offsets, ray_counts, selbin, selw, block_total, block_offset, total;
   DevBuf sample_key, sample_w, raw, sample_z;
+  DevBuf guard_mask, refine_list, guard_probe;   // ADANERF_SAMPLING_GUARDED: undecided bit per ray (one word per 32), ids of the
+                                                 // rays to re-evaluate, first-pass top value of each undecided ray (monitor)
+  float guard_eps = 0.f;             // the band in raw-output units; 0: not calibrated yet
   DepthMap dm{};
   int shade_grid[3] = {0, 0, 0};
   int device = 0;                 // HIP device ordinal this context lives on
@@ -271,7 +274,8 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   if (thr == 0.f && n_max != kBins) return bad(ADANERF_EUNSUPPORTED, "adaptiveSamplingThreshold == 0 (dense) requires numRaymarchSamples == 128");
   if (!coarse_fine && (n_max < 1 || n_max > kBins)) return bad(ADANERF_EINVAL, "numRaymarchSamples must be in 1..128");
   if (opt->precision < 0 || opt->precision > 2) return bad(ADANERF_EINVAL, "precision must be ADANERF_PREC_{BF16,FP16,FP32}");
-  if (opt->sampling_mode < 0 || opt->sampling_mode > 2) return bad(ADANERF_EINVAL, "sampling_mode must be ADANERF_SAMPLING_{SPLIT_FP16,FP32,FP16}");
+  if (opt->sampling_mode < 0 || opt->sampling_mode > 3) return bad(ADANERF_EINVAL, "sampling_mode must be ADANERF_SAMPLING_{SPLIT_FP16,FP32,FP16,GUARDED}");
+  if (!(opt->guard_eps <= 1.0f)) return bad(ADANERF_EINVAL, "guard_eps must be <= 1 (<= 0 selects the default)");
 
   // ---- info / ray generation constants (A1: src/util/raygeneration.py:10-26, float64) ----
   const int w = opt->width, h = opt->height;
@@ -438,10 +442,19 @@ int ensure_batch_buffers(adanerf_ctx* c, int n_rays, int n_max) {
     if ((rc = dev_alloc(c, &c->oracle, R * kBins * sizeof(float)))) return rc;
     if ((rc = dev_alloc(c, &c->selbin, S))) return rc;
     if ((rc = dev_alloc(c, &c->selw, S * sizeof(float)))) return rc;
+    if (c->sampling_mode == ADANERF_SAMPLING_GUARDED) {
+      if ((rc = dev_alloc(c, &c->guard_mask, nblk * sizeof(uint32_t)))) return rc;
+      if ((rc = dev_alloc(c, &c->refine_list, R * sizeof(int32_t)))) return rc;
+      if ((rc = dev_alloc(c, &c->guard_probe, R * sizeof(float)))) return rc;
+    }
   }
   if ((rc = dev_alloc(c, &c->block_total, nblk * sizeof(int32_t)))) return rc;
   if ((rc = dev_alloc(c, &c->block_offset, nblk * sizeof(int32_t)))) return rc;
-  if ((rc = dev_alloc(c, &c->total, 64))) return rc;
+  if (!c->total.p) {
+    if ((rc = dev_alloc(c, &c->total, 64))) return rc;      // [0] samples of the batch, [4] rays re-evaluated by the guarded selection,
+                                                            // [8] largest first-pass error seen (float bits), [9] rays where it exceeded the band
+    HIP_TRY(c, hipMemset(c->total.p, 0, 64));
+  }
   if ((rc = dev_alloc(c, &c->sample_key, S * sizeof(uint32_t)))) return rc;
   if ((rc = dev_alloc(c, &c->sample_w, S * sizeof(float)))) return rc;
   if ((rc = dev_alloc(c, &c->raw, S * 4 * sizeof(float)))) return rc;
@@ -479,6 +492,8 @@ int occupancy_grid(adanerf_ctx* c, K kernel, int threads, int* out) {
   return ADANERF_OK;
 }
 
+int calibrate_guard(adanerf_ctx* c, int n_poses, uint32_t seed, bool install, float* max_diff);
+
 // sel != nullptr: the adaptive selection runs in the kernel's epilogue (k_select_pair.hip.hpp) and d_oracle may be null
 int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle, float* d_rays, const SelectOut* sel = nullptr) {
   if (n_rays <= 0) return ADANERF_OK;
@@ -502,9 +517,23 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
     HIP_TRY(c, launch_sample_mlp_gen(a, c->gen0, full, c->topo0.width, grid.x, c->stream));
     return ADANERF_OK;
   }
+  // Guarded two-precision selection: plain fp16 for every ray, then the split engine on the rays the guard band flagged.
+  // Only where the selection is fused; otherwise this mode is the split-precision engine.
+  const bool guarded = c->sampling_mode == ADANERF_SAMPLING_GUARDED && sel != nullptr;
+  if (guarded) {
+    if (!(c->guard_eps > 0.f)) {      // first guarded frame of a context created without a band: measure one for this model
+      float d = 0.f;
+      int rc = calibrate_guard(c, 8, 1u, true, &d);
+      if (rc) return rc;
+    }
+    a.sel.guard_mask = reinterpret_cast<uint32_t*>(c->guard_mask.p);
+    a.sel.guard_eps = guard_band_of(c->transform, c->guard_eps);
+    a.sel.guard_probe = reinterpret_cast<float*>(c->guard_probe.p);
+    a.sel.guard_seen = reinterpret_cast<uint32_t*>(c->total.p) + 8;
+  }
   if (c->sampling_mode == 1) {
     HIP_TRY(c, launch_sample_mlp_f32(a, full, grid.x, c->stream));
-  } else if (c->sampling_mode == 2) {
+  } else if (c->sampling_mode == 2 || guarded) {
     if (!c->net0_f16.w.p) {
       PackedNet pn;
       std::string err;
@@ -522,6 +551,30 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
     dim3 g16(std::min<unsigned>((n_rays + 255) / 256, static_cast<unsigned>(c->sample16_grid))), b16(512);
     if (full) hipLaunchKernelGGL((sample_mlp16_kernel<10, 4>), g16, b16, 0, c->stream, a);
     else hipLaunchKernelGGL((sample_mlp16_kernel<2, 2>), g16, b16, 0, c->stream, a);
+    if (guarded) {
+      // undecided rays -> ascending list (+ count at total[4]) -> split engine over the list, rows overwritten in place
+      const int n_words = (n_rays + 31) / 32;
+      int32_t* n_list = reinterpret_cast<int32_t*>(c->total.p) + 4;
+      hipLaunchKernelGGL(refine_list_kernel, dim3((n_words + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(c->guard_mask.p),
+                         n_words, reinterpret_cast<int32_t*>(c->refine_list.p), n_list);
+      SampleArgs r = a;
+      r.net16 = c->net0_split.params;
+      r.rays_out = nullptr;              // the first pass wrote the ray records
+      r.sel.guard_mask = nullptr;
+      r.sel.guard_band = r.sel.guard_eps;      // the second pass only monitors against the band
+      r.sel.guard_eps = 0.f;
+      r.sel.refine_list = reinterpret_cast<const int32_t*>(c->refine_list.p);
+      r.ray_list = r.sel.refine_list;
+      r.n_list = n_list;
+      if (!c->sample_grid) {
+        int rc = full ? occupancy_grid(c, sample_mlp16x3_kernel<10, 4>, 256, &c->sample_grid)
+                      : occupancy_grid(c, sample_mlp16x3_kernel<2, 2>, 256, &c->sample_grid);
+        if (rc) return rc;
+      }
+      const dim3 rgrid(std::min<unsigned>(grid.x, static_cast<unsigned>(c->sample_grid)));
+      if (full) hipLaunchKernelGGL((sample_mlp16x3_kernel<10, 4>), rgrid, block, 0, c->stream, r);
+      else hipLaunchKernelGGL((sample_mlp16x3_kernel<2, 2>), rgrid, block, 0, c->stream, r);
+    }
   } else {
     if (!c->sample_grid) {
       int rc = full ? occupancy_grid(c, sample_mlp16x3_kernel<10, 4>, 256, &c->sample_grid)
@@ -585,7 +638,8 @@ int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max,
     return ADANERF_OK;
   }
   if (use_pair_select(c, n_max)) {
-    hipLaunchKernelGGL(select_rows_kernel, dim3((n_rays + 127) / 128), dim3(256), 0, c->stream, d_oracle, n_rays, select_out(c, n_max, thr, d_cnt));
+    hipLaunchKernelGGL(select_rows_kernel, dim3((n_rays + 127) / 128), dim3(256), 0, c->stream, d_oracle, n_rays, select_out(c, n_max, thr, d_cnt),
+                       static_cast<const int32_t*>(nullptr));
     return launch_expand(c, n_rays, n_max, kPairSegShift, d_off, d_cnt, d_key, d_w, d_total);
   }
   const int nblk = (n_rays + kSelRaysPerBlock - 1) / kSelRaysPerBlock;
@@ -593,6 +647,96 @@ int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max,
                      reinterpret_cast<uint8_t*>(c->selbin.p), reinterpret_cast<float*>(c->selw.p),
                      reinterpret_cast<int32_t*>(c->block_total.p));
   return launch_expand(c, n_rays, n_max, kSelSegShift, d_off, d_cnt, d_key, d_w, d_total);
+}
+
+// Largest |plain-fp16 - split-precision| raw output of the sampling network over n_poses x 64 x 64 calibration rays
+// (include/adanerf_hip.h: adanerf_calibrate_guard).  Temporarily replaces the ray generator's image and camera.
+int calibrate_guard(adanerf_ctx* c, int n_poses, uint32_t seed, bool install, float* max_diff) {
+  if (c->coarse_fine || c->generic0) return fail(c, ADANERF_EUNSUPPORTED, "guard calibration needs an 8 x 256 sampling network");
+  if (n_poses < 1 || n_poses > 4096) return fail(c, ADANERF_EINVAL, "n_poses must be in 1..4096");
+  constexpr int CW = 64, CH = 64, CR = CW * CH;
+  const RayGenParams saved = c->rg;
+  const int saved_mode = c->sampling_mode;
+  RayGenParams g = saved;
+  // same field of view on a 64 x 64 image (setup_model's arithmetic): x_dist = tan(fov / 2) focal, y_dist = x_dist h / w
+  const double x_dist = -saved.start_x + saved.x_pp / 2, y_dist = -saved.start_y + saved.y_pp / 2;
+  g.w = CW;
+  g.h = CH;
+  g.x_pp = x_dist / (CW / 2.0);
+  g.y_pp = y_dist / (CH / 2.0);
+  g.start_x = -(x_dist - g.x_pp / 2);
+  g.start_y = -(y_dist - g.y_pp / 2);
+  g.strip_rows = CH;
+  g.world = 1;
+  g.rank = 0;
+  DevBuf a_buf, b_buf, acc;
+  int rc = ADANERF_OK;
+  auto done = [&](int code) {
+    (void)hipStreamSynchronize(c->stream);
+    dev_free(&a_buf);
+    dev_free(&b_buf);
+    dev_free(&acc);
+    c->rg = saved;
+    c->sampling_mode = saved_mode;
+    return code;
+  };
+  if ((rc = dev_alloc(c, &a_buf, static_cast<size_t>(CR) * kBins * sizeof(float)))) return done(rc);
+  if ((rc = dev_alloc(c, &b_buf, static_cast<size_t>(CR) * kBins * sizeof(float)))) return done(rc);
+  if ((rc = dev_alloc(c, &acc, 64))) return done(rc);
+  if (hipMemsetAsync(acc.p, 0, 64, c->stream) != hipSuccess) return done(fail(c, ADANERF_EDEVICE, "hipMemsetAsync failed"));
+  uint64_t st = 0x9E3779B97F4A7C15ull ^ (static_cast<uint64_t>(seed) << 17);
+  auto rnd = [&]() {      // xorshift64*, uniform in [0, 1)
+    st ^= st >> 12;
+    st ^= st << 25;
+    st ^= st >> 27;
+    return static_cast<double>((st * 0x2545F4914F6CDD1Dull) >> 11) * (1.0 / 9007199254740992.0);
+  };
+  for (int k = 0; k < n_poses; ++k) {
+    for (int i = 0; i < 3; ++i) g.pos[i] = g.center[i] + static_cast<float>((rnd() - 0.5) * 0.9 * c->info.view_cell_size[i]);
+    // orientation: yaw about z, then pitch (the viewer's camera: z up, looking along -z of the camera frame)
+    const double yaw = 2.0 * M_PI * rnd(), pitch = (rnd() - 0.5) * (c->info.use_ndc ? 0.2 : 1.4);
+    const double cy = std::cos(yaw), sy = std::sin(yaw), cp = std::cos(pitch), sp = std::sin(pitch);
+    double fwd[3], right[3], up[3];
+    if (c->info.use_ndc) {      // forward-facing scenes look down -z
+      fwd[0] = sp * cy; fwd[1] = sp * sy; fwd[2] = -cp;
+      right[0] = 1; right[1] = 0; right[2] = 0;
+    } else {
+      fwd[0] = cp * cy; fwd[1] = cp * sy; fwd[2] = sp;
+      right[0] = sy; right[1] = -cy; right[2] = 0;
+    }
+    // re-orthogonalise: right = normalize(right - (right . fwd) fwd), up = right x fwd
+    const double rf = right[0] * fwd[0] + right[1] * fwd[1] + right[2] * fwd[2];
+    double n = 0;
+    for (int i = 0; i < 3; ++i) { right[i] -= rf * fwd[i]; n += right[i] * right[i]; }
+    n = std::sqrt(n);
+    for (int i = 0; i < 3; ++i) right[i] /= n;
+    up[0] = right[1] * fwd[2] - right[2] * fwd[1];
+    up[1] = right[2] * fwd[0] - right[0] * fwd[2];
+    up[2] = right[0] * fwd[1] - right[1] * fwd[0];
+    for (int i = 0; i < 3; ++i) {      // columns of c2w: camera x = right, y = up, -z = forward
+      g.rot[3 * i + 0] = static_cast<float>(right[i]);
+      g.rot[3 * i + 1] = static_cast<float>(up[i]);
+      g.rot[3 * i + 2] = static_cast<float>(-fwd[i]);
+    }
+    c->rg = g;
+    c->sampling_mode = ADANERF_SAMPLING_SPLIT_FP16;
+    if ((rc = launch_sample_mlp(c, 0, CR, reinterpret_cast<float*>(a_buf.p), nullptr))) return done(rc);
+    c->sampling_mode = ADANERF_SAMPLING_FP16;
+    if ((rc = launch_sample_mlp(c, 0, CR, reinterpret_cast<float*>(b_buf.p), nullptr))) return done(rc);
+    hipLaunchKernelGGL(max_abs_diff_kernel, dim3(256), dim3(256), 0, c->stream, reinterpret_cast<const float*>(a_buf.p),
+                       reinterpret_cast<const float*>(b_buf.p), static_cast<size_t>(CR) * kBins, reinterpret_cast<uint32_t*>(acc.p));
+  }
+  uint32_t res[2] = {0, 0};
+  if (hipMemcpyAsync(res, acc.p, sizeof(res), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+    return done(fail(c, ADANERF_EDEVICE, "guard calibration: read-back failed"));
+  float d;
+  std::memcpy(&d, &res[0], sizeof(d));
+  if (max_diff) *max_diff = res[1] ? INFINITY : d;
+  if (install) {
+    c->guard_eps = res[1] ? ADANERF_GUARD_EPS_DEFAULT : std::max(ADANERF_GUARD_CALIB_MARGIN * d, ADANERF_GUARD_EPS_MIN);
+    c->info.guard_eps = c->guard_eps;
+  }
+  return done(ADANERF_OK);
 }
 
 constexpr int kShadeWaves = 8;   // one 8-wave workgroup per CU (two independent 4-wave workgroups measured 4.2-5.7 ms vs 3.8)
@@ -629,7 +773,11 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
   } else {
     const int tile = kShadeWaves * 32;
     const int tiles = (max_samples + tile - 1) / tile;
-    if (prec == ADANERF_PREC_BF16) {
+    if (tune::kShadeBlocks == 2) {      // two sample blocks per wave, 4 waves x 64 samples (same 256-sample tile)
+      const int cu = c->info.compute_units;
+      if (prec == ADANERF_PREC_BF16) hipLaunchKernelGGL((shade_mlp16x2_kernel<Bf16, 10, 4>), dim3(std::min(tiles, cu)), dim3(256), 0, c->stream, a);
+      else hipLaunchKernelGGL((shade_mlp16x2_kernel<Fp16, 10, 4>), dim3(std::min(tiles, cu)), dim3(256), 0, c->stream, a);
+    } else if (prec == ADANERF_PREC_BF16) {
       if (!c->shade_grid[0] && (rc = occupancy_grid(c, shade_mlp16_kernel<Bf16, 10, 4, kShadeWaves>, kShadeWaves * 64, &c->shade_grid[0]))) return rc;
       hipLaunchKernelGGL((shade_mlp16_kernel<Bf16, 10, 4, kShadeWaves>), dim3(std::min(tiles, c->shade_grid[0])), dim3(kShadeWaves * 64), 0,
                          c->stream, a);
@@ -782,6 +930,8 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     if (!c->generic0 && !pack_sampling_net(n0, sh, Elem::F16_SPLIT, &p0s, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
   }
   c->sampling_mode = opt->sampling_mode;
+  c->guard_eps = opt->guard_eps > 0.f ? opt->guard_eps : 0.f;      // 0: calibrated before the first guarded frame
+  c->info.guard_eps = c->guard_eps;
   {   // topology of the shading net first (fp32 packing accepts every supported topology)
     PackedNet probe;
     if (!pack_shading_net(c->net1_host, sh, Elem::F32, &probe, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
@@ -922,7 +1072,8 @@ int adanerf_destroy(adanerf_ctx* c) {
   DevBuf* bufs[] = {&c->net0_split.w, &c->net0_split.b, &c->net0_f16.w, &c->net0_f16.b, &c->overflow, &c->net0.w, &c->net0.b, &c->net1[0].w, &c->net1[0].b, &c->net1[1].w, &c->net1[1].b, &c->net1[2].w, &c->net1[2].b,
                     &c->ztab, &c->rays, &c->oracle, &c->ray_offsets, &c->ray_counts, &c->selbin, &c->selw, &c->block_total,
                     &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw, &c->sample_z, &c->rsi_z,
-                    &c->netc[0].w, &c->netc[0].b, &c->netc[1].w, &c->netc[1].b, &c->netc[2].w, &c->netc[2].b, &c->ztab_coarse, &c->raw_coarse, &c->key_coarse};
+                    &c->netc[0].w, &c->netc[0].b, &c->netc[1].w, &c->netc[1].b, &c->netc[2].w, &c->netc[2].b, &c->ztab_coarse, &c->raw_coarse, &c->key_coarse,
+                    &c->guard_mask, &c->refine_list, &c->guard_probe};
   for (DevBuf* b : bufs) dev_free(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -985,6 +1136,42 @@ int adanerf_compact(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, int32
   int rc = ensure_compact_scratch(c, n_rays, n_max);
   if (rc) return rc;
   return launch_compact(c, d_oracle, n_rays, n_max, thr, d_off, d_cnt, d_key, d_w, d_total);
+}
+
+int adanerf_compact_guarded(adanerf_ctx* c, const float* d_approx, const float* d_exact, int32_t n_rays, int32_t n_max, float thr, float eps,
+                            int32_t* d_off, int32_t* d_cnt, uint32_t* d_key, float* d_w, int32_t* d_total, int32_t* d_refined) {
+  if (!c) return ADANERF_EINVAL;
+  BIND(c);
+  if (!d_approx || !d_exact || !d_off || !d_cnt || !d_key || !d_w || !d_total || !d_refined) return fail(c, ADANERF_EINVAL, "NULL buffer");
+  if (n_rays < 0 || n_max < 1 || n_max > kPairMaxN || !(thr > 0.f) || !(eps > 0.f)) return fail(c, ADANERF_EINVAL, "n_rays/n_max/thr/eps out of range");
+  if (static_cast<int64_t>(n_rays) >= (1ll << 25)) return fail(c, ADANERF_EINVAL, "n_rays must be < 2^25 per batch");
+  if (n_rays == 0) return ADANERF_OK;
+  int rc = ensure_compact_scratch(c, n_rays, n_max);
+  if (rc) return rc;
+  const int n_words = (n_rays + 31) / 32;
+  if (c->guard_mask.bytes < n_words * sizeof(uint32_t) || c->refine_list.bytes < static_cast<size_t>(n_rays) * sizeof(int32_t)) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((rc = dev_alloc(c, &c->guard_mask, n_words * sizeof(uint32_t)))) return rc;
+    if ((rc = dev_alloc(c, &c->refine_list, static_cast<size_t>(n_rays) * sizeof(int32_t)))) return rc;
+  }
+  SelectOut so = select_out(c, n_max, thr, d_cnt);
+  so.guard_mask = reinterpret_cast<uint32_t*>(c->guard_mask.p);
+  so.guard_eps = guard_band_of(c->transform, eps);
+  const dim3 grid((n_rays + 127) / 128), block(256);
+  hipLaunchKernelGGL(select_rows_kernel, grid, block, 0, c->stream, d_approx, n_rays, so, static_cast<const int32_t*>(nullptr));
+  hipLaunchKernelGGL(refine_list_kernel, dim3((n_words + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(c->guard_mask.p), n_words,
+                     reinterpret_cast<int32_t*>(c->refine_list.p), d_refined);
+  so.guard_mask = nullptr;
+  so.guard_eps = 0.f;
+  so.refine_list = reinterpret_cast<const int32_t*>(c->refine_list.p);
+  hipLaunchKernelGGL(select_rows_kernel, grid, block, 0, c->stream, d_exact, n_rays, so, static_cast<const int32_t*>(d_refined));
+  return launch_expand(c, n_rays, n_max, kPairSegShift, d_off, d_cnt, d_key, d_w, d_total);
+}
+
+int adanerf_calibrate_guard(adanerf_ctx* c, int32_t n_poses, uint32_t seed, int32_t set, float* max_diff) {
+  if (!c) return ADANERF_EINVAL;
+  BIND(c);
+  return calibrate_guard(c, n_poses, seed, set != 0, max_diff);
 }
 
 int adanerf_shade_features(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, int32_t n_samples, float* d_feat) {
@@ -1095,7 +1282,14 @@ int sum_stats(adanerf_ctx* c, adanerf_stats* stats) {
     stats->ms_composite += t;
     HIP_TRY(c, hipEventElapsedTime(&t, ev[0], ev[4]));
     stats->ms_total += t;
-    stats->total_samples += *c->pinned_totals[b];
+    stats->total_samples += c->pinned_totals[b][0];
+    if (c->sampling_mode == ADANERF_SAMPLING_GUARDED) {
+      stats->rays_refined += c->pinned_totals[b][4];
+      float seen;                                      // cumulative on the device: the latest batch holds the running values
+      std::memcpy(&seen, &c->pinned_totals[b][8], sizeof(seen));
+      stats->guard_max_seen = std::max(stats->guard_max_seen, seen);
+      stats->guard_violations = std::max(stats->guard_violations, c->pinned_totals[b][9]);
+    }
   }
   int32_t ovf = 0;
   HIP_TRY(c, hipMemcpy(&ovf, c->overflow.p, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1106,6 +1300,9 @@ int sum_stats(adanerf_ctx* c, adanerf_stats* stats) {
   // plus whatever an earlier, full event pool was folded into
   const adanerf_stats& f = c->folded;
   stats->total_samples += f.total_samples;
+  stats->rays_refined += f.rays_refined;
+  stats->guard_max_seen = std::max(stats->guard_max_seen, f.guard_max_seen);
+  stats->guard_violations = std::max(stats->guard_violations, f.guard_violations);
   stats->ms_total += f.ms_total;
   stats->ms_sample_mlp += f.ms_sample_mlp;
   stats->ms_compact += f.ms_compact;
@@ -1180,8 +1377,8 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     }
     while (c->pinned_totals.size() < need / 5) {
       int32_t* p = nullptr;
-      HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(int32_t), hipHostMallocDefault));
-      *p = 0;
+      HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&p), 16 * sizeof(int32_t), hipHostMallocDefault));   // image of the `total` block
+      std::memset(p, 0, 16 * sizeof(int32_t));
       c->pinned_totals.push_back(p);
     }
   }
@@ -1241,7 +1438,7 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     if (rc) return rc;
     if (ev) {
       HIP_TRY(c, hipEventRecord(ev[4], c->stream));
-      HIP_TRY(c, hipMemcpyAsync(c->pinned_totals[c->events_used / 5], total, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(c->pinned_totals[c->events_used / 5], total, 10 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
       c->events_used += 5;
     }
   }

@@ -176,16 +176,20 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ o
 }
 
 // Lane-pair selection (k_select_pair.hip.hpp), standalone form: rows of [R,128] fp32 in global memory (stage API / parity tests).  4 waves x 32 rays per workgroup.
-__global__ __launch_bounds__(256) void select_rows_kernel(const float* __restrict__ oracle, int n_rays, SelectOut so) {
+// n_list != null: the refinement pass of the guarded selection -- rows so.refine_list[0 .. *n_list) only (n_rays bounds the launch).
+__global__ __launch_bounds__(256) void select_rows_kernel(const float* __restrict__ oracle, int n_rays, SelectOut so,
+                                                          const int32_t* __restrict__ n_list = nullptr) {
   __shared__ __attribute__((aligned(16))) char lds[4 * kPairLdsBytesPerWave];
   const int lane = lane_id();
   const int wave = static_cast<int>(threadIdx.x) >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int first = (blockIdx.x * 4 + wave) * 32;
+  if (n_list) n_rays = min(n_rays, *n_list);
   if (first >= n_rays) return;                       // wave-uniform
   const int local = first + j;
   const bool valid = local < n_rays;
-  const float* row = oracle + static_cast<size_t>(valid ? local : n_rays - 1) * kBins;
+  const int lidx = valid ? local : n_rays - 1;
+  const float* row = oracle + static_cast<size_t>(n_list ? so.refine_list[lidx] : lidx) * kBins;
   float x[64];
 #pragma unroll
   for (int m = 0; m < 4; ++m)
@@ -198,7 +202,31 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const float* __restric
       x[16 * m + 4 * g + 3] = v.w;
     }
   const uint32_t stage = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + wave * kPairLdsBytesPerWave + lane * 16;
-  pair_epilogue(x, lane, local, valid, stage, so);
+  bool bad = false;
+  if (so.guard_mask) {      // guard mode: a non-finite row is undecided by definition (the sampling kernels do the same)
+    float z = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) z = __builtin_fmaf(x[i], 0.f, z);
+    bad = (z != z) | (__shfl_xor(static_cast<int>(z != z), 32) != 0);
+  }
+  pair_epilogue(x, lane, local, valid, stage, so, bad);
+}
+
+// max |a - b| over n floats -> *out (float bits of a non-negative value, atomicMax); a non-finite difference sets out[1]
+__global__ __launch_bounds__(256) void max_abs_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, uint32_t* __restrict__ out) {
+  float m = 0.f;
+  bool bad = false;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const float d = fabsf(a[i] - b[i]);
+    if (d == d && d < INFINITY) m = fmaxf(m, d);
+    else bad = true;
+  }
+  m = wave_max_nonneg(m);
+  const uint64_t anybad = __ballot(bad);
+  if ((threadIdx.x & 63) == 0) {
+    if (m > 0.f) atomicMax(&out[0], __builtin_bit_cast(uint32_t, m));
+    if (anybad) atomicAdd(&out[1], 1u);
+  }
 }
 
 // exclusive scan of the per-block totals by one workgroup; writes S to *total
@@ -285,6 +313,35 @@ __global__ __launch_bounds__(256) void expand_kernel(const int32_t* __restrict__
     sample_key[o + k] = (static_cast<uint32_t>(r) << 7) | selbin[src + k];
     sample_w[o + k] = selw[src + k];
   }
+}
+
+// Guarded selection, between its two passes: the ascending list of the rays whose guard bit is set (one word per 32 rays,
+// written by pair_epilogue) and their number.  256 words (8 192 rays) per workgroup; like expand_kernel every workgroup sums what
+// lies in front of it instead of waiting for a scan (<= 80 KB of L2 reads per workgroup at 800 x 800).  Deterministic order.
+__global__ __launch_bounds__(256) void refine_list_kernel(const uint32_t* __restrict__ mask, int n_words, int32_t* __restrict__ list,
+                                                          int32_t* __restrict__ count) {
+  __shared__ int part[4], wtot[4];
+  const int t = static_cast<int>(threadIdx.x);
+  const int b0 = blockIdx.x * 256;
+  int s = 0;
+  for (int i = t; i < b0; i += 256) s += __popc(mask[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  const int wi = b0 + t;
+  const uint32_t m = wi < n_words ? mask[wi] : 0u;
+  const int c = __popc(m);
+  int x = c;                                      // inclusive scan inside the wave
+  for (int off = 1; off < 64; off <<= 1) {
+    const int y = __shfl_up(x, off, 64);
+    if ((t & 63) >= off) x += y;
+  }
+  if ((t & 63) == 63) wtot[t >> 6] = x;
+  if ((t & 63) == 0) part[t >> 6] = s;
+  __syncthreads();
+  int base = part[0] + part[1] + part[2] + part[3] + x - c;
+  for (int w = 0; w < (t >> 6); ++w) base += wtot[w];
+  for (uint32_t r = m; r; r &= r - 1u) list[base++] = wi * 32 + __builtin_ctz(r);
+  if (blockIdx.x == gridDim.x - 1 && t == 255) *count = base;      // the last thread's end = the total
 }
 
 // Debug view of the sampling network (viewer 'O' key: copyResultSamplingNetwork -> samplesToImage,

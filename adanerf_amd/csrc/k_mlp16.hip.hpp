@@ -286,7 +286,7 @@ __device__ __forceinline__ void epilogue_quad_16(const f32x16& acc, int m, int g
 
 constexpr int kKeepAllF32 = -2;   // layer_16 KEEP_F32_TILE: every tile's raw accumulator goes to keep[m]
 
-#if ADN_OVERRIDABLE
+#if ADN_EXPERIMENT_BUILD
 }  // namespace adanerf
 #include "x_handsched.hip.hpp"     // experiment builds only (-DADN_EXPERIMENT): HsLayer / HsLayer3, see profiles/r02_handsched.md
 namespace adanerf {
@@ -297,7 +297,7 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
                                          uint32_t* out, f32x16* keep = nullptr) {
   constexpr int CF = WS::kChunk;
   constexpr int KS = S1 + S2;
-#if ADN_OVERRIDABLE
+#if ADN_EXPERIMENT_BUILD
   if constexpr (tune::kHandSched) {
     HsLayer<ET, WS, S1, S2, MT, RELU, FPOS, KEEP_F32_TILE>::run(st, bias_addr, in1, in2, out, keep);
     return;
@@ -434,14 +434,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
       lds_stash_write<QD / 8>(stash + (QP / 8) * 1024, dirs);
       layer_16<ET, WS, QP / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, lane, pts, pts, hA);
     }
-#if ADN_OVERRIDABLE
+#if ADN_EXPERIMENT_BUILD
     if constexpr (tune::kHandSched) ws_settle(st);      // no LDS read in flight into a loop or over its back-edge (HsLayer)
 #endif
 #pragma unroll 1
     for (int l = 1; l <= 3; l += 2) {
       layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l] * 4, lane, hA, hA, hB);
       layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l + 1] * 4, lane, hB, hB, hA);
-  #if ADN_OVERRIDABLE
+  #if ADN_EXPERIMENT_BUILD
     if constexpr (tune::kHandSched) ws_settle(st);      // no LDS read in flight over a loop back-edge (HsLayer)
 #endif
     }
@@ -463,11 +463,147 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
     }
     f32x16 rgb_tile;
     layer_16<ET, WS, 8, 0, 1, false, (32 + 4 * 128 + 160 + 2 * 128 + 144 + 72) % CF, 0>(st, bias0 + bo[10] * 4, lane, hB, hB, hA, &rgb_tile);
-#if ADN_OVERRIDABLE
+#if ADN_EXPERIMENT_BUILD
     if constexpr (tune::kHandSched) ws_settle(st);
 #endif
     if (h == 0 && s < total)
       *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(rgb_tile[0], rgb_tile[1], rgb_tile[2], alpha);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+// ---- two sample blocks per wave -------------------------------------------------------------------------------------------
+// layer_16 for TWO 32-sample column blocks held by one wave: every weight fragment read from LDS feeds two MFMAs (one per
+// block), so the LDS operand traffic, the DMA issue and the barriers per MFMA are half of layer_16's.  The price is the register
+// file: 2 x (64 + 64) packed activation registers, i.e. one wave per SIMD (up to 512 registers), so nothing but the wave's own
+// instruction stream hides latencies: the two accumulator chains alternate (no dependent back-to-back MFMAs), the bias block of
+// tile m + 1 is requested while tile m computes, and the epilogue of tile m - 1 (both blocks: 8 quads) is spread over the
+// first k-steps of tile m.  Both chains start from the bias registers as the C operand (no copies).
+template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
+__device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uint32_t* in1A, const uint32_t* in2A, const uint32_t* in1B,
+                                           const uint32_t* in2B, uint32_t* outA, uint32_t* outB, f32x16* keepA = nullptr,
+                                           f32x16* keepB = nullptr) {
+  constexpr int CF = WS::kChunk;
+  constexpr int KS = S1 + S2;
+  constexpr int PER = (KS >= 8) ? 1 : (8 + KS - 1) / KS;      // epilogue quads of the previous tile per k-step
+  BiasRegs br;
+  f32x16 pA, pB;
+  lds_bias_issue(bias_addr, br);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    f32x16 bias, accA, accB;
+    lds_bias_take(br, &bias);
+    if (m + 1 < MT) lds_bias_issue(bias_addr + (m + 1) * 128, br);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int f = (FPOS + m * KS + s) % CF;
+      ws_position<0>(st, f, false);
+      const uint32_t* sa = (s < S1) ? (in1A + 4 * s) : (in2A + 4 * (s - S1));
+      const uint32_t* sb = (s < S1) ? (in1B + 4 * s) : (in2B + 4 * (s - S1));
+      const u32x4 ba = {sa[0], sa[1], sa[2], sa[3]}, bb = {sb[0], sb[1], sb[2], sb[3]};
+      accA = ET::mfma(st.R[f % WS::kRegs], ba, s == 0 ? bias : accA);
+      accB = ET::mfma(st.R[f % WS::kRegs], bb, s == 0 ? bias : accB);
+      ws_refill<0>(st, f);
+      if (m > 0 && KEEP_F32_TILE != m - 1) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+          const int q = s * PER + k;
+          if (q < 4) epilogue_quad_16<ET, RELU>(pA, m - 1, q, outA);
+          else if (q < 8) epilogue_quad_16<ET, RELU>(pB, m - 1, q - 4, outB);
+        }
+      }
+    }
+    if (KEEP_F32_TILE == m) {
+      *keepA = accA;
+      *keepB = accB;
+    }
+    if (m + 1 < MT) {
+      pA = accA;
+      pB = accB;
+    } else if (KEEP_F32_TILE != m) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(accA, m, g, outA);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(accB, m, g, outB);
+    }
+  }
+}
+
+// A5+A6, 16-bit MFMA path, two sample blocks per wave (layer_16x2): workgroup = 4 waves (one per SIMD) x 64 samples = the same
+// 256-sample tile as shade_mlp16_kernel; same weight stream, ring and bias blocks.
+template <class ET, int FP, int FD>
+__global__ __launch_bounds__(256) void shade_mlp16x2_kernel(ShadeArgs a) {
+  static_assert(FP == 10 && FD == 4, "fragment positions below assume the 10-4 shading encoding");
+  constexpr int QP = pe_slots(FP), QD = pe_slots(FD);
+  constexpr int WAVES = 4, TILE = WAVES * 64, CF = tune::kChunkFrags2, RS = tune::kRingSlots2, LPW = CF / WAVES;
+  constexpr int kRingBytes = CF * RS * 1024;
+  static_assert(CF % WAVES == 0 && CF % tune::kRegFrags2 == 0 && kShadeFrags16 % CF == 0 && CF % 8 == 0 && CF <= 32, "chunk geometry");
+  typedef WStream<CF, RS, LPW, tune::kRegFrags2> WS;
+  constexpr int kStashPerBlock = (QP / 8 + QD / 8) * 1024;
+  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kShadeBiasFloats * 4 + WAVES * 2 * kStashPerBlock];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const uint32_t stash = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + kShadeBiasFloats * 4 +
+                         wave * 2 * kStashPerBlock + lane * 16;
+  int total = a.total ? *a.total : a.max_samples;
+  if (total > a.max_samples) total = a.max_samples;
+  const int ntiles = (total + TILE - 1) / TILE;
+  if (static_cast<int>(blockIdx.x) >= ntiles) return;    // workgroup-uniform
+  {
+    float* lds_bias = reinterpret_cast<float*>(lds + kRingBytes);
+    for (int i = threadIdx.x; i < kShadeBiasFloats; i += blockDim.x) lds_bias[i] = a.net.bias[i];
+  }
+  __syncthreads();
+  WS st;
+  ws_start(st, a.net.w, kShadeFrags16 * 1024, lds, wave, lane);
+  const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
+  const uint32_t* bo = a.net.b_off;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int s0 = tile * TILE + wave * 64 + j, s1 = s0 + 32;
+    uint32_t hA0[64], hB0[64], hA1[64], hB1[64];
+    {
+      float x[3], dpe[3];
+      uint32_t pts0[QP / 2], pts1[QP / 2], dirs[QD / 2];
+      load_sample(a, s0, total, x, dpe);
+      pe_pack<ET, FP>(x, h, pts0);
+      pe_pack<ET, FD>(dpe, h, dirs);
+      lds_stash_write<QP / 8>(stash, pts0);
+      lds_stash_write<QD / 8>(stash + (QP / 8) * 1024, dirs);
+      load_sample(a, s1, total, x, dpe);
+      pe_pack<ET, FP>(x, h, pts1);
+      pe_pack<ET, FD>(dpe, h, dirs);
+      lds_stash_write<QP / 8>(stash + kStashPerBlock, pts1);
+      lds_stash_write<QD / 8>(stash + kStashPerBlock + (QP / 8) * 1024, dirs);
+      layer_16x2<ET, WS, QP / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, pts0, pts0, pts1, pts1, hA0, hA1);
+    }
+#pragma unroll 1
+    for (int l = 1; l <= 3; l += 2) {
+      layer_16x2<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l] * 4, hA0, hA0, hA1, hA1, hB0, hB1);
+      layer_16x2<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l + 1] * 4, hB0, hB0, hB1, hB1, hA0, hA1);
+    }
+    {
+      uint32_t pts0[QP / 2], pts1[QP / 2];
+      lds_stash_read<QP / 8>(stash, pts0);
+      lds_stash_read<QP / 8>(stash + kStashPerBlock, pts1);
+      layer_16x2<ET, WS, QP / 8, 16, 8, true, 0>(st, bias0 + bo[5] * 4, pts0, hA0, pts1, hA1, hB0, hB1);   // cat([pts, h])
+    }
+    layer_16x2<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[6] * 4, hB0, hB0, hB1, hB1, hA0, hA1);
+    layer_16x2<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[7] * 4, hA0, hA0, hA1, hA1, hB0, hB1);
+    f32x16 alpha0, alpha1;
+    layer_16x2<ET, WS, 16, 0, 9, false, 0, 8>(st, bias0 + bo[8] * 4, hB0, hB0, hB1, hB1, hA0, hA1, &alpha0, &alpha1);      // feature (+alpha row)
+    {
+      uint32_t d0[QD / 2], d1[QD / 2];
+      lds_stash_read<QD / 8>(stash + (QP / 8) * 1024, d0);
+      lds_stash_read<QD / 8>(stash + kStashPerBlock + (QP / 8) * 1024, d1);
+      layer_16x2<ET, WS, 16, QD / 8, 4, true, (32 + 4 * 128 + 160 + 2 * 128 + 144) % CF>(st, bias0 + bo[9] * 4, hA0, d0, hA1, d1, hB0, hB1);   // cat([feature, dir])
+    }
+    f32x16 rgb0, rgb1;
+    layer_16x2<ET, WS, 8, 0, 1, false, (32 + 4 * 128 + 160 + 2 * 128 + 144 + 72) % CF, 0>(st, bias0 + bo[10] * 4, hB0, hB0, hB1, hB1, hA0, hA1, &rgb0, &rgb1);
+    if (h == 0 && s0 < total)
+      *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s0) * 4) = make_float4(rgb0[0], rgb0[1], rgb0[2], alpha0[0]);
+    if (h == 0 && s1 < total)
+      *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s1) * 4) = make_float4(rgb1[0], rgb1[1], rgb1[2], alpha1[0]);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }

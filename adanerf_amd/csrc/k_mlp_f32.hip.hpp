@@ -57,6 +57,9 @@ struct SampleArgs {
   float* rays_out;       // [n_rays,8] or null
   SelectOut sel;         // fused_select: adaptive selection in the kernel's epilogue (16-bit engines)
   int32_t fused_select;
+  // pass 2 of the guarded selection (split engine): rays = ray_list[0 .. *n_list) instead of 0 .. n_rays (n_rays bounds the launch)
+  const int32_t* ray_list;
+  const int32_t* n_list;
 };
 
 // A1+A2+A3.  One wave = one block of 32 rays; 4 waves per workgroup (one per SIMD, up to 512 VGPRs).

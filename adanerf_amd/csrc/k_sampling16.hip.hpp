@@ -40,11 +40,15 @@ __device__ __forceinline__ void epilogue_pair_16x3(const f32x16& acc, const f32x
   }
 }
 
-#if ADN_OVERRIDABLE
+#if ADN_EXPERIMENT_BUILD
 }  // namespace adanerf
 #define ADN_HANDSCHED_PART2
 #include "x_handsched.hip.hpp"
 namespace adanerf {
+#endif
+
+#if !ADN_EXPERIMENT_BUILD
+static_assert(!tune::kHandSched && !tune::kHandSchedSampling, "the hand-scheduled layers exist in experiment builds only (-DADN_EXPERIMENT)");
 #endif
 
 template <class WS, int KS, int MT, bool LAST, int FPOS>
@@ -53,7 +57,7 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
   // Software pipeline across output tiles (one wave per SIMD: nothing else hides these latencies):
   //  - the bias block of tile m+1 is requested right after tile m's accumulators are initialised,
   //  - the epilogue of tile m-1 is spread, one accumulator pair per k-step, over tile m's MFMAs.
-#if ADN_OVERRIDABLE
+#if ADN_EXPERIMENT_BUILD
   if constexpr (tune::kHandSchedSampling) {
     HsLayer3<WS, KS, MT, LAST, FPOS>::run(st, bias_addr, in_hi, in_lo, out_hi, out_lo, out_f32);
     return;
@@ -128,7 +132,10 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int j = lane & 31, h = lane >> 5;
-  const int ntiles = (a.n_rays + TILE - 1) / TILE;
+  // refinement pass of the guarded selection: the rays are listed in a.ray_list, their number is known on the device only
+  int n_rays = a.n_rays;
+  if (a.ray_list) n_rays = min(n_rays, __builtin_amdgcn_readfirstlane(*a.n_list));
+  const int ntiles = (n_rays + TILE - 1) / TILE;
   if (static_cast<int>(blockIdx.x) >= ntiles) return;
   // staging block of the fused selection (pair_emit), wave-private
   const uint32_t sel_stage = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + kBiasFloats * 4 +
@@ -146,8 +153,9 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int local = tile * TILE + wave * 32 + j;
-    const bool valid = local < a.n_rays;
-    const int ray = a.first_ray + (valid ? local : a.n_rays - 1);
+    const bool valid = local < n_rays;
+    const int lidx = valid ? local : n_rays - 1;
+    const int ray = a.first_ray + (a.ray_list ? a.ray_list[lidx] : lidx);
     int col, row;
     ray_pixel(a.g, ray, &col, &row);
     float nds[3], p[3], u[3];
@@ -163,20 +171,20 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
       for (int q = 0; q < Q0 / 2; ++q) split_pack(t[2 * q], t[2 * q + 1], &aH[q], &aL[q]);
     }
     layer_16x3<WS, Q0 / 8, 8, false, 0>(st, bias0 + bo[0] * 4, lane, aH, aL, bH, bL, nullptr);
-#if ADN_OVERRIDABLE
+#if ADN_EXPERIMENT_BUILD
     if constexpr (tune::kHandSchedSampling) ws_settle_acc(st);      // ... nor into a loop (the allocator may re-home the ring at the header)
 #endif
 #pragma unroll 1
     for (int l = 1; l <= 5; l += 2) {
       layer_16x3<WS, 16, 8, false, 0>(st, bias0 + bo[l] * 4, lane, bH, bL, aH, aL, nullptr);
       layer_16x3<WS, 16, 8, false, 0>(st, bias0 + bo[l + 1] * 4, lane, aH, aL, bH, bL, nullptr);
-#if ADN_OVERRIDABLE
+#if ADN_EXPERIMENT_BUILD
       if constexpr (tune::kHandSchedSampling) ws_settle_acc(st);      // no LDS read in flight over a loop back-edge (HsLayer3)
 #endif
     }
     float out[64];
     layer_16x3<WS, 16, 4, true, 0>(st, bias0 + bo[7] * 4, lane, bH, bL, nullptr, nullptr, out);
-#if ADN_OVERRIDABLE
+#if ADN_EXPERIMENT_BUILD
     if constexpr (tune::kHandSchedSampling) ws_settle_acc(st);
 #endif
 
@@ -280,20 +288,20 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
       for (int q = 0; q < Q0 / 2; ++q) in0[q] = Fp16::pack(t[2 * q], t[2 * q + 1]);
       layer_16<Fp16, WS, Q0 / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, lane, in0, in0, hA);
     }
-#if ADN_OVERRIDABLE
+#if ADN_EXPERIMENT_BUILD
     if constexpr (tune::kHandSched) ws_settle(st);
 #endif
 #pragma unroll 1
     for (int l = 1; l <= 5; l += 2) {
       layer_16<Fp16, WS, 16, 0, 8, true, F0 % CF>(st, bias0 + bo[l] * 4, lane, hA, hA, hB);
       layer_16<Fp16, WS, 16, 0, 8, true, F0 % CF>(st, bias0 + bo[l + 1] * 4, lane, hB, hB, hA);
-#if ADN_OVERRIDABLE
+#if ADN_EXPERIMENT_BUILD
       if constexpr (tune::kHandSched) ws_settle(st);      // no LDS read in flight over a loop back-edge (HsLayer)
 #endif
     }
     f32x16 out[4];
     layer_16<Fp16, WS, 16, 0, 4, false, F0 % CF, kKeepAllF32>(st, bias0 + bo[7] * 4, lane, hA, hA, hB, out);
-#if ADN_OVERRIDABLE
+#if ADN_EXPERIMENT_BUILD
     if constexpr (tune::kHandSched) ws_settle(st);
 #endif
     if (a.fused_select) {
@@ -305,8 +313,9 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
         z = __builtin_fmaf(x[i], 0.f, z);
       }
       const bool bad_ray = (z != z) | (__shfl_xor(static_cast<int>(z != z), 32) != 0);
-      if (bad_ray && valid && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
-      pair_epilogue(x, lane, local, valid, sel_stage, a.sel);
+      // guard mode: a non-finite ray goes to the refinement pass, which does the counting
+      if (bad_ray && valid && h == 0 && a.overflow_flag && !a.sel.guard_mask) atomicAdd(a.overflow_flag, 1);
+      pair_epilogue(x, lane, local, valid, sel_stage, a.sel, bad_ray);
     }
     if (valid && a.oracle_out) {
       float* o = a.oracle_out + static_cast<size_t>(local) * kBins;

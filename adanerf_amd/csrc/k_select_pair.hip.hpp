@@ -17,10 +17,26 @@ struct SelectOut {
   int32_t n_max;
   float thr;
   int32_t transform;    // kOracle*: what the sampler applies to the raw network outputs first (losses[0])
+  // Guard-banded two-precision selection (ADANERF_SAMPLING_GUARDED, see pair_select):
+  uint32_t* guard_mask;        // pass 1 (plain-fp16 engine): [ceil(R / 32)] bit j of word s set <=> ray 32 s + j is undecided
+  float guard_eps;             //   guard_band_of(transform, bound on |fp16-engine output - split-engine output| per raw value)
+  const int32_t* refine_list;  // pass 2 (split engine on the undecided rays only): `local` indexes this list of ray ids; the
+                               //   ray's counts / selbin / selw are overwritten and seg_total corrected by the count difference
+  // Monitor of the assumption behind the band: pass 1 leaves the largest (transformed) value of every undecided ray in
+  // guard_probe[ray]; pass 2 compares it with its own and keeps the largest difference seen (guard_seen[0], float bits) and the
+  // number of rays where it exceeded the band (guard_seen[1]).  A sample of the error, for free, on every frame.
+  float* guard_probe;          // [R] or null
+  uint32_t* guard_seen;        // [2] or null
+  float guard_band;            // pass 2: the band pass 1 used (guard_eps is 0 there)
 };
 
 // src/nerf_raymarch_common.py:624-630 / 686-690: BCEWithLogitsLoss -> sigmoid, CrossEntropyLoss[Weighted] -> softmax over the bins
 constexpr int kOracleRaw = 0, kOracleSigmoid = 1, kOracleSoftmax = 2;
+
+// SelectOut::guard_eps for a bound eps on the raw outputs (host side; see pair_select)
+inline float guard_band_of(int transform, float eps) {
+  return transform == kOracleSigmoid ? 0.25f * eps : (transform == kOracleSoftmax ? 1.01f * (__builtin_expf(2.0f * eps) - 1.0f) : eps);
+}
 
 constexpr int kPairSegShift = 5;                 // a wave selects for 32 rays = one entry of seg_total
 constexpr int kPairMaxN = 16;                    // largest n_max this path handles (sorted lists live in registers)
@@ -69,8 +85,21 @@ __device__ __forceinline__ int pair_below(uint32_t qlo, uint32_t qhi, int g) {  
 //   2. partner's list by one cross-half exchange, bitonic merge -> the ray's n_max-th largest value,
 //   3. cut value t = max(that, thr) (or the maximum when nothing reaches thr); kept = {x >= t}; only if more than n_max
 //      values pass -- a tie at the cut-off -- the slower exact tie rule runs (wave-uniform branch).
+//
+// Guard band (eps_raw > 0; the caller runs a cheaper, less accurate network whose raw outputs y are within eps of the exact
+// engine's x): *undecided is set unless the selection from y provably equals the selection from ANY x with |x - y| <= eps.
+// With e = the bound carried through the sampler's transform (kOracleRaw: eps; sigmoid: eps / 4 since sigma' <= 1/4; softmax:
+// p~ / p lies in [exp(-2 eps), exp(2 eps)], so |p~ - p| <= max(p~) (exp(2 eps) - 1); the host passes the transform's factor
+// as eps_raw, guard_band_of(), so that no loop-invariant VGPR is held across the MLP for it), a ray is decided iff
+//   (a) none of its n_max largest values lies within e of thr (membership of {x >= thr} is then the same for x and y; smaller
+//       values are either below thr - e or cut off by (b)),
+//   (b) exactly as many values reach u = max(v_n - 2 e, thr - e) as reach the cut value t (no value that could overtake the
+//       n_max-th one; for the arg-max fallback u = v_1 - 2 e: the runner-up is more than 2 e behind),
+//   (c) no tie at the cut and no non-finite value.
+// Everything is derived from the merged sorted list c[] plus ONE counting pass over the lane's 64 values.
 template <int NB>
-__device__ __forceinline__ int pair_select(const float* x, int h, int n_max, float thr, uint32_t* sel_lo, uint32_t* sel_hi) {
+__device__ __forceinline__ int pair_select(const float* x, int h, int n_max, float thr, uint32_t* sel_lo, uint32_t* sel_hi,
+                                           float eps_raw = 0.f, int transform = 0, bool* undecided = nullptr, float* top = nullptr) {
   static_assert(NB == 4 || NB == 8 || NB == 16, "bitonic merge");
   float s[NB];
 #pragma unroll
@@ -104,6 +133,7 @@ __device__ __forceinline__ int pair_select(const float* x, int h, int n_max, flo
   float tn = c[0];
 #pragma unroll
   for (int k = 1; k < NB; ++k) tn = (k == n_max - 1) ? c[k] : tn;
+  if (top) *top = c[0];
   const bool none = c[0] < thr;                       // nothing reaches the threshold: arg-max alone
   const float t = none ? c[0] : fmaxf(tn, thr);
   const int n_eff = none ? 1 : n_max;
@@ -113,6 +143,20 @@ __device__ __forceinline__ int pair_select(const float* x, int h, int n_max, flo
   int own = __popc(lo) + __popc(hi);
   int total = own + static_cast<int>(pair_xchg(static_cast<uint32_t>(own)));
   const bool tie = total > n_eff;
+  if (eps_raw > 0.f) {      // wave-uniform
+    const float e = transform == kOracleSoftmax ? eps_raw * c[0] : eps_raw;      // eps_raw: see guard_band_of()
+    bool und = tie;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) und |= (k < n_max) && (fabsf(c[k] - thr) <= e);
+    const float u = none ? c[0] - 2.0f * e : fmaxf(tn - 2.0f * e, thr - e);
+    int cu = 0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) cu += (x[i] >= u) ? 1 : 0;
+    cu += static_cast<int>(pair_xchg(static_cast<uint32_t>(cu)));
+    und |= cu != total;
+    und |= !(c[0] - c[0] == 0.f) | !(e - e == 0.f);      // inf / NaN among the candidates or in the bound
+    *undecided = und | (pair_xchg(static_cast<uint32_t>(und)) != 0u);
+  }
   if (__ballot(tie) != 0ull) {
     // exact tie rule: everything above t, then the lowest-bin members of {x == t} until n_eff are kept
     uint32_t glo, ghi;
@@ -149,6 +193,17 @@ __device__ __forceinline__ int pair_select(const float* x, int h, int n_max, flo
   *sel_lo = lo;
   *sel_hi = hi;
   return total;
+}
+
+// wave64 max of non-negative floats (their bit patterns order like unsigned integers); every lane gets the result
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  uint32_t x = __builtin_bit_cast(uint32_t, v);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t y = static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), off));
+    x = x > y ? x : y;
+  }
+  return __builtin_bit_cast(float, x);
 }
 
 // hand-issued LDS accesses (hipcc would otherwise order them against the LDS-DMA weight ring with vmcnt(0): see k_mlp16.hip.hpp)
@@ -194,7 +249,9 @@ __device__ __forceinline__ void pair_emit(const float* x, uint32_t lo, uint32_t 
 //   x        64 values of ray j in lane (j, h) (layout above)
 //   local    ray index of lane j inside the batch, valid = local < n_rays (invalid lanes hold a duplicate ray)
 //   stage    see pair_emit
-__device__ __forceinline__ void pair_epilogue(const float* x_raw, int lane, int local, bool valid, uint32_t stage, const SelectOut& so) {
+//   force_undecided  guard mode: the caller already knows the ray needs the exact engine (non-finite raw outputs)
+__device__ __forceinline__ void pair_epilogue(const float* x_raw, int lane, int local, bool valid, uint32_t stage, const SelectOut& so,
+                                              bool force_undecided = false) {
   const int h = lane >> 5;
   float x[64];
   if (so.transform == kOracleSigmoid) {
@@ -220,14 +277,46 @@ __device__ __forceinline__ void pair_epilogue(const float* x_raw, int lane, int 
   }
   uint32_t lo, hi;
   int total;
-  if (so.n_max <= 4) total = pair_select<4>(x, h, so.n_max, so.thr, &lo, &hi);
-  else if (so.n_max <= 8) total = pair_select<8>(x, h, so.n_max, so.thr, &lo, &hi);
-  else total = pair_select<16>(x, h, so.n_max, so.thr, &lo, &hi);
+  bool und = false;
+  float top = 0.f;
+  const float eps = so.guard_eps;      // pass 1: the band; 0 otherwise (host) -- a plain kernel argument, no per-lane select
+  if (so.n_max <= 4) total = pair_select<4>(x, h, so.n_max, so.thr, &lo, &hi, eps, so.transform, &und, &top);
+  else if (so.n_max <= 8) total = pair_select<8>(x, h, so.n_max, so.thr, &lo, &hi, eps, so.transform, &und, &top);
+  else total = pair_select<16>(x, h, so.n_max, so.thr, &lo, &hi, eps, so.transform, &und, &top);
+  if (so.refine_list) {
+    // pass 2 of the guarded selection: this wave's rays are scattered over the batch; replace the ray's row and correct the
+    // total of its 32-ray segment by the difference (integer atomics: the result does not depend on their order)
+    const int target = valid ? so.refine_list[local] : 0;
+    if (so.guard_probe) {
+      const float band = so.transform == kOracleSoftmax ? so.guard_band * top : so.guard_band;
+      float d = (valid && h == 0) ? fabsf(top - so.guard_probe[target]) : 0.f;
+      if (!(d == d)) d = 0.f;                                   // a non-finite first-pass value is why the ray is here
+      const uint64_t over = __ballot(d > band);
+      d = wave_max_nonneg(d);
+      if (lane == 0) {
+        if (d > 0.f) atomicMax(&so.guard_seen[0], __builtin_bit_cast(uint32_t, d));
+        if (over) atomicAdd(&so.guard_seen[1], static_cast<uint32_t>(__popcll(over)));
+      }
+    }
+    pair_emit(x, lo, hi, h, stage, valid, static_cast<size_t>(target) * so.n_max, so.selbin, so.selw);
+    if (valid && h == 0) {
+      const int old = so.counts[target];
+      so.counts[target] = total;
+      if (total != old) atomicAdd(&so.seg_total[target >> kPairSegShift], total - old);
+    }
+    return;
+  }
   pair_emit(x, lo, hi, h, stage, valid, static_cast<size_t>(local) * so.n_max, so.selbin, so.selw);
   int t = (valid && h == 0) ? total : 0;
   if (valid && h == 0) so.counts[local] = total;
 #pragma unroll
   for (int off = 16; off >= 1; off >>= 1) t += __shfl_xor(t, off);      // lanes 0..31 hold the rays
+  if (so.guard_mask) {
+    const bool u = (und | force_undecided) && valid;
+    const uint64_t b = __ballot(u);      // lanes j and j + 32 agree; bits 0..31 = the rays
+    if (lane == 0 && valid) so.guard_mask[local >> kPairSegShift] = static_cast<uint32_t>(b);
+    if (so.guard_probe && u && h == 0) so.guard_probe[local] = top;
+  }
   if (lane == 0 && valid) so.seg_total[local >> kPairSegShift] = t;   // lane 0 invalid: the whole wave is beyond n_rays
 }
 

@@ -9,8 +9,10 @@ namespace tune {
 
 #if defined(ADN_EXPERIMENT)
 #define ADN_OVERRIDABLE 1
+#define ADN_EXPERIMENT_BUILD 1      // stays defined: gates the experiment-only code in k_mlp16 / k_sampling16 (x_handsched.hip.hpp)
 #else
 #define ADN_OVERRIDABLE 0
+#define ADN_EXPERIMENT_BUILD 0
 #endif
 
 // ---- LDS weight ring of the 16-bit engines (k_mlp16.hip.hpp) ---------------------------------------------------------
@@ -94,6 +96,29 @@ constexpr int kDmaGroup = 0;
 constexpr int kSkipPad = ADN_PAD;
 #else
 constexpr int kSkipPad = 11;
+#endif
+
+// ---- shading kernel with two sample blocks per wave (shade_mlp16x2_kernel, one wave per SIMD) ----------------------------
+// kShadeBlocks: 1 = shade_mlp16_kernel (8 waves x 32 samples), 2 = shade_mlp16x2_kernel (4 waves x 64 samples)
+#if ADN_OVERRIDABLE && defined(ADN_SHADE_BLOCKS)
+constexpr int kShadeBlocks = ADN_SHADE_BLOCKS;
+#else
+constexpr int kShadeBlocks = 1;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_CF2)
+constexpr int kChunkFrags2 = ADN_CF2;
+#else
+constexpr int kChunkFrags2 = 16;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_RS2)
+constexpr int kRingSlots2 = ADN_RS2;
+#else
+constexpr int kRingSlots2 = 6;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_NR2)
+constexpr int kRegFrags2 = ADN_NR2;
+#else
+constexpr int kRegFrags2 = 16;
 #endif
 
 // ---- selection (k_compact.hip.hpp) -----------------------------------------------------------------------------------

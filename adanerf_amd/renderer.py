@@ -24,6 +24,7 @@ _PREC = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "fp32": PREC_FP
 BUF_RAYS, BUF_ORACLE, BUF_RAY_OFFSETS, BUF_RAY_COUNTS, BUF_SAMPLE_KEY, BUF_SAMPLE_W, BUF_RAW, BUF_TOTAL, BUF_SAMPLE_Z, BUF_RAW_COARSE = range(10)
 SAMPLER_ADAPTIVE, SAMPLER_PDF, SAMPLER_COARSE_FINE = 0, 1, 2
 FLAG_KEEP_ORACLE, FLAG_WAVE_SELECT = 1, 2
+SAMPLING_MODES = {"split": 0, "fp16x3": 0, "fp32": 1, "fp16": 2, "guarded": 3}
 
 
 class AdaNeRFError(RuntimeError):
@@ -34,7 +35,7 @@ class _Options(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("batch_rays", C.c_int32), ("device_id", C.c_int32),
                 ("precision", C.c_int32), ("num_samples", C.c_int32), ("threshold", C.c_float),
                 ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("strip_rows", C.c_int32),
-                ("sampling_mode", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("sampling_mode", C.c_int32), ("flags", C.c_int32), ("guard_eps", C.c_float), ("reserved", C.c_int32 * 3)]
 
 
 class Info(C.Structure):
@@ -43,20 +44,21 @@ class Info(C.Structure):
                 ("num_samples", C.c_int32), ("threshold", C.c_float), ("dense", C.c_int32), ("use_ndc", C.c_int32),
                 ("precision", C.c_int32), ("compute_units", C.c_int32), ("fov", C.c_float), ("focal", C.c_float),
                 ("view_cell_center", C.c_float * 3), ("view_cell_radius", C.c_float), ("depth_range", C.c_float * 2),
-                ("max_depth", C.c_float), ("sampler_mode", C.c_int32), ("view_cell_size", C.c_float * 3), ("num_samples_coarse", C.c_int32)]
+                ("max_depth", C.c_float), ("sampler_mode", C.c_int32), ("view_cell_size", C.c_float * 3), ("num_samples_coarse", C.c_int32), ("guard_eps", C.c_float)]
 
 
 class Stats(C.Structure):
     _fields_ = [("total_samples", C.c_int64), ("rays", C.c_int32), ("batches", C.c_int32), ("ms_total", C.c_float),
                 ("ms_sample_mlp", C.c_float), ("ms_compact", C.c_float), ("ms_shade_mlp", C.c_float),
                 ("ms_composite", C.c_float), ("shade_launches", C.c_int32), ("sample_launches", C.c_int32),
-                ("sampling_overflow", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("sampling_overflow", C.c_int32), ("rays_refined", C.c_int32), ("guard_max_seen", C.c_float),
+                ("guard_violations", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_last_error", "adanerf_set_camera",
            "adanerf_render", "adanerf_set_aux_outputs", "adanerf_assemble_strips", "adanerf_sync", "adanerf_set_stream", "adanerf_set_profiling",
            "adanerf_collect_stats", "adanerf_ray_features", "adanerf_sample_mlp",
-           "adanerf_compact", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_shade_mlp_z", "adanerf_sample_pdf", "adanerf_sample_uniform", "adanerf_shade_mlp_coarse", "adanerf_sample_from_coarse",
+           "adanerf_compact", "adanerf_compact_guarded", "adanerf_calibrate_guard", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_shade_mlp_z", "adanerf_sample_pdf", "adanerf_sample_uniform", "adanerf_shade_mlp_coarse", "adanerf_sample_from_coarse",
            "adanerf_composite", "adanerf_composite_classic", "adanerf_copy_result_sampling_network",
            "adanerf_render_oracle", "adanerf_gather_to", "adanerf_malloc",
            "adanerf_free", "adanerf_memcpy_h2d", "adanerf_memcpy_d2h", "adanerf_get_buffer"]
@@ -90,6 +92,8 @@ def load_library(path: Optional[str] = None):
     lib.adanerf_ray_features.argtypes = [vp, i32, i32, f32p, f32p]
     lib.adanerf_sample_mlp.argtypes = [vp, i32, i32, f32p, f32p]
     lib.adanerf_compact.argtypes = [vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, vp]
+    lib.adanerf_compact_guarded.argtypes = [vp, vp, vp, i32, i32, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp]
+    lib.adanerf_calibrate_guard.argtypes = [vp, i32, C.c_uint32, i32, C.POINTER(C.c_float)]
     lib.adanerf_shade_features.argtypes = [vp, vp, vp, i32, vp]
     lib.adanerf_shade_mlp.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     lib.adanerf_composite.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
@@ -186,7 +190,8 @@ class NeuralRenderer:
 
     def __init__(self, settings: Settings, precision="bf16", device_id: int = 0, num_samples: int = 0,
                  threshold: float = -1.0, shard_rank: int = 0, shard_world: int = 1, strip_rows: int = 8,
-                 sampling: str = "split", lib_path: Optional[str] = None, keep_oracle: bool = False, wave_select: bool = False):
+                 sampling: str = "split", lib_path: Optional[str] = None, keep_oracle: bool = False, wave_select: bool = False,
+                 guard_eps: float = 0.0):
         self.settings = settings
         self.lib = load_library(lib_path)
         self.handle = None
@@ -194,7 +199,7 @@ class NeuralRenderer:
                              device_id=device_id, precision=_PREC[precision] if isinstance(precision, str) else int(precision),
                              num_samples=num_samples, threshold=threshold, shard_rank=shard_rank,
                              shard_world=shard_world, strip_rows=strip_rows,
-                             sampling_mode={"split": 0, "fp16x3": 0, "fp32": 1, "fp16": 2}[sampling],
+                             sampling_mode=SAMPLING_MODES[sampling], guard_eps=guard_eps,
                              flags=(FLAG_KEEP_ORACLE if keep_oracle else 0) | (FLAG_WAVE_SELECT if wave_select else 0))
         self.info = Info()
         self.last_stats = Stats()
@@ -328,6 +333,21 @@ class NeuralRenderer:
     def compact(self, oracle, n_rays: int, n_max: int, thr: float, ray_offsets, ray_counts, sample_key, sample_w, total):
         self._check(self.lib.adanerf_compact(self.handle, _ptr(oracle), n_rays, n_max, thr, _ptr(ray_offsets),
                                              _ptr(ray_counts), _ptr(sample_key), _ptr(sample_w), _ptr(total)))
+
+    def compact_guarded(self, oracle_approx, oracle_exact, n_rays: int, n_max: int, thr: float, eps: float, ray_offsets, ray_counts,
+                        sample_key, sample_w, total, refined):
+        self._check(self.lib.adanerf_compact_guarded(self.handle, _ptr(oracle_approx), _ptr(oracle_exact), n_rays, n_max, thr, eps,
+                                                     _ptr(ray_offsets), _ptr(ray_counts), _ptr(sample_key), _ptr(sample_w), _ptr(total),
+                                                     _ptr(refined)))
+
+    def calibrate_guard(self, n_poses: int = 8, seed: int = 1, install: bool = False) -> float:
+        """Largest |plain-fp16 - split-precision| raw output over n_poses x 4096 calibration rays; install=True makes
+        ADANERF_GUARD_CALIB_MARGIN x that the context's guard band."""
+        d = C.c_float(0)
+        self._check(self.lib.adanerf_calibrate_guard(self.handle, n_poses, seed, 1 if install else 0, C.byref(d)))
+        if install:
+            self._check(self.lib.adanerf_get_info(self.handle, C.byref(self.info)))
+        return float(d.value)
 
     def shade_features(self, rays, sample_key, n_samples: int, features_out):
         self._check(self.lib.adanerf_shade_features(self.handle, _ptr(rays), _ptr(sample_key), n_samples, _ptr(features_out)))

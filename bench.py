@@ -143,8 +143,10 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--batch-rays", type=int, default=-1)
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's adaptive sampling threshold")
-    ap.add_argument("--sampling", default="split", choices=["split", "fp32", "fp16"],
-                    help="sampling-MLP arithmetic: split-fp16 (default, fp32-accurate), exact fp32, or the opt-in plain fp16 speed mode")
+    ap.add_argument("--sampling", default="split", choices=["split", "fp32", "fp16", "guarded"],
+                    help="sampling-MLP arithmetic: split-fp16 (fp32-accurate), guarded (plain fp16 + split-fp16 on the rays inside the guard "
+                         "band: the split engine's selections), exact fp32, or the opt-in plain fp16 speed mode")
+    ap.add_argument("--guard-eps", type=float, default=0.0, help="band of --sampling guarded (0: the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-speed-mode", action="store_true", help="skip the extra fp16-sampling measurement reported under speed_mode")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of wall time the CPU baseline may compute (all its cores busy)")
@@ -201,7 +203,7 @@ def main():
     from adanerf_amd import sharding
     strip_rows = sharding.balanced_strip_rows(h, world)
     r = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision, sampling=args.sampling,
-                                   device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=strip_rows)
+                                   guard_eps=args.guard_eps, device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=strip_rows)
     r.init()
     r.set_camera(pose, rot)
     dev = torch.device("cuda", local_rank)
@@ -356,13 +358,39 @@ def main():
         smp_launch = max(st.sample_launches, 1)
         smp_tflops = SAMPLE_FLOP_PER_RAY * (r.info.rays_local * frames / smp_launch) / (st.ms_sample_mlp / smp_launch * 1e-3) / 1e12 \
             if st.ms_sample_mlp > 0 else 0.0
-        # HBM-side view of the two bandwidth-bound stages (algorithmic bytes)
+        # Where the sampling stage sits against the MFMA roofline.  Algorithmic = 898 048 FLOP per ray; executed =
+        # what the engine issues for it: the split engine three f16 MFMAs per term, the guarded mode one per term for every ray
+        # plus three for each re-evaluated ray, the exact engine one on the fp32-MFMA pipe.
         R = r.info.rays_local
-        comp_bytes = R * 512 + R * 8 + samples_per_frame_local * 10 if thr > 0 else R * 512 + samples_per_frame_local * 8
-        cmp_bytes = samples_per_frame_local * 20 + R * 8 + R * 16
-        hbm = {"compact_GBps": comp_bytes / (stage_ms["compact"] * 1e-3) / 1e9 if stage_ms["compact"] > 0 else None,
-               "composite_GBps": cmp_bytes / (stage_ms["composite"] * 1e-3) / 1e9 if stage_ms["composite"] > 0 else None,
-               "peak_GBps": 8000.0}
+        refined = (st.rays_refined / frames) if args.sampling == "guarded" else 0.0
+        exec_mult = {"split": 3.0, "fp16": 1.0, "fp32": 1.0, "guarded": 1.0 + 3.0 * refined / max(R, 1)}[args.sampling]
+        smp_peak = PEAK_TFLOPS["fp32" if args.sampling == "fp32" else "fp16"]
+        smp_ms = st.ms_sample_mlp / frames
+        sampling_roofline = {"bound": "mfma", "stage": "ray generation + encoding + sampling MLP (+ fused selection; guarded: + list + refinement pass)",
+                             "engine": args.sampling, "avg_ms_per_frame": smp_ms, "flop_per_ray": SAMPLE_FLOP_PER_RAY,
+                             "achieved_algorithmic": smp_tflops, "achieved_executed": smp_tflops * exec_mult, "peak": smp_peak, "unit": "TFLOP/s",
+                             "frac_algorithmic": smp_tflops / smp_peak, "frac_executed": smp_tflops * exec_mult / smp_peak,
+                             "rays_refined_per_frame": refined if args.sampling == "guarded" else None}
+        # HBM-side view of the two bandwidth-bound stages: bytes the stage's kernels move by construction
+        S_loc = samples_per_frame_local
+        fused = args.sampling in ("split", "fp16", "guarded") and 0.0 < thr and n_max <= 16 and args.workload != "nerf_coarse_fine"
+        if args.workload == "nerf_coarse_fine":
+            comp_bytes, comp_what = None, "fine sampler (not an HBM-bound stage)"
+        elif thr == 0.0:
+            comp_bytes, comp_what = R * 512 + S_loc * 8 + R * 8, "dense_expand_kernel: oracle values in, keys + weights + offsets + counts out"
+        elif fused:      # selection ran inside the sampling kernel: the stage is expand_kernel alone
+            comp_bytes = R * 4 + S_loc * 5 + R * 4 + S_loc * 8
+            comp_what = "expand_kernel: counts + kept (bin, value) rows in, offsets + keys + weights out"
+        else:            # selection kernel over the [R,128] oracle buffer, then expand_kernel
+            comp_bytes = R * 512 + R * 4 + S_loc * 5 + R * 4 + S_loc * 5 + R * 4 + S_loc * 8
+            comp_what = "selection kernel over the oracle buffer + expand_kernel"
+        cmp_bytes = S_loc * 20 + R * 8 + R * 16
+        comp_gbps = comp_bytes / (stage_ms["compact"] * 1e-3) / 1e9 if comp_bytes and stage_ms["compact"] > 0 else None
+        cmp_gbps = cmp_bytes / (stage_ms["composite"] * 1e-3) / 1e9 if stage_ms["composite"] > 0 else None
+        hbm = {"compact_GBps": comp_gbps, "compact_frac": comp_gbps / 8000.0 if comp_gbps else None, "compact_bytes_per_frame": comp_bytes,
+               "compact_stage": comp_what, "composite_GBps": cmp_gbps, "composite_frac": cmp_gbps / 8000.0 if cmp_gbps else None,
+               "composite_bytes_per_frame": cmp_bytes, "peak_GBps": 8000.0}
+        assert not comp_gbps or comp_gbps < 8000.0, "compact stage above the HBM peak: the byte model is wrong"
 
         cpu = None
         quality = {}
@@ -410,14 +438,16 @@ def main():
                "vs_baseline": None, "dtype": args.precision, "data": data,
                "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, 8x256 shading MLP %s, sampling MLP %s" %
                                       (args.workload, w, h, n_max, thr, args.precision,
-                                       {"split": "split-fp16 (3 MFMAs per term)", "fp32": "fp32 MFMA", "fp16": "plain fp16 (opt-in speed mode)"}[args.sampling]),
+                                       {"split": "split-fp16 (3 MFMAs per term)", "fp32": "fp32 MFMA", "fp16": "plain fp16 (opt-in speed mode)",
+                                        "guarded": "guarded two-precision (plain fp16, split-fp16 on the rays inside the band)"}[args.sampling]),
                           "parallelism": ("image-strip shard x%d (%d-row strips, round-robin) + %s gather overlapped with the next frame" %
                                           (world, strip_rows, "RCCL" if backend == "nccl" else backend)) if use_dist else "single GPU",
                           "exchange": exchange,
+                          "rays_refined_per_frame": (st.rays_refined / frames) if args.sampling == "guarded" else None,
                           "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame,
                           "camera": ("%d-pose orbit inside the view cell" % args.orbit) if poses else "fixed: view-cell centre, yaw 100 deg"},
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,
-               "sampling_mlp_algorithmic_tflops": smp_tflops, "hbm_stages": hbm, "quality": quality, "speed_mode": speed}
+               "sampling_mlp_algorithmic_tflops": smp_tflops, "sampling_roofline": sampling_roofline, "hbm_stages": hbm, "quality": quality, "speed_mode": speed}
         if shard_samples:
             mean_s = sum(shard_samples) / len(shard_samples)
             rec["shards"] = {"samples_per_frame": shard_samples, "shade_ms_per_frame": shard_shade_ms,

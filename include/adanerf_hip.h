@@ -47,7 +47,9 @@
 extern "C" {
 #endif
 
-#define ADANERF_ABI_VERSION 2   /* 2: adanerf_info.view_cell_size, .num_samples_coarse appended */
+#define ADANERF_ABI_VERSION 3   /* 2: adanerf_info.view_cell_size, .num_samples_coarse appended
+                                   3: ADANERF_SAMPLING_GUARDED, adanerf_options.guard_eps, adanerf_stats.rays_refined
+                                      (both carved out of the reserved words: struct sizes unchanged) */
 
 enum {
   ADANERF_OK = 0,
@@ -62,10 +64,19 @@ enum {
   ADANERF_SAMPLING_SPLIT_FP16 = 0, /* default: x = hi + 2^-11 lo' (two fp16), 3 x v_mfma_f32_32x32x16_f16 per term,
                                       fp32 accumulate; 22-bit operands, measured error <= fp32 sgemm's */
   ADANERF_SAMPLING_FP32 = 1,       /* v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain */
-  ADANERF_SAMPLING_FP16 = 2        /* opt-in speed mode: plain fp16 operands, one MFMA per term, fp32 accumulate -- what the
+  ADANERF_SAMPLING_FP16 = 2,       /* opt-in speed mode: plain fp16 operands, one MFMA per term, fp32 accumulate -- what the
                                       reference viewer's TensorRT engine does (imagegenerator.cpp:155-156).  Raw outputs
                                       are then within ~3e-3 of fp32 and the selected bins differ from the fp32 PyTorch
                                       path on 0.3-1.5 % of rays (tools/probes/sampling_agreement.py); 3x faster. */
+  ADANERF_SAMPLING_GUARDED = 3     /* two-precision selection with the results of ADANERF_SAMPLING_SPLIT_FP16: every ray goes
+                                      through the plain-fp16 engine; a ray whose selection could change under a perturbation
+                                      of guard_eps of its raw outputs (a value within the band around the threshold, the
+                                      N-th / (N+1)-th largest closer than twice the band, a tie, a non-finite value) is
+                                      re-evaluated by the split-precision engine, which overwrites its row.  Selections are
+                                      those of the split engine as long as |fp16 output - split output| <= guard_eps holds
+                                      (adanerf_stats.rays_refined counts the re-evaluated rays).  Applies where the selection
+                                      is fused into the sampling kernel (adaptive sampler, N <= 16, threshold > 0, 8 x 256
+                                      net); everywhere else this mode runs the split-precision engine alone. */
 };
 
 /* sample placement (config.ini rayMarchSampler[1]) */
@@ -109,8 +120,18 @@ typedef struct adanerf_options {
   int32_t strip_rows;       /* rows per strip for round-robin strip sharding; <=0 -> 8 */
   int32_t sampling_mode;    /* ADANERF_SAMPLING_* */
   int32_t flags;            /* ADANERF_FLAG_* (0 = defaults) */
-  int32_t reserved[4];
+  float   guard_eps;        /* ADANERF_SAMPLING_GUARDED: the band, in units of the raw network outputs; <= 0 -> calibrated
+                               for the loaded model at the first frame (adanerf_calibrate_guard) */
+  int32_t reserved[3];
 } adanerf_options;
+
+/* Band of the guarded selection when calibration is impossible (non-finite outputs): about 2x the largest difference between
+ * the plain-fp16 and the split-precision engine measured on the shipped networks (4.7e-3). */
+#define ADANERF_GUARD_EPS_DEFAULT 1.0e-2f
+/* The calibrated band is ADANERF_GUARD_CALIB_MARGIN x the largest difference found on the calibration rays, at least
+ * ADANERF_GUARD_EPS_MIN. */
+#define ADANERF_GUARD_CALIB_MARGIN 2.0f
+#define ADANERF_GUARD_EPS_MIN 1.0e-3f
 
 typedef struct adanerf_info {
   int32_t abi_version;
@@ -134,6 +155,7 @@ typedef struct adanerf_info {
   int32_t sampler_mode;     /* ADANERF_SAMPLER_* (from rayMarchSampler[1]) */
   float   view_cell_size[3];/* dataset_info.txt view_cell_size (the viewer's camera speed: max(size / 2), camera.cpp:47) */
   int32_t num_samples_coarse; /* ADANERF_SAMPLER_COARSE_FINE: Nc (num_samples is then Nc + Nf); else 0 */
+  float   guard_eps;          /* ADANERF_SAMPLING_GUARDED: the band in use (0 until it has been calibrated) */
 } adanerf_info;
 
 /* per-frame statistics: the fields the reference logs every 100 frames
@@ -151,7 +173,13 @@ typedef struct adanerf_stats {
   int32_t sample_launches;    /* kernel launches behind ms_sample_mlp */
   int32_t sampling_overflow;  /* rays (since create) whose oracle values were non-finite: an activation left the
                                  fp16 range of the split-precision engine -> use ADANERF_SAMPLING_FP32 */
-  int32_t reserved[5];
+  int32_t rays_refined;       /* ADANERF_SAMPLING_GUARDED: rays re-evaluated by the split-precision engine, summed like
+                                 total_samples */
+  float   guard_max_seen;     /* ... largest |fp16 - split| seen since create on the re-evaluated rays' top value (the
+                                 assumption behind the band, sampled on every frame) */
+  int32_t guard_violations;   /* ... re-evaluated rays (since create) where that difference exceeded the band: if this is
+                                 not 0 the band is too narrow for this model -- raise guard_eps or use SPLIT_FP16 */
+  int32_t reserved[2];
 } adanerf_stats;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
@@ -235,6 +263,23 @@ int adanerf_sample_mlp(adanerf_ctx* ctx, int32_t first_ray, int32_t n_rays,
 int adanerf_compact(adanerf_ctx* ctx, const float* d_oracle, int32_t n_rays, int32_t n_max, float thr,
                     int32_t* d_ray_offsets, int32_t* d_ray_counts, uint32_t* d_sample_key,
                     float* d_sample_w, int32_t* d_total);
+
+/* The guarded two-precision selection (ADANERF_SAMPLING_GUARDED) on caller-provided values, for tests: selects from
+ * d_oracle_approx [n_rays,128] with the guard band eps, then re-selects the undecided rays from d_oracle_exact [n_rays,128],
+ * then compacts.  If |approx - exact| <= eps everywhere the outputs equal adanerf_compact(d_oracle_exact, ...) except that
+ * d_sample_w holds the approximate values on the rays that were not re-selected.  d_refined [1] int32: how many were.
+ * n_max <= 16, thr > 0. */
+int adanerf_compact_guarded(adanerf_ctx* ctx, const float* d_oracle_approx, const float* d_oracle_exact, int32_t n_rays,
+                            int32_t n_max, float thr, float eps, int32_t* d_ray_offsets, int32_t* d_ray_counts,
+                            uint32_t* d_sample_key, float* d_sample_w, int32_t* d_total, int32_t* d_refined);
+
+/* Calibrates the band of ADANERF_SAMPLING_GUARDED for the loaded model: n_poses cameras drawn inside the view cell
+ * (positions uniform in 90 % of it, any orientation; seeded), 64 x 64 rays covering the field of view each, through both the
+ * plain-fp16 and the split-precision sampling network; *max_diff = the largest |difference| over all raw outputs.
+ * set != 0 also installs max(ADANERF_GUARD_CALIB_MARGIN * max_diff, ADANERF_GUARD_EPS_MIN) as the context's band (what a
+ * context created with guard_eps <= 0 does by itself before its first guarded frame, with 8 poses and seed 1).
+ * Synchronous.  8 x 256 sampling networks only. */
+int adanerf_calibrate_guard(adanerf_ctx* ctx, int32_t n_poses, uint32_t seed, int32_t set, float* max_diff);
 
 /* Explicit shading-net input features [n_samples, n_in1] fp32 = [PE(x^) | PE(dir)] (parity/debug;
  * the render path never materialises them). */

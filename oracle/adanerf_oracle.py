@@ -626,6 +626,35 @@ def select_adaptive(orc: np.ndarray, n_max: int, thr: float):
     return count, bins, wts.astype(F32)
 
 
+def guard_undecided(y: np.ndarray, n_max: int, thr: float, eps: float, transform: str = "none") -> np.ndarray:
+    """Guard band of the two-precision selection (no reference counterpart: the build's own ADANERF_SAMPLING_GUARDED,
+    adanerf_amd/csrc/k_select_pair.hip.hpp pair_select; restated here so the CPU suite can check the rule itself).
+    ``y`` [R,128]: the sampler's transformed values computed by the cheaper engine, whose RAW outputs are within ``eps``
+    of the exact engine's.  Returns a bool [R]: False only where select_adaptive(x) == select_adaptive(y) for EVERY x
+    with |x - y| <= e (e = eps carried through the transform).  Rule: undecided iff one of the n_max largest values lies
+    within e of thr, or more values reach u = max(v_n - 2e, thr - e) (arg-max fallback: v_1 - 2e) than reach the cut
+    value, or there is a tie at the cut / a non-finite value."""
+    y = y.astype(F32)
+    srt = -np.sort(-y, axis=1)
+    c0 = srt[:, 0]
+    if transform == "softmax":
+        e = (F32(1.01) * F32(np.expm1(2.0 * eps)) * c0).astype(F32)
+    else:
+        e = np.full(len(y), F32(0.25 * eps if transform == "sigmoid" else eps), dtype=F32)
+    top = srt[:, :n_max]
+    tn = top[:, n_max - 1]
+    none = c0 < F32(thr)
+    t = np.where(none, c0, np.maximum(tn, F32(thr)))
+    n_eff = np.where(none, 1, n_max)
+    total = (y >= t[:, None]).sum(axis=1)
+    und = total > n_eff
+    und |= (np.abs(top - F32(thr)) <= e[:, None]).any(axis=1)
+    u = np.where(none, c0 - F32(2) * e, np.maximum(tn - F32(2) * e, F32(thr) - e))
+    und |= (y >= u[:, None]).sum(axis=1) != total
+    und |= ~np.isfinite(y).all(axis=1)
+    return und
+
+
 def compact(count: np.ndarray, bins: np.ndarray, wts: np.ndarray):
     """Ray-major, depth-ascending flat order == ``embedded[mapping]`` order of
     src/features.py:438-446, 481-484.  Returns (ray_offset [R] int32 exclusive prefix,

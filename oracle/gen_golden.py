@@ -371,9 +371,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--timing", action="store_true")
     ap.add_argument("--only", default=None, help="comma-separated case names: write only these fixtures")
+    ap.add_argument("--out", default=None, help="write into this directory instead of tests/golden (tests/test_golden_regen.py)")
     args = ap.parse_args()
-    global ONLY
+    global ONLY, GOLD
     ONLY = set(args.only.split(",")) if args.only else None
+    if args.out:
+        GOLD = os.path.abspath(args.out)
     os.makedirs(GOLD, exist_ok=True)
     R = import_reference()
     torch = R.torch

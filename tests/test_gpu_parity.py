@@ -520,6 +520,147 @@ def test_fused_selection_equals_separate_launches(cases, name, w, h, bs, samplin
             assert np.array_equal(a, b)
 
 
+# ---------------------------------------------------------------------------------------------
+# A3 + A4, guarded two-precision selection (ADANERF_SAMPLING_GUARDED)
+# ---------------------------------------------------------------------------------------------
+
+def _gpu_compact_guarded(r, approx, exact, n_max, thr, eps):
+    n = approx.shape[0]
+    d_a, d_e = r.to_device(approx), r.to_device(exact)
+    off, cnt = r.empty((n,), np.int32), r.empty((n,), np.int32)
+    key, w = r.empty((n * n_max,), np.uint32), r.empty((n * n_max,), np.float32)
+    tot, ref = r.empty((1,), np.int32), r.empty((1,), np.int32)
+    r.compact_guarded(d_a, d_e, n, n_max, thr, eps, off, cnt, key, w, tot, ref)
+    t = int(tot.numpy()[0])
+    return off.numpy(), cnt.numpy(), key.numpy()[:t], w.numpy()[:t], t, int(ref.numpy()[0])
+
+
+@pytest.mark.parametrize("n_max,thr", [(8, 0.2), (4, 0.15), (16, 0.15), (1, 0.3), (7, 0.05)])
+def test_compact_guarded_reproduces_the_exact_selection(cases, n_max, thr):
+    """Stage-level check of the guard band on values the test controls: `approx` differs from `exact` by less than eps
+    everywhere (random and adversarial directions, a population sitting right at the threshold, ties, NaN / inf rows, a
+    ragged tail).  The two-pass result must be the selection of `exact` bit for bit -- counts, offsets, keys -- with the
+    exact values on the re-selected rays and the approximate ones elsewhere, and the number of re-selected rays must be
+    what the rule (oracle.guard_undecided) says."""
+    rng = np.random.default_rng(n_max * 100 + 7)
+    R, eps = 20011, 0.01
+    exact = (rng.standard_normal((R, 128)) * 0.05).astype(np.float32)
+    for i in range(R):
+        k = rng.integers(0, 20)
+        exact[i, rng.integers(0, 128, k)] = rng.uniform(0, 1.2, k)
+        if i % 4 == 0:
+            exact[i, rng.integers(0, 128, 3)] = thr + rng.uniform(-0.03, 0.03, 3)
+        if i % 97 == 0:
+            exact[i, rng.integers(0, 128, 2)] = exact[i].max()      # tie at the top
+    exact[11, 5], exact[12, 7], exact[13, :] = np.nan, np.inf, np.nan
+    d = rng.uniform(-1, 1, exact.shape).astype(np.float32)
+    d[::3] = np.sign(thr - exact[::3])                               # every third row: straight at the threshold
+    approx = (exact + np.float32(eps * 0.999) * d).astype(np.float32)
+    approx[np.isnan(exact)] = np.nan
+    z, meta, sc, wts, dpath = cases["classroom_n8_thr02"]
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(dpath, 16, 16), precision="bf16") as r:
+        off, cnt, key, w, tot, refined = _gpu_compact_guarded(r, approx, exact, n_max, thr, eps)
+    with np.errstate(invalid="ignore"):
+        e_cnt, e_bins, e_w = O.select_adaptive(np.where(np.isnan(exact), -np.inf, exact), n_max, thr)
+        und = O.guard_undecided(approx, n_max, thr, eps)
+    e_cnt[13] = 1                                                    # all-NaN row: bin 0 (as select_kernel)
+    e_off, e_ray, e_bin, _ = O.compact(e_cnt, e_bins, e_w)
+    ok = np.ones(R, bool)
+    ok[[11, 13]] = False                                             # NaN rows: implementation-defined values, counts only
+    assert np.array_equal(cnt[ok], e_cnt[ok]) and cnt[13] == 1
+    assert tot == int(cnt.sum()) and np.array_equal(off, np.concatenate([[0], np.cumsum(cnt)[:-1]]))
+    ray = (key >> 7).astype(np.int64)
+    sel = ok[ray]
+    exp_key = (e_ray.astype(np.uint32) << 7) | e_bin.astype(np.uint32)
+    assert np.array_equal(key[sel], exp_key[ok[e_ray]])
+    # kept values: the exact engine's on re-selected rays, the approximate engine's elsewhere
+    exp_w = np.where(und[ray], exact[ray, key & 127], approx[ray, key & 127])
+    assert np.array_equal(w[sel], exp_w[sel])
+    assert refined == int(und.sum()), (refined, int(und.sum()))
+    record("compact_guarded", n_max=n_max, thr=thr, eps=eps, rays=R, refined=refined)
+
+
+@pytest.mark.parametrize("name,w,h,bs", [("classroom_n8_thr02", 200, 160, -1), ("classroom_n8_thr02", 97, 61, 1000),
+                                         ("classroom_n16_thr015", 160, 120, -1), ("barbershop_n4_thr015", 131, 77, 4096),
+                                         ("ndc_synthetic_n8", 192, 108, -1), ("synthetic_fixed8", 64, 64, 37)])
+def test_guarded_sampling_reproduces_the_split_engine(cases, name, w, h, bs):
+    """The guarded mode (plain fp16 for every ray, split precision for the rays inside the band) must select exactly what
+    the split-precision engine selects: counts, offsets and keys bit for bit.  With the band opened to 1.0 every ray is
+    re-evaluated and the whole frame is the split engine's bit for bit; the kept oracle values of the other rays come
+    from the fp16 engine and stay within the band."""
+    z, meta, sc, wts, d = cases[name]
+
+    def run(**kw):
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=bs), precision="bf16", **kw) as r:
+            r.set_camera(z["pose"], z["rot"])
+            rgb, rgba, st = r.render_numpy()
+            nb = r.info.batch_rays
+            last = (w * h) - ((w * h - 1) // nb) * nb
+            cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (last,))
+            off = r.buffer(R.BUF_RAY_OFFSETS, np.int32, (last,))
+            tot = int(r.buffer(R.BUF_TOTAL, np.int32, (1,))[0])
+            key = r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (tot,))
+            sw = r.buffer(R.BUF_SAMPLE_W, np.float32, (tot,))
+            assert st.sampling_overflow == 0
+            r.lib.adanerf_get_info(r.handle, r.info)
+            return dict(rgb=rgb, rgba=rgba, total=int(st.total_samples), cnt=cnt, off=off, tot=tot, key=key, sw=sw, refined=int(st.rays_refined),
+                        eps=float(r.info.guard_eps), seen=float(st.guard_max_seen), viol=int(st.guard_violations))
+
+    split = run(sampling="split")
+    guard = run(sampling="guarded")                 # band calibrated for the model at the first frame
+    wide = run(sampling="guarded", guard_eps=1.0)
+    meta_keys = ("refined", "eps", "seen", "viol")
+    for k in ("total", "cnt", "off", "tot", "key"):
+        assert np.array_equal(split[k], guard[k]), k
+    for k in split:
+        if k not in meta_keys:
+            assert np.array_equal(split[k], wide[k]), k
+    assert wide["refined"] == w * h and split["refined"] == 0 and wide["eps"] == 1.0
+    assert 0 < guard["refined"] < w * h
+    # the calibrated band: 2x the largest engine difference on the calibration rays; what the monitor saw on this frame's
+    # re-evaluated rays and what the kept values of the other rays show must lie inside it
+    assert 1e-3 <= guard["eps"] <= 2e-2, guard["eps"]
+    assert guard["viol"] == 0 and 0.0 < guard["seen"] <= guard["eps"]
+    sw_diff = float(np.abs(guard["sw"] - split["sw"]).max())
+    assert sw_diff <= guard["eps"]
+    p = O.psnr(guard["rgb"], split["rgb"])
+    record("guarded_vs_split", case=name, w=w, h=h, refined_frac=guard["refined"] / (w * h), psnr_db=p, max_sw_diff=sw_diff,
+           eps=guard["eps"], monitor_max_seen=guard["seen"])
+    assert p > 60.0
+
+
+def test_guard_calibration(cases):
+    """adanerf_calibrate_guard: seeded, repeatable, and 2x its result becomes the band.  The calibration rays are not this
+    frame's rays, so the frame's own largest engine difference (measured here through the stage API) is an independent
+    check that the margin holds."""
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    w, h = 200, 160
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded") as r:
+        r.set_camera(z["pose"], z["rot"])
+        assert r.info.guard_eps == 0.0                      # not calibrated yet
+        a = r.calibrate_guard(8, 1)
+        b = r.calibrate_guard(8, 1)
+        c = r.calibrate_guard(4, 7)
+        assert a == b and 1e-4 < a < 1e-2 and 1e-4 < c < 1e-2
+        r.calibrate_guard(8, 1, install=True)
+        assert abs(r.info.guard_eps - max(2.0 * a, 1e-3)) < 1e-9
+        rgb, rgba, st = r.render_numpy()                    # the camera set before the calibration is still in place
+        eps = r.info.guard_eps
+    diffs = {}
+    for smp in ("split", "fp16"):
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling=smp) as r:
+            r.set_camera(z["pose"], z["rot"])
+            buf = r.empty((w * h, 128), np.float32)
+            r.sample_mlp(0, w * h, buf, None)
+            diffs[smp] = buf.numpy()
+            if smp == "split":
+                rgb_s = r.render_numpy()[0]
+    frame_max = float(np.abs(diffs["split"] - diffs["fp16"]).max())
+    record("guard_calibration", calibrated_max=a, eps=eps, frame_max_diff=frame_max)
+    assert frame_max <= eps
+    assert O.psnr(rgb, rgb_s) > 60.0
+
+
 def test_render_is_deterministic(cases):
     z, meta, sc, wts, d = cases["classroom_n8_thr02"]
     with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, 200, 160), precision="bf16") as r:
