@@ -57,7 +57,8 @@ struct adanerf_ctx {
   int fp0 = 10, fd0 = 4, fp1 = 10, fd1 = 4;
   int ray_samples = 0;            // raySampleInput[0]
   NetTopology topo0, topo1;       // read off the ONNX initializers
-  bool generic0 = false, generic1 = false;   // not the 8 x 256 (/ skip 4) topology: the run-time-shaped fp32 kernels (k_generic_f32.hip.hpp)
+  bool generic0 = false, generic1 = false;   // not the 8 x 256 (/ skip 4) topology or not a 10-4 (2-2) encoding: the run-time-shaped fp32 kernels (k_generic_f32.hip.hpp)
+  int enc0 = kEnc10_4, enc1 = kEnc10_4;      // slot layout of the two networks' encodings (launch_f32.hpp)
   GenericTopo gen0{}, gen1{};
   DevBuf rsi_z;                   // [ray_samples] world depths of the raySampleInput points
   int shade_gen_grid = 0;
@@ -96,6 +97,8 @@ struct adanerf_ctx {
   int device = 0;                 // HIP device ordinal this context lives on
   float* aux_depth = nullptr;        // adanerf_set_aux_outputs: caller-owned [rays_local] buffers filled by adanerf_render
   float* aux_acc = nullptr;
+  float* aux_disp = nullptr;         // adanerf_set_disp_output
+  DevBuf disp_scratch;               // [2, batch] depth / accumulation of the batch when the caller asked for disparity only
   hipEvent_t peer_event = nullptr;   // adanerf_gather_to: orders the destination stream behind the copy
   uint64_t peer_tried = 0;           // bit d: peer access to device d has been requested once
 };
@@ -172,6 +175,20 @@ struct ModelSetup {
   bool normalize0 = false;
 };
 
+// slot layout of an encoding pair: the specialised kernels exist for 10-4 (both networks) and 2-2 (sampling network); any other
+// pair is packed into the catch-all kMaxBands layout and runs on the run-time-shaped fp32 kernels
+int enc_layout(int fp, int fd, bool sampling) {
+  if (fp == 10 && fd == 4) return kEnc10_4;
+  if (sampling && fp == 2 && fd == 2) return kEnc2_2;
+  return kEncMax;
+}
+NetShape shape_of(int fp0, int fd0, int fp1, int fd1, int ray_samples, bool net0_is_sampling = true) {
+  NetShape sh{fp0, fd0, fp1, fd1, ray_samples};
+  if (enc_layout(fp0, fd0, net0_is_sampling) == kEncMax) sh.lp0 = sh.ld0 = kMaxBands;
+  if (enc_layout(fp1, fd1, false) == kEncMax) sh.lp1 = sh.ld1 = kMaxBands;
+  return sh;
+}
+
 Elem elem_of(int prec) {
   return prec == ADANERF_PREC_BF16 ? Elem::BF16 : (prec == ADANERF_PREC_FP16 ? Elem::F16 : (prec == 3 ? Elem::F16_SPLIT : Elem::F32));
 }
@@ -208,7 +225,6 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
     // RayMarchFromPoses without an oracle in front draws its depths from rayMarchSampler[0] (src/features.py:431-436)
     if (cf.rayMarchSampler.empty() || cf.rayMarchSampler[0] != "LinearlySpacedZNearZFar")
       return bad(ADANERF_EUNSUPPORTED, "coarse/fine: rayMarchSampler[0] must be LinearlySpacedZNearZFar");
-    if (cf.useNDC) return bad(ADANERF_EUNSUPPORTED, "coarse/fine: useNDC is not supported");
     if (cf.numRaymarchSamples.size() != 2) return bad(ADANERF_EIO, "coarse/fine: numRaymarchSamples must be [Nc, Nf]");
   } else if (cf.rayMarchSampler.size() != 2 || (!pdf_mode && !contains(cf.rayMarchSampler[1], "FromClassifiedDepthAdaptive")))
     return bad(ADANERF_EUNSUPPORTED, "rayMarchSampler[1] must be FromClassifiedDepthAdaptive[NoDepthRange] or FromClassifiedDepth");
@@ -231,10 +247,11 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   ms->fd0 = static_cast<int>(cf.posEncArgs[0][1]);
   ms->fp1 = static_cast<int>(cf.posEncArgs[1][0]);
   ms->fd1 = static_cast<int>(cf.posEncArgs[1][1]);
-  if (coarse_fine && (ms->fp0 != 10 || ms->fd0 != 4)) return bad(ADANERF_EUNSUPPORTED, "coarse/fine: posEncArgs[0] must be 10-4");
-  if (!((ms->fp0 == 10 && ms->fd0 == 4) || (ms->fp0 == 2 && ms->fd0 == 2)))
-    return bad(ADANERF_EUNSUPPORTED, "posEncArgs[0] must be 10-4 or 2-2");
-  if (ms->fp1 != 10 || ms->fd1 != 4) return bad(ADANERF_EUNSUPPORTED, "posEncArgs[1] must be 10-4");
+  // any F_pos-F_dir the reference's "nerf" encoding accepts (src/util/feature_encoding.py:54-73; viewer config.cpp:142-146) up to
+  // kMaxBands bands: 10-4 (both nets) and 2-2 (sampling net) run on the specialised kernels, every other pair on the
+  // run-time-shaped fp32 kernels with the catch-all slot layout
+  for (int f : {ms->fp0, ms->fd0, ms->fp1, ms->fd1})
+    if (f < 0 || f > kMaxBands) return bad(ADANERF_EUNSUPPORTED, "posEncArgs: 0.." + std::to_string(kMaxBands) + " frequency bands are supported");
   const bool ndc = cf.useNDC;
   const bool no_range = !coarse_fine && contains(cf.rayMarchSampler[1], "NoDepthRange");
   if (!pdf_mode && !coarse_fine && ndc != no_range) return bad(ADANERF_EUNSUPPORTED, "useNDC requires the NoDepthRange sampler and vice versa");
@@ -406,7 +423,7 @@ int ensure_net1(adanerf_ctx* c, int prec) {
   if (c->net1[prec].w.p) return ADANERF_OK;
   PackedNet pn;
   std::string err;
-  NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1, c->ray_samples};
+  const NetShape sh = shape_of(c->fp0, c->fd0, c->fp1, c->fd1, c->ray_samples, !c->coarse_fine);
   if (!pack_shading_net(c->net1_host, sh, elem_of(prec), &pn, &err)) return fail(c, ADANERF_EIO, "model1.onnx: " + err);
   return upload_net(c, pn, &c->net1[prec]);
 }
@@ -418,7 +435,7 @@ int ensure_netc(adanerf_ctx* c, int prec) {
   if (c->netc[prec].w.p) return ADANERF_OK;
   PackedNet pn;
   std::string err;
-  NetShape sh{c->fp0, c->fd0, c->fp0, c->fd0, 0};
+  const NetShape sh = shape_of(c->fp0, c->fd0, c->fp0, c->fd0, 0, false);
   if (!pack_shading_net(c->net0_host, sh, elem_of(prec), &pn, &err)) return fail(c, ADANERF_EIO, "model0.onnx: " + err);
   return upload_net(c, pn, &c->netc[prec]);
 }
@@ -514,7 +531,7 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
   const bool full = c->fp0 == 10 && c->fd0 == 4;
   if (c->generic0) {      // any other topology / raySampleInput: run-time-shaped fp32 kernel, whatever sampling_mode asks for
     if (sel) return fail(c, ADANERF_EINVAL, "fused selection is not available on the generic sampling kernel");
-    HIP_TRY(c, launch_sample_mlp_gen(a, c->gen0, full, c->topo0.width, grid.x, c->stream));
+    HIP_TRY(c, launch_sample_mlp_gen(a, c->gen0, c->enc0, c->topo0.width, grid.x, c->stream));
     return ADANERF_OK;
   }
   // Guarded two-precision selection: plain fp16 for every ray, then the split engine on the rays the guard band flagged.
@@ -537,7 +554,7 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
     if (!c->net0_f16.w.p) {
       PackedNet pn;
       std::string err;
-      NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1, c->ray_samples};
+      const NetShape sh = shape_of(c->fp0, c->fd0, c->fp1, c->fd1, c->ray_samples);
       if (!pack_sampling_net(c->net0_host, sh, Elem::F16, &pn, &err)) return fail(c, ADANERF_EIO, "model0.onnx: " + err);
       int rc = upload_net(c, pn, &c->net0_f16);
       if (rc) return rc;
@@ -761,11 +778,11 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
   a.total = d_total;
   a.max_samples = max_samples;
   a.raw_out = d_raw;
-  if (c->fp1 != 10 || c->fd1 != 4) return fail(c, ADANERF_EUNSUPPORTED, "shading net posEncArgs must be 10-4");
   if (generic) {
-    if (!gen_grid) HIP_TRY(c, shade_mlp_gen_grid(c->info.compute_units, topo.width, &gen_grid));
+    const int enc = coarse ? enc_layout(c->fp0, c->fd0, false) : c->enc1;
+    if (!gen_grid) HIP_TRY(c, shade_mlp_gen_grid(c->info.compute_units, enc, topo.width, &gen_grid));
     const int tiles = (max_samples + 127) / 128;
-    HIP_TRY(c, launch_shade_mlp_gen(a, gen, topo.width, std::min(tiles, gen_grid), c->stream));
+    HIP_TRY(c, launch_shade_mlp_gen(a, gen, enc, topo.width, std::min(tiles, gen_grid), c->stream));
   } else if (prec == ADANERF_PREC_FP32) {
     if (!c->shade_grid[2]) HIP_TRY(c, shade_mlp_f32_grid(c->info.compute_units, &c->shade_grid[2]));
     const int tiles = (max_samples + 127) / 128;
@@ -913,20 +930,22 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   if (!read_onnx_initializers(join_path(model_dir, "model0.onnx"), &n0, &err)) return bail(ADANERF_EIO, err);
   if (!read_onnx_initializers(join_path(model_dir, "model1.onnx"), &c->net1_host, &err)) return bail(ADANERF_EIO, err);
   c->ray_samples = ms.ray_samples;
-  NetShape sh{c->fp0, c->fd0, c->fp1, c->fd1, c->ray_samples};
+  const NetShape sh = shape_of(c->fp0, c->fd0, c->fp1, c->fd1, c->ray_samples, !c->coarse_fine);
+  c->enc0 = enc_layout(c->fp0, c->fd0, !c->coarse_fine);
+  c->enc1 = enc_layout(c->fp1, c->fd1, false);
   PackedNet p0, p1;
   PackedNet p0s;
   if (c->coarse_fine) {       // model0.onnx is a NeRF net here (src/models.py:199-277); probe its topology with the fp32 packing
-    NetShape shc{c->fp0, c->fd0, c->fp0, c->fd0, 0};
+    const NetShape shc = shape_of(c->fp0, c->fd0, c->fp0, c->fd0, 0, false);
     if (!pack_shading_net(n0, shc, Elem::F32, &p0, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
     c->topoc = p0.topo;
-    c->genericc = !p0.topo.is_default(true);
+    c->genericc = !p0.topo.is_default(true) || c->enc0 == kEncMax;
     if (!c->genericc && opt->precision != ADANERF_PREC_FP32 && !pack_shading_net(n0, shc, elem_of(opt->precision), &p0, &err))
       return bail(ADANERF_EIO, "model0.onnx: " + err);
   } else {
     if (!pack_sampling_net(n0, sh, Elem::F32, &p0, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
     c->topo0 = p0.topo;
-    c->generic0 = !p0.topo.is_default(false);
+    c->generic0 = !p0.topo.is_default(false) || c->enc0 == kEncMax;
     if (!c->generic0 && !pack_sampling_net(n0, sh, Elem::F16_SPLIT, &p0s, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
   }
   c->sampling_mode = opt->sampling_mode;
@@ -936,7 +955,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     PackedNet probe;
     if (!pack_shading_net(c->net1_host, sh, Elem::F32, &probe, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
     c->topo1 = probe.topo;
-    c->generic1 = !probe.topo.is_default(true);
+    c->generic1 = !probe.topo.is_default(true) || c->enc1 == kEncMax;
     if (c->generic1) c->info.precision = ADANERF_PREC_FP32;      // what actually runs; the caller asked for opt->precision
     if (c->generic1 || opt->precision == ADANERF_PREC_FP32) p1 = std::move(probe);
     else if (!pack_shading_net(c->net1_host, sh, elem_of(opt->precision), &p1, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
@@ -973,6 +992,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
       return bail(ADANERF_EDEVICE, "coarse depth table upload failed");
     c->spc = c->sp;
     c->spc.normalize = ms.normalize0;
+    c->sp.unit_dir = 0;      // the fine pass encodes rays_d as RayMarchFromPoses handed it over: un-normalised under NDC (src/features.py:654-668)
     c->spc.ztab = reinterpret_cast<const float*>(c->ztab_coarse.p);
     c->genc = GenericTopo{c->topoc.depth, c->topoc.skip, 0, 0, nullptr, 0.f};
   } else {
@@ -1023,8 +1043,9 @@ int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precis
   std::string err;
   if (!cfg.load(model_dir, &err)) return fail(nullptr, ADANERF_EIO, err);
   if (cfg.posEncArgs.size() != 2) return fail(nullptr, ADANERF_EIO, "posEncArgs missing");
-  NetShape sh{static_cast<int>(cfg.posEncArgs[0][0]), static_cast<int>(cfg.posEncArgs[0][1]), static_cast<int>(cfg.posEncArgs[1][0]),
-              static_cast<int>(cfg.posEncArgs[1][1]), cfg.raySampleInput.empty() ? 0 : cfg.raySampleInput[0]};
+  const bool cfm = cfg.inFeatures.size() == 2 && cfg.inFeatures[0] == "RayMarchFromPoses" && cfg.inFeatures[1] == "RayMarchFromCoarse";
+  const NetShape sh = shape_of(static_cast<int>(cfg.posEncArgs[0][0]), static_cast<int>(cfg.posEncArgs[0][1]), static_cast<int>(cfg.posEncArgs[1][0]),
+                               static_cast<int>(cfg.posEncArgs[1][1]), cfg.raySampleInput.empty() ? 0 : cfg.raySampleInput[0], !cfm);
   TensorMap tm;
   if (!read_onnx_initializers(join_path(model_dir, net == 0 ? "model0.onnx" : "model1.onnx"), &tm, &err)) return fail(nullptr, ADANERF_EIO, err);
   PackedNet pn;
@@ -1052,7 +1073,7 @@ int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precis
       const size_t i = pn.w_off.size();
       layer_out[4 * i + 0] = static_cast<int32_t>(pn.rsi_w_off);
       layer_out[4 * i + 1] = pn.topo.ray_samples;
-      layer_out[4 * i + 2] = pe_slots(sh.fp0);
+      layer_out[4 * i + 2] = pe_slots(sh.lp0 ? sh.lp0 : sh.fp0);
       layer_out[4 * i + 3] = pn.mtiles[0];
     }
   }
@@ -1073,7 +1094,7 @@ int adanerf_destroy(adanerf_ctx* c) {
                     &c->ztab, &c->rays, &c->oracle, &c->ray_offsets, &c->ray_counts, &c->selbin, &c->selw, &c->block_total,
                     &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw, &c->sample_z, &c->rsi_z,
                     &c->netc[0].w, &c->netc[0].b, &c->netc[1].w, &c->netc[1].b, &c->netc[2].w, &c->netc[2].b, &c->ztab_coarse, &c->raw_coarse, &c->key_coarse,
-                    &c->guard_mask, &c->refine_list, &c->guard_probe};
+                    &c->guard_mask, &c->refine_list, &c->guard_probe, &c->disp_scratch};
   for (DevBuf* b : bufs) dev_free(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -1110,8 +1131,7 @@ int adanerf_ray_features(adanerf_ctx* c, int32_t first_ray, int32_t n_rays, floa
   dim3 grid((n_rays + 255) / 256), block(256);
   const float* rz = reinterpret_cast<const float*>(c->rsi_z.p);
   const float d1 = c->cfg.depthRange[1];
-  if (c->fp0 == 10) hipLaunchKernelGGL((ray_features_kernel<10, 4>), grid, block, 0, c->stream, c->rg, first_ray, n_rays, d_feat, d_rays, c->ray_samples, rz, d1);
-  else hipLaunchKernelGGL((ray_features_kernel<2, 2>), grid, block, 0, c->stream, c->rg, first_ray, n_rays, d_feat, d_rays, c->ray_samples, rz, d1);
+  hipLaunchKernelGGL(ray_features_kernel, grid, block, 0, c->stream, c->rg, first_ray, n_rays, d_feat, d_rays, c->ray_samples, rz, d1, c->fp0, c->fd0);
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;
 }
@@ -1184,7 +1204,7 @@ int adanerf_shade_features(adanerf_ctx* c, const float* d_rays, const uint32_t* 
   a.rays = d_rays;
   a.sample_key = d_key;
   a.max_samples = n_samples;
-  hipLaunchKernelGGL((shade_features_kernel<10, 4>), dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, a, d_feat);
+  hipLaunchKernelGGL(shade_features_kernel, dim3((n_samples + 255) / 256), dim3(256), 0, c->stream, a, d_feat, c->fp1, c->fd1);
   HIP_TRY(c, hipGetLastError());
   return ADANERF_OK;
 }
@@ -1433,9 +1453,18 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     void* rgba_b = d_rgba8 ? static_cast<char*>(d_rgba8) + static_cast<size_t>(first) * 4 : nullptr;
     float* depth_b = c->aux_depth ? c->aux_depth + first : nullptr;
     float* acc_b = c->aux_acc ? c->aux_acc + first : nullptr;
+    if (c->aux_disp && (!depth_b || !acc_b)) {      // disparity needs both maps of the batch
+      if ((rc = dev_alloc(c, &c->disp_scratch, static_cast<size_t>(B) * 2 * sizeof(float)))) return rc;
+      if (!depth_b) depth_b = reinterpret_cast<float*>(c->disp_scratch.p);
+      if (!acc_b) acc_b = reinterpret_cast<float*>(c->disp_scratch.p) + B;
+    }
     if (pdf) rc = launch_composite_classic(c, raw, sz, rays, n, N, rgb_b, rgba_b, depth_b, acc_b);
     else rc = launch_composite(c, raw, sw, off, cnt, n, rgb_b, rgba_b, key, depth_b, acc_b);
     if (rc) return rc;
+    if (c->aux_disp && n > 0) {
+      hipLaunchKernelGGL(disp_map_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, depth_b, acc_b, n, c->aux_disp + first);
+      HIP_TRY(c, hipGetLastError());
+    }
     if (ev) {
       HIP_TRY(c, hipEventRecord(ev[4], c->stream));
       HIP_TRY(c, hipMemcpyAsync(c->pinned_totals[c->events_used / 5], total, 10 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1462,6 +1491,12 @@ int adanerf_set_aux_outputs(adanerf_ctx* c, float* d_depth_map, float* d_acc_map
   if (!c) return ADANERF_EINVAL;
   c->aux_depth = d_depth_map;
   c->aux_acc = d_acc_map;
+  return ADANERF_OK;
+}
+
+int adanerf_set_disp_output(adanerf_ctx* c, float* d_disp_map) {
+  if (!c) return ADANERF_EINVAL;
+  c->aux_disp = d_disp_map;
   return ADANERF_OK;
 }
 

@@ -23,8 +23,10 @@ __global__ __launch_bounds__(256) void camera_rays_kernel(RayGenParams g, int fi
   float nds[3], p[3];
   gen_ray(g, col, row, nds, p);
   float4* r = reinterpret_cast<float4*>(rays_out + static_cast<size_t>(i) * 8);
-  r[0] = make_float4(g.pos[0], g.pos[1], g.pos[2], 0.f);
-  r[1] = make_float4(nds[0], nds[1], nds[2], 0.f);
+  float ro[3] = {g.pos[0], g.pos[1], g.pos[2]}, rd[3] = {nds[0], nds[1], nds[2]};
+  if (g.use_ndc) ndc_ray(g, g.pos, nds, ro, rd);      // src/features.py:429-431: everything downstream works on the NDC ray
+  r[0] = make_float4(ro[0], ro[1], ro[2], 0.f);
+  r[1] = make_float4(rd[0], rd[1], rd[2], 0.f);
 }
 
 // n samples per ray at table depths: key = ray << 7 | k (the shading kernel reads the depth table by k)

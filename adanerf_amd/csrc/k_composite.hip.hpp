@@ -20,6 +20,14 @@ struct AuxOut {
   const float* ztab;
 };
 
+// disp_map of src/nerf_raymarch_common.py:61 / :138: 1 / max(1e-10, depth_map / sum(weights)), from the two maps above
+__global__ __launch_bounds__(256) void disp_map_kernel(const float* __restrict__ depth, const float* __restrict__ acc, int n, float* __restrict__ disp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float q = depth[i] / acc[i];
+  disp[i] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));      // torch.max propagates the NaN of an empty ray (0 / 0); fmaxf would not
+}
+
 // one sample of the front-to-back recurrence (src/nerf_raymarch_common.py:91-144): every product and sum rounds
 // to fp32 where the reference's does; returns the sample's weight
 __device__ __forceinline__ float composite_step(const float4 v, float wv, int mult_mode, float& cr, float& cg, float& cb, float& T) {

@@ -234,8 +234,11 @@ __device__ __forceinline__ void lds_bias_issue(uint32_t byte_addr, BiasRegs& r) 
                : "=&v"(r.b0), "=&v"(r.b1), "=&v"(r.b2), "=&v"(r.b3)
                : "v"(byte_addr));
 }
+// YOUNGER: LDS reads this wave has issued behind the bias reads that need not have returned (LDS returns in order; the
+// counter has 4 bits).  0 drains every fragment prefetch in flight -- what a wave alone on its SIMD should not do per tile.
+template <int YOUNGER = 0>
 __device__ __forceinline__ void lds_bias_take(BiasRegs& r, f32x16* acc) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.b0), "+v"(r.b1), "+v"(r.b2), "+v"(r.b3));
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r.b0), "+v"(r.b1), "+v"(r.b2), "+v"(r.b3) : "n"(YOUNGER > 15 ? 15 : YOUNGER));
   f32x16 a;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -485,26 +488,45 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
                                            f32x16* keepB = nullptr) {
   constexpr int CF = WS::kChunk;
   constexpr int KS = S1 + S2;
+  constexpr int ABL = tune::kAblateShade;
   constexpr int PER = (KS >= 8) ? 1 : (8 + KS - 1) / KS;      // epilogue quads of the previous tile per k-step
+  // LDS reads issued between a bias request and its use: the tile's KS fragment re-fills (none under ablation 2)
+  constexpr int kYounger = (ABL & 2) ? 0 : (tune::kBiasWaitCounted ? KS : 0);
   BiasRegs br;
   f32x16 pA, pB;
-  lds_bias_issue(bias_addr, br);
+  if (!(ABL & 4) && !tune::kBiasPlain) lds_bias_issue(bias_addr, br);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 bias, accA, accB;
-    lds_bias_take(br, &bias);
-    if (m + 1 < MT) lds_bias_issue(bias_addr + (m + 1) * 128, br);
+    if (tune::kSchedGroups) __builtin_amdgcn_sched_barrier(0);      // one scheduling region per tile (the group solver's cost grows fast with the region)
+    if (ABL & 4) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias[r] = 0.f;
+    } else if (tune::kBiasPlain) {
+      // compiler-visible LDS loads: hipcc counts them in its own lgkmcnt ladder (no full drain in front of a tile) and is
+      // free to issue them early
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u32x4 t = lds_read128(bias_addr + m * 128 + 16 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias[4 * g + e] = __builtin_bit_cast(float, t[e]);
+      }
+    } else {
+      if (m == 0) lds_bias_take<0>(br, &bias);              // first tile of the layer: issued just now
+      else lds_bias_take<kYounger>(br, &bias);
+      if (m + 1 < MT) lds_bias_issue(bias_addr + (m + 1) * 128, br);
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int f = (FPOS + m * KS + s) % CF;
-      ws_position<0>(st, f, false);
+      ws_position<ABL>(st, f, false);
       const uint32_t* sa = (s < S1) ? (in1A + 4 * s) : (in2A + 4 * (s - S1));
       const uint32_t* sb = (s < S1) ? (in1B + 4 * s) : (in2B + 4 * (s - S1));
       const u32x4 ba = {sa[0], sa[1], sa[2], sa[3]}, bb = {sb[0], sb[1], sb[2], sb[3]};
       accA = ET::mfma(st.R[f % WS::kRegs], ba, s == 0 ? bias : accA);
       accB = ET::mfma(st.R[f % WS::kRegs], bb, s == 0 ? bias : accB);
-      ws_refill<0>(st, f);
-      if (m > 0 && KEEP_F32_TILE != m - 1) {
+      ws_refill<ABL>(st, f);
+      if (m > 0 && KEEP_F32_TILE != m - 1 && !(ABL & 8)) {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
           const int q = s * PER + k;
@@ -512,12 +534,25 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
           else if (q < 8) epilogue_quad_16<ET, RELU>(pB, m - 1, q - 4, outB);
         }
       }
+      if (tune::kSchedGroups) {
+        // pin the interleave the source describes: per k-step two MFMAs, the fragment re-fill, one epilogue quad (hipcc
+        // otherwise bunches a tile's re-fills and the previous tile's whole epilogue behind the first MFMAs of the tile)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // VALU
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // VALU
+      }
     }
     if (KEEP_F32_TILE == m) {
       *keepA = accA;
       *keepB = accB;
     }
-    if (m + 1 < MT) {
+    if ((ABL & 8) && KEEP_F32_TILE != m) {
+      asm volatile("" ::"v"(accA), "v"(accB));
+#pragma unroll
+      for (int g = 0; g < 8; ++g) asm volatile("" : "=v"(outA[8 * m + g]), "=v"(outB[8 * m + g]));
+    } else if (m + 1 < MT) {
       pA = accA;
       pB = accB;
     } else if (KEEP_F32_TILE != m) {
@@ -652,13 +687,12 @@ __global__ __launch_bounds__(256) void shade_mlp32_kernel(ShadeArgs a) {
 }
 
 // Debug/parity: explicit shading-net input features in the reference's column order.
-template <int FP, int FD>
-__global__ __launch_bounds__(256) void shade_features_kernel(ShadeArgs a, float* feat) {
+static __global__ __launch_bounds__(256) void shade_features_kernel(ShadeArgs a, float* feat, int FP, int FD) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= a.max_samples) return;
   float x[3], dpe[3];
   load_sample(a, s, a.max_samples, x, dpe);
-  constexpr int NP = 3 + 6 * FP, ND = 3 + 6 * FD;
+  const int NP = 3 + 6 * FP, ND = 3 + 6 * FD;
   float* f = feat + static_cast<size_t>(s) * (NP + ND);
   for (int c = 0; c < 3; ++c) {
     f[c] = x[c];

@@ -119,9 +119,9 @@ __global__ __launch_bounds__(256) void sample_mlp_kernel(SampleArgs a) {
 // Debug/parity: explicit oracle-net input features in the reference's column order.
 // ray_samples > 0 (raySampleInput): A more blocks of 3 + 6 FP columns, the points p + d z_a encoded as the reference does
 // (src/features.py:876-888: encode(x / d1), identity part scaled back by d1).
-template <int FP, int FD>
-__global__ __launch_bounds__(256) void ray_features_kernel(RayGenParams g, int first_ray, int n_rays, float* feat, float* rays_out,
-                                                           int ray_samples, const float* rsi_z, float rsi_d1) {
+// FP / FD: bands of the position / direction encoding (run-time: any posEncArgs[0]).
+static __global__ __launch_bounds__(256) void ray_features_kernel(RayGenParams g, int first_ray, int n_rays, float* feat, float* rays_out,
+                                                           int ray_samples, const float* rsi_z, float rsi_d1, int FP, int FD) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rays) return;
   int col, row;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void ray_features_kernel(RayGenParams g, int f
   gen_ray(g, col, row, nds, p);
   unit3(nds, u);
   if (feat) {
-    constexpr int ND = 3 + 6 * FD, NP = 3 + 6 * FP;
+    const int ND = 3 + 6 * FD, NP = 3 + 6 * FP;
     float* f = feat + static_cast<size_t>(i) * (ND + NP + ray_samples * NP);
     for (int a = 0; a < ray_samples; ++a) {
       float* fa = f + ND + NP + a * NP;

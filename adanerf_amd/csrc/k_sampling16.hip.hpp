@@ -70,6 +70,7 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 acc, cross;
+    if (tune::kSchedGroupsSampling) __builtin_amdgcn_sched_barrier(0);      // one scheduling region per tile
     if (tune::kAblateSample & 4) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -98,6 +99,17 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
           const int pi = s * PER + k;
           if (pi < 8) epilogue_pair_16x3<LAST>(pacc, pcross, m - 1, pi, out_hi, out_lo, out_f32);
         }
+      }
+      if (tune::kSchedGroupsSampling) {
+        // pin the k-step's interleave: three MFMAs, two fragment re-fills, the VALU of one epilogue pair spread between them
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, tune::kSgbValuSampling, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, tune::kSgbValuSampling, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, tune::kSgbValuSampling, 0);
       }
     }
     if ((tune::kAblateSample & 8) && !LAST) {

@@ -27,35 +27,42 @@ hipError_t launch_shade_mlp_f32(const ShadeArgs& a, int grid, hipStream_t stream
 }
 
 
-hipError_t launch_sample_mlp_gen(const SampleArgs& a, const GenericTopo& t, bool full, int width, unsigned grid, hipStream_t stream) {
-#define ADN_GEN_S(W)                                                                                                   \
-  if (width == W) {                                                                                                    \
-    if (full) hipLaunchKernelGGL((sample_mlp_gen_kernel<10, 4, W>), dim3(grid), dim3(256), 0, stream, a, t);           \
-    else hipLaunchKernelGGL((sample_mlp_gen_kernel<2, 2, W>), dim3(grid), dim3(256), 0, stream, a, t);                 \
-    return hipGetLastError();                                                                                          \
+hipError_t launch_sample_mlp_gen(const SampleArgs& a, const GenericTopo& t, int enc, int width, unsigned grid, hipStream_t stream) {
+#define ADN_GEN_S(W)                                                                                                             \
+  if (width == W) {                                                                                                              \
+    if (enc == kEnc10_4) hipLaunchKernelGGL((sample_mlp_gen_kernel<10, 4, W>), dim3(grid), dim3(256), 0, stream, a, t);          \
+    else if (enc == kEnc2_2) hipLaunchKernelGGL((sample_mlp_gen_kernel<2, 2, W>), dim3(grid), dim3(256), 0, stream, a, t);       \
+    else hipLaunchKernelGGL((sample_mlp_gen_kernel<kMaxBands, kMaxBands, W>), dim3(grid), dim3(256), 0, stream, a, t);           \
+    return hipGetLastError();                                                                                                    \
   }
   ADN_GEN_S(64) ADN_GEN_S(128) ADN_GEN_S(256)
 #undef ADN_GEN_S
   return hipErrorInvalidValue;
 }
 
-hipError_t shade_mlp_gen_grid(int compute_units, int width, int* grid) {
+hipError_t shade_mlp_gen_grid(int compute_units, int enc, int width, int* grid) {
   int per_cu = 0;
   hipError_t e = hipErrorInvalidValue;
-  if (width == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shade_mlp32_gen_kernel<10, 4, 64>, 256, 0);
-  if (width == 128) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shade_mlp32_gen_kernel<10, 4, 128>, 256, 0);
-  if (width == 256) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shade_mlp32_gen_kernel<10, 4, 256>, 256, 0);
+#define ADN_GEN_G(W)                                                                                                             \
+  if (width == W) e = enc == kEnc10_4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shade_mlp32_gen_kernel<10, 4, W>, 256, 0)   \
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shade_mlp32_gen_kernel<kMaxBands, kMaxBands, W>, 256, 0);
+  ADN_GEN_G(64) ADN_GEN_G(128) ADN_GEN_G(256)
+#undef ADN_GEN_G
   if (e != hipSuccess) return e;
   *grid = (per_cu < 1 ? 1 : per_cu) * compute_units;
   return hipSuccess;
 }
 
-hipError_t launch_shade_mlp_gen(const ShadeArgs& a, const GenericTopo& t, int width, int grid, hipStream_t stream) {
-  if (width == 64) hipLaunchKernelGGL((shade_mlp32_gen_kernel<10, 4, 64>), dim3(grid), dim3(256), 0, stream, a, t);
-  else if (width == 128) hipLaunchKernelGGL((shade_mlp32_gen_kernel<10, 4, 128>), dim3(grid), dim3(256), 0, stream, a, t);
-  else if (width == 256) hipLaunchKernelGGL((shade_mlp32_gen_kernel<10, 4, 256>), dim3(grid), dim3(256), 0, stream, a, t);
-  else return hipErrorInvalidValue;
-  return hipGetLastError();
+hipError_t launch_shade_mlp_gen(const ShadeArgs& a, const GenericTopo& t, int enc, int width, int grid, hipStream_t stream) {
+#define ADN_GEN_L(W)                                                                                                             \
+  if (width == W) {                                                                                                              \
+    if (enc == kEnc10_4) hipLaunchKernelGGL((shade_mlp32_gen_kernel<10, 4, W>), dim3(grid), dim3(256), 0, stream, a, t);         \
+    else hipLaunchKernelGGL((shade_mlp32_gen_kernel<kMaxBands, kMaxBands, W>), dim3(grid), dim3(256), 0, stream, a, t);          \
+    return hipGetLastError();                                                                                                    \
+  }
+  ADN_GEN_L(64) ADN_GEN_L(128) ADN_GEN_L(256)
+#undef ADN_GEN_L
+  return hipErrorInvalidValue;
 }
 
 }  // namespace adanerf

@@ -18,8 +18,10 @@ hipError_t shade_mlp_f32_grid(int compute_units, int* grid);
 hipError_t launch_shade_mlp_f32(const ShadeArgs& a, int grid, hipStream_t stream);
 
 // Generic-topology kernels (k_generic_f32.hip.hpp): width 64 / 128 / 256, run-time depth / skip / raySampleInput.
-// full: 10-4 oracle encoding (else 2-2).  hipErrorInvalidValue for a width without an instantiation.
-hipError_t launch_sample_mlp_gen(const SampleArgs& a, const GenericTopo& t, bool full, int width, unsigned grid, hipStream_t stream);
-hipError_t shade_mlp_gen_grid(int compute_units, int width, int* grid);
-hipError_t launch_shade_mlp_gen(const ShadeArgs& a, const GenericTopo& t, int width, int grid, hipStream_t stream);
+// enc: slot layout of the positional encodings the network was packed with -- kEnc10_4, kEnc2_2 (sampling nets only) or
+// kEncMax (the catch-all kMaxBands-band layout: any posEncArgs).  hipErrorInvalidValue for a width / layout without an instantiation.
+enum { kEnc10_4 = 0, kEnc2_2 = 1, kEncMax = 2 };
+hipError_t launch_sample_mlp_gen(const SampleArgs& a, const GenericTopo& t, int enc, int width, unsigned grid, hipStream_t stream);
+hipError_t shade_mlp_gen_grid(int compute_units, int enc, int width, int* grid);
+hipError_t launch_shade_mlp_gen(const ShadeArgs& a, const GenericTopo& t, int enc, int width, int grid, hipStream_t stream);
 }  // namespace adanerf

@@ -32,14 +32,19 @@ ADN_HD inline int act_feature(int q, int h) { return 32 * (q >> 4) + 8 * ((q & 1
 ADN_HD constexpr int pe_slots(int F) { return ((3 * F + 2) + 7) & ~7; }
 
 // source column (within the PE block [x, sin(2^0 x), cos(2^0 x), ...], 3-vectors interleaved as
-// src/util/feature_encoding.py:54-73) of slot q for lane-half h; -1 = zero padding
-ADN_HD inline int pe_col(int F, int q, int h) {
-  if (q < 3 * F) {
+// src/util/feature_encoding.py:54-73) of slot q for lane-half h; -1 = zero padding.
+// FL >= F ("layout bands"): the slot layout of an FL-band encoding carrying only F bands -- bands F..FL-1 get no source column
+// (zero weights), the identity slots sit at 3 FL.  The kernels are instantiated for a few layouts ((10,4), (2,2) and the
+// catch-all kMaxBands); any other posEncArgs F <= kMaxBands is packed into the catch-all layout.
+constexpr int kMaxBands = 16;
+ADN_HD inline int pe_col(int F, int q, int h, int FL = 0) {
+  if (FL <= 0) FL = F;
+  if (q < 3 * FL) {
     int b = q / 3, c = q - 3 * b;
-    return 3 + 6 * b + 3 * h + c;
+    return b < F ? 3 + 6 * b + 3 * h + c : -1;
   }
-  if (q == 3 * F) return h ? 2 : 0;      // x | z
-  if (q == 3 * F + 1) return h ? -1 : 1; // y | pad
+  if (q == 3 * FL) return h ? 2 : 0;      // x | z
+  if (q == 3 * FL + 1) return h ? -1 : 1; // y | pad
   return -1;
 }
 

@@ -101,10 +101,11 @@ void init_layer(VLayer* L, int rows_padded, int cols) {
   L->b.assign(rows_padded, 0.f);
 }
 
-void add_pe_slots(VLayer* L, int F, int col_base) {
-  int n = pe_slots(F);
+void add_pe_slots(VLayer* L, int F, int col_base, int FL = 0) {
+  if (FL <= 0) FL = F;
+  int n = pe_slots(FL);
   for (int q = 0; q < n; ++q) {
-    int c0 = pe_col(F, q, 0), c1 = pe_col(F, q, 1);
+    int c0 = pe_col(F, q, 0, FL), c1 = pe_col(F, q, 1, FL);
     L->col_h0.push_back(c0 < 0 ? -1 : col_base + c0);
     L->col_h1.push_back(c1 < 0 ? -1 : col_base + c1);
   }
@@ -177,8 +178,9 @@ bool fail(std::string* err, const std::string& msg) {
 
 // raySampleInput part of the sampling net's first layer: K-major fragments [a][s4][m][lane][4] (fp32 engine only), so the
 // kernel can walk the A extra points in a run-time loop with all MT accumulators live.
-void emit_ray_samples(const VLayer& L, int A, int fp, int col_base, PackedNet* out) {
-  const int QP = pe_slots(fp), MT = L.rows / 32, n_pt = 3 + 6 * fp;
+void emit_ray_samples(const VLayer& L, int A, int fp, int col_base, PackedNet* out, int FL = 0) {
+  if (FL <= 0) FL = fp;
+  const int QP = pe_slots(FL), MT = L.rows / 32, n_pt = 3 + 6 * fp;
   out->rsi_w_off = static_cast<uint32_t>(out->weights.size() / 16);
   const size_t base = out->weights.size();
   out->weights.resize(base + static_cast<size_t>(A) * (QP / 4) * MT * 64 * 16);
@@ -190,7 +192,7 @@ void emit_ray_samples(const VLayer& L, int A, int fp, int col_base, PackedNet* o
           const int row = 32 * m + (lane & 31), h = lane >> 5;
           const size_t frag = ((static_cast<size_t>(a) * (QP / 4) + s4) * MT + m) * 64 + lane;
           for (int e = 0; e < 4; ++e) {
-            const int c = pe_col(fp, 4 * s4 + e, h);
+            const int c = pe_col(fp, 4 * s4 + e, h, FL);
             const float v = c < 0 ? 0.f : L.w[static_cast<size_t>(row) * L.cols + col_base + a * n_pt + c];
             std::memcpy(dst + frag * 16 + 4 * e, &v, 4);
           }
@@ -210,8 +212,8 @@ bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, Pac
   T.width = find(net0, "layers.0.weight", err)->rows();     // exists: depth >= 2
   T.ray_samples = sh.ray_samples;
   if (T.width % 32 != 0 || T.width < 32 || T.width > 512) return fail(err, "sampling net: width " + std::to_string(T.width) + " (multiples of 32 up to 512 supported)");
-  if (!T.is_default(false) && elem != Elem::F32)
-    return fail(err, "sampling net: only the 8 x 256 topology without raySampleInput runs on the 16-bit engines");
+  if ((!T.is_default(false) || sh.lp0 || sh.ld0) && elem != Elem::F32)
+    return fail(err, "sampling net: only the 8 x 256 topology without raySampleInput and with a 10-4 or 2-2 encoding runs on the 16-bit engines");
   for (int i = 0; i < T.depth; ++i) {
     const Tensor* W = find(net0, "layers." + std::to_string(i) + ".weight", err);
     const Tensor* B = find(net0, "layers." + std::to_string(i) + ".bias", err);
@@ -226,13 +228,13 @@ bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, Pac
     init_layer(&L, n_out, k);
     if (!set_rows(&L, 0, W, B, k, err, "layers." + std::to_string(i))) return false;
     if (i == 0) {
-      add_pe_slots(&L, sh.fd0, 0);        // [dir PE | pos PE]  (src/features.py:868-874)
-      add_pe_slots(&L, sh.fp0, n_dir);
+      add_pe_slots(&L, sh.fd0, 0, sh.ld0);        // [dir PE | pos PE]  (src/features.py:868-874)
+      add_pe_slots(&L, sh.fp0, n_dir, sh.lp0);
     } else {
       add_act_slots(&L, T.width, 0);
     }
     emit(L, elem, out);
-    if (i == 0 && sh.ray_samples > 0) emit_ray_samples(L, sh.ray_samples, sh.fp0, n_dir + n_pos, out);
+    if (i == 0 && sh.ray_samples > 0) emit_ray_samples(L, sh.ray_samples, sh.fp0, n_dir + n_pos, out, sh.lp0);
   }
   return true;
 }
@@ -256,8 +258,8 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
       T.skip = i - 1;
     }
   }
-  if (!T.is_default(true) && elem != Elem::F32)
-    return fail(err, "shading net: only the 8 x 256 / skip 4 topology runs on the 16-bit engine");
+  if ((!T.is_default(true) || sh.lp1 || sh.ld1) && elem != Elem::F32)
+    return fail(err, "shading net: only the 8 x 256 / skip 4 topology with the 10-4 encoding runs on the 16-bit engine");
   for (int i = 0; i < T.depth; ++i) {
     const std::string nm = "pts_linears." + std::to_string(i);
     const Tensor* W = find(net1, nm + ".weight", err);
@@ -272,9 +274,9 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
     init_layer(&L, Wd, k);
     if (!set_rows(&L, 0, W, B, k, err, nm)) return false;
     if (i == 0) {
-      add_pe_slots(&L, sh.fp1, 0);
+      add_pe_slots(&L, sh.fp1, 0, sh.lp1);
     } else if (i == T.skip + 1) {          // cat([input_pts, h])  (src/models.py:260-261)
-      add_pe_slots(&L, sh.fp1, 0);
+      add_pe_slots(&L, sh.fp1, 0, sh.lp1);
       add_act_slots(&L, Wd, n_pos);
     } else {
       add_act_slots(&L, Wd, 0);
@@ -310,7 +312,7 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
     init_layer(&L, Wd / 2, Wd + n_dir);
     if (!set_rows(&L, 0, W, B, Wd + n_dir, err, "views_linears.0")) return false;
     add_act_slots(&L, Wd, 0);
-    add_pe_slots(&L, sh.fd1, Wd);
+    add_pe_slots(&L, sh.fd1, Wd, sh.ld1);
     emit(L, elem, out);
   }
   {   // rgb_linear W/2 -> 3 (tile 0 rows 0..2)

@@ -45,6 +45,9 @@ struct NetShape {
   int fp0 = 10, fd0 = 4;   // posEncArgs[0]  (oracle net input encoding)
   int fp1 = 10, fd1 = 4;   // posEncArgs[1]  (shading net input encoding)
   int ray_samples = 0;     // raySampleInput[0]: extra encoded points along the ray in the oracle net's input
+  // layout bands per encoding (layout.hpp pe_col): 0 = the encoding's own band count (kernels instantiated for it), else the
+  // catch-all kMaxBands layout of the run-time-shaped kernels
+  int lp0 = 0, ld0 = 0, lp1 = 0, ld1 = 0;
 };
 
 

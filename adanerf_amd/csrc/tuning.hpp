@@ -99,11 +99,12 @@ constexpr int kSkipPad = 11;
 #endif
 
 // ---- shading kernel with two sample blocks per wave (shade_mlp16x2_kernel, one wave per SIMD) ----------------------------
-// kShadeBlocks: 1 = shade_mlp16_kernel (8 waves x 32 samples), 2 = shade_mlp16x2_kernel (4 waves x 64 samples)
+// kShadeBlocks: 1 = shade_mlp16_kernel (8 waves x 32 samples), 2 = shade_mlp16x2_kernel (4 waves x 64 samples; shipped since
+// round 3: profiles/r03_shade_two_blocks.md)
 #if ADN_OVERRIDABLE && defined(ADN_SHADE_BLOCKS)
 constexpr int kShadeBlocks = ADN_SHADE_BLOCKS;
 #else
-constexpr int kShadeBlocks = 1;
+constexpr int kShadeBlocks = 2;
 #endif
 #if ADN_OVERRIDABLE && defined(ADN_CF2)
 constexpr int kChunkFrags2 = ADN_CF2;
@@ -114,6 +115,33 @@ constexpr int kChunkFrags2 = 16;
 constexpr int kRingSlots2 = ADN_RS2;
 #else
 constexpr int kRingSlots2 = 6;
+#endif
+// counted lgkmcnt wait in front of a tile's bias block instead of a full drain (layer_16x2)
+#if ADN_OVERRIDABLE && defined(ADN_BIASWAIT)
+constexpr bool kBiasWaitCounted = ADN_BIASWAIT != 0;
+#else
+constexpr bool kBiasWaitCounted = false;     // not safe with compiler-scheduled re-fills (the count assumes they were issued): experiment only
+#endif
+// bias blocks through compiler-visible LDS loads / the k-step interleave pinned with sched_group_barrier (layer_16x2)
+#if ADN_OVERRIDABLE && defined(ADN_BIASPLAIN)
+constexpr bool kBiasPlain = ADN_BIASPLAIN != 0;
+#else
+constexpr bool kBiasPlain = false;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_SGB)
+constexpr bool kSchedGroups = ADN_SGB != 0;
+#else
+constexpr bool kSchedGroups = true;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_SGB_S)
+constexpr bool kSchedGroupsSampling = ADN_SGB_S != 0;
+#else
+constexpr bool kSchedGroupsSampling = false;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_SGB_S_VALU)
+constexpr int kSgbValuSampling = ADN_SGB_S_VALU;
+#else
+constexpr int kSgbValuSampling = 5;
 #endif
 #if ADN_OVERRIDABLE && defined(ADN_NR2)
 constexpr int kRegFrags2 = ADN_NR2;

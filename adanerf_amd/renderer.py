@@ -56,7 +56,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_last_error", "adanerf_set_camera",
-           "adanerf_render", "adanerf_set_aux_outputs", "adanerf_assemble_strips", "adanerf_sync", "adanerf_set_stream", "adanerf_set_profiling",
+           "adanerf_render", "adanerf_set_aux_outputs", "adanerf_set_disp_output", "adanerf_assemble_strips", "adanerf_sync", "adanerf_set_stream", "adanerf_set_profiling",
            "adanerf_collect_stats", "adanerf_ray_features", "adanerf_sample_mlp",
            "adanerf_compact", "adanerf_compact_guarded", "adanerf_calibrate_guard", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_shade_mlp_z", "adanerf_sample_pdf", "adanerf_sample_uniform", "adanerf_shade_mlp_coarse", "adanerf_sample_from_coarse",
            "adanerf_composite", "adanerf_composite_classic", "adanerf_copy_result_sampling_network",
@@ -85,6 +85,7 @@ def load_library(path: Optional[str] = None):
     lib.adanerf_render.argtypes = [vp, vp, vp, C.POINTER(Stats)]
     lib.adanerf_assemble_strips.argtypes = [vp, vp, vp]
     lib.adanerf_set_aux_outputs.argtypes = [vp, vp, vp]
+    lib.adanerf_set_disp_output.argtypes = [vp, vp]
     lib.adanerf_sync.argtypes = [vp]
     lib.adanerf_set_stream.argtypes = [vp, vp]
     lib.adanerf_set_profiling.argtypes = [vp, i32]
@@ -270,6 +271,10 @@ class NeuralRenderer:
     def set_aux_outputs(self, depth_map=None, acc_map=None):
         """Subsequent renders also fill [rays_local] fp32 depth_map (sum w z) / acc_map (sum w); None switches them off."""
         self._check(self.lib.adanerf_set_aux_outputs(self.handle, _ptr(depth_map), _ptr(acc_map)))
+
+    def set_disp_output(self, disp_map=None):
+        """Subsequent renders also fill [rays_local] fp32 disp_map = 1 / max(1e-10, depth_map / acc_map); None switches it off."""
+        self._check(self.lib.adanerf_set_disp_output(self.handle, _ptr(disp_map)))
 
     def gather_from(self, dst, src_renderer: "NeuralRenderer", src, nbytes: int):
         """Stream-ordered copy of ``nbytes`` from ``src`` (on ``src_renderer``'s device / stream) into ``dst`` on this

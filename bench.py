@@ -143,9 +143,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--batch-rays", type=int, default=-1)
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's adaptive sampling threshold")
-    ap.add_argument("--sampling", default="split", choices=["split", "fp32", "fp16", "guarded"],
-                    help="sampling-MLP arithmetic: split-fp16 (fp32-accurate), guarded (plain fp16 + split-fp16 on the rays inside the guard "
-                         "band: the split engine's selections), exact fp32, or the opt-in plain fp16 speed mode")
+    ap.add_argument("--sampling", default="guarded", choices=["split", "fp32", "fp16", "guarded"],
+                    help="sampling-MLP arithmetic: guarded (default: plain fp16 + split-fp16 on the rays inside the guard band -- the split "
+                         "engine's selections), split-fp16 (fp32-accurate, every ray), exact fp32, or the opt-in plain fp16 speed mode")
     ap.add_argument("--guard-eps", type=float, default=0.0, help="band of --sampling guarded (0: the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-speed-mode", action="store_true", help="skip the extra fp16-sampling measurement reported under speed_mode")
@@ -291,6 +291,7 @@ def main():
     dt = time.perf_counter() - t0
     st, frames = r.collect_stats()
     r.set_profiling(False)
+    r.lib.adanerf_get_info(r.handle, r.info)      # the guard band is calibrated at the first guarded frame
     exchange = None
     if dist:
         exchange = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
@@ -411,7 +412,7 @@ def main():
         # opt-in speed mode, reported beside the headline (never as it): the same frame with the sampling MLP in plain
         # fp16 (the viewer's TensorRT arithmetic); selection then deviates from the fp32 path on ~1 % of rays
         speed = None
-        if world == 1 and args.sampling == "split" and not args.no_speed_mode:
+        if world == 1 and args.sampling in ("split", "guarded") and not args.no_speed_mode:
             with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision,
                                            sampling="fp16", device_id=local_rank) as r2:
                 r2.set_camera(pose, rot)
@@ -444,6 +445,8 @@ def main():
                                           (world, strip_rows, "RCCL" if backend == "nccl" else backend)) if use_dist else "single GPU",
                           "exchange": exchange,
                           "rays_refined_per_frame": (st.rays_refined / frames) if args.sampling == "guarded" else None,
+                          "guard": ({"eps": float(r.info.guard_eps), "monitor_max_seen": float(st.guard_max_seen),
+                                     "monitor_violations": int(st.guard_violations)} if args.sampling == "guarded" else None),
                           "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame,
                           "camera": ("%d-pose orbit inside the view cell" % args.orbit) if poses else "fixed: view-cell centre, yaw 100 deg"},
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,

@@ -209,11 +209,16 @@ int adanerf_render(adanerf_ctx* ctx, void* d_rgba8_out, float* d_rgb_f32_out, ad
  * adanerf_render also fills
  *   d_depth_map [rays_local] fp32   sum_k w_k z_k, z = world depth of the sample as the sampler placed it (NDC depth for
  *                                   useNDC models).  The reference's NeRFOutputDepth is this value under NDC and
- *                                   depth_transform.from_world(.) of it otherwise (src/features.py:571-577); its disp_map
- *                                   is 1 / max(1e-10, depth_map / acc_map)
+ *                                   depth_transform.from_world(.) of it otherwise (src/features.py:571-577); its disp_map:
+ *                                   adanerf_set_disp_output
  *   d_acc_map   [rays_local] fp32   sum_k w_k (accumulated opacity)
  * with w_k the compositing weight of sample k (after accumulationMult).  Either may be NULL.  Caller-owned buffers. */
 int adanerf_set_aux_outputs(adanerf_ctx* ctx, float* d_depth_map, float* d_acc_map);
+
+/* The third secondary output of the reference's compositing (disp_map, src/nerf_raymarch_common.py:61 and :138):
+ * d_disp_map [rays_local] fp32 = 1 / max(1e-10, depth_map / acc_map), filled by every adanerf_render until reset with NULL
+ * (independent of adanerf_set_aux_outputs; a ray with acc_map == 0 gives NaN exactly as the reference's 0 / 0 does). */
+int adanerf_set_disp_output(adanerf_ctx* ctx, float* d_disp_map);
 
 /* De-interleaves the gathered shard payloads ([shard_world][rays_local_max] uchar4, rank-major)
  * into the full row-major image [h*w] uchar4. */

@@ -789,13 +789,13 @@ def sample_pdf_bins(bins: np.ndarray, weights: np.ndarray, n: int) -> np.ndarray
 
 
 def render_coarse_fine(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: Scene, weights: Weights,
-                       chunk: int = 4096, keep: bool = False):
+                       chunk: int = 4096, keep: bool = False, w: int = 0, h: int = 0):
     """Vanilla NeRF with hierarchical sampling: RayMarchFromPoses over LinearlySpacedZNearZFar depths ->
     net 0 -> nerf_raw2outputs weights -> RayMarchFromCoarse (src/features.py:640-672: pdf over the interval mid-points
     with weights[1:-1], merged and sorted with the coarse depths) -> net 1 -> nerf_raw2outputs.  The reference's own
     RayMarchFromCoarse.postprocess cannot run (it unpacks five of nerf_raw2outputs' six values, src/features.py:688); its
     arithmetic is the nerf_raw2outputs call it makes, which is what is restated (and pinned) here."""
-    assert scene.sampler == "CoarseFine" and not scene.use_ndc
+    assert scene.sampler == "CoarseFine"
     nc, nf = scene.num_samples_coarse, scene.num_samples
     zc1 = coarse_depths(scene)
     acc: Dict[str, list] = {}
@@ -806,20 +806,24 @@ def render_coarse_fine(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, 
         p = np.repeat(pose.astype(F32)[None], r, 0)      # the rays start at the camera (src/features.py:426-428), not on the view-cell sphere
         zc = np.repeat(zc1[None], r, 0)
         sray = np.repeat(np.arange(r, dtype=np.int32), nc)
-        f0 = shading_inputs(p, nds, sray, zc.reshape(-1), sc0)
+        f0 = shading_inputs(p, nds, sray, zc.reshape(-1), sc0, w, h)
         raw0 = shading_mlp(f0, weights.net0, 3 + 6 * scene.pos_enc[0][0])
-        w0 = classic_weights(raw0.reshape(r, nc, 4), zc, nds)
-        rgb0 = composite_classic(raw0.reshape(r, nc, 4), zc, nds)
+        rd = nds
+        if scene.use_ndc:      # src/features.py:429-431: everything downstream sees the NDC ray (un-normalised direction in the distances)
+            p, rd = ndc_rays(h, w, focal_from_fov(w, scene.fov), 1.0, p, nds)
+        w0 = classic_weights(raw0.reshape(r, nc, 4), zc, rd)
+        rgb0 = composite_classic(raw0.reshape(r, nc, 4), zc, rd)
         mid = (F32(0.5) * (zc[:, 1:] + zc[:, :-1])).astype(F32)
         zf = sample_pdf_bins(mid, w0[:, 1:-1], nf)
         za = np.sort(np.concatenate([zc, zf], -1), -1).astype(F32)
         sray = np.repeat(np.arange(r, dtype=np.int32), nc + nf)
-        f1 = shading_inputs(p, nds, sray, za.reshape(-1), scene)
+        p_w = np.repeat(pose.astype(F32)[None], r, 0)
+        f1 = shading_inputs(p_w, nds, sray, za.reshape(-1), scene, w, h, unit_dir=False)
         raw1 = shading_mlp(f1, weights.net1, 3 + 6 * scene.pos_enc[1][0])
-        rgb, dm, am = composite_classic(raw1.reshape(r, nc + nf, 4), za, nds, aux=True)
+        rgb, dm, am = composite_classic(raw1.reshape(r, nc + nf, 4), za, rd, aux=True)
         item = dict(rgb=rgb, depth_map=dm, acc_map=am, count=np.full(r, nc + nf, np.int32))
         if keep:
-            item.update(nds=nds, p=p, z_coarse=zc, raw0=raw0, weights0=w0, rgb_coarse=rgb0, z_fine=zf, z=za.reshape(-1), feat1=f1, raw=raw1)
+            item.update(nds=rd, p=p, z_coarse=zc, raw0=raw0, weights0=w0, rgb_coarse=rgb0, z_fine=zf, z=za.reshape(-1), feat1=f1, raw=raw1)
         for k, v in item.items():
             acc.setdefault(k, []).append(v)
     return {k: np.concatenate(v) for k, v in acc.items()}
@@ -864,7 +868,7 @@ def ndc_rays(h: int, w: int, focal: float, near: float, rays_o: np.ndarray, rays
 
 
 def shading_inputs(p: np.ndarray, nds: np.ndarray, sample_ray: np.ndarray, z: np.ndarray,
-                   scene: Scene, w: int = 0, h: int = 0) -> np.ndarray:
+                   scene: Scene, w: int = 0, h: int = 0, unit_dir: bool = True) -> np.ndarray:
     """src/features.py:420-479: x = o + d*z; normalise; [PE_pos(x^) | PE_dir(dir)].
     ``z`` is the per-sample world depth (to_world_depth of the bin's t)."""
     fp, fd = scene.pos_enc[1]
@@ -872,7 +876,9 @@ def shading_inputs(p: np.ndarray, nds: np.ndarray, sample_ray: np.ndarray, z: np
     dir_pe = nds
     if scene.use_ndc:
         o, d = ndc_rays(h, w, focal_from_fov(w, scene.fov), 1.0, p, nds)
-        dir_pe = (d / np.sqrt(np.sum(d * d, -1, keepdims=True, dtype=F32))).astype(F32)
+        # RayMarchFromPoses encodes the normalised NDC direction (src/features.py:431); RayMarchFromCoarse is handed rays_d and
+        # encodes it as it is (src/features.py:654-668): unit_dir = False
+        dir_pe = (d / np.sqrt(np.sum(d * d, -1, keepdims=True, dtype=F32))).astype(F32) if unit_dir else d
     x = (o[sample_ray] + d[sample_ray] * z[:, None]).astype(F32)
     if scene.normalization == "InverseSqrtDistCentered":
         # src/nerf_raymarch_common.py:226-230
@@ -969,7 +975,7 @@ def render_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: 
     (src/evaluate.py:206-241).  Returns dict with rgb [R,3], count [R] and, when ``keep``,
     every intermediate the golden fixtures hold."""
     if scene.sampler == "CoarseFine":
-        return render_coarse_fine(dirs_cam, pose, rot, scene, weights, min(chunk, 4096), keep)
+        return render_coarse_fine(dirs_cam, pose, rot, scene, weights, min(chunk, 4096), keep, w, h)
     out_rgb = []
     out_cnt = []
     out_depth = []

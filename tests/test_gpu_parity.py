@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import adanerf_oracle as O
-from conftest import CASES, GOLD, PDF_CASES, TRANSFORM_CASES, case_weights, load_case, record
+from conftest import CASES, GOLD, PDF_CASES, TRANSFORM_CASES, case_weights, check_identical, load_case, record, residual_budget
 
 import adanerf_amd
 from adanerf_amd import renderer as R
@@ -109,7 +109,7 @@ def test_sample_mlp_matches_reference(cases, name, sampling):
     if sc.threshold > 0:
         cnt, bins, _ = O.select_adaptive(orc, sc.num_samples, sc.threshold)
         same = (cnt == z["sel_count"]) & (bins == z["sel_bins"]).all(axis=1)
-        assert same.mean() >= 0.995, "rays with identical bin sets: %.4f" % same.mean()
+        check_identical(same, "sample_mlp_selection", 0, case=name, sampling=sampling)      # against the reference's own selection
 
 
 # ---------------------------------------------------------------------------------------------
@@ -264,7 +264,7 @@ def test_compact_applies_the_samplers_transform(transform_cases, name, wave_sele
         off, cnt, key, sw, total = gpu_compact(r, z["oracle_out"], sc.num_samples, sc.threshold)
     e_cnt, e_bins, e_w = z["sel_count"].astype(np.int32), z["sel_bins"], z["sel_weight"]
     same = cnt == e_cnt
-    assert same.mean() >= 0.995, same.mean()            # a value within an ulp of the threshold may fall on the other side
+    check_identical(same, "compact_transform", 0, case=name)      # device expf vs torch: no value of these fixtures sits within an ulp of the threshold
     e_off, e_ray, e_bin, e_sw = O.compact(e_cnt, e_bins, e_w)
     if same.all():
         assert np.array_equal((key & 127).astype(np.int16), e_bin)
@@ -281,7 +281,7 @@ def test_frame_with_transformed_oracle_matches_oracle(transform_cases, name):
             r.set_camera(z["pose"], z["rot"])
             rgb, rgba, st = r.render_numpy()
             cnt, same = same_bin_sets(r, ref, w * h, sc.num_samples)
-        assert same.mean() >= 0.99, (kw, same.mean())
+        check_identical(same, "frame_transformed", residual_budget(w * h), case=name, **kw)
         np.testing.assert_allclose(rgb[same], ref["rgb"][same], rtol=0, atol=3e-4)
     assert 1.5 < st.total_samples / (w * h) < 7.5
 
@@ -444,7 +444,7 @@ def test_frame_fp32_matches_oracle(cases, name):
         rgb, rgba, st = r.render_numpy()
         cnt, same = same_bin_sets(r, ref, w * h, sc.num_samples)
     assert st.total_samples == int(cnt.sum())
-    assert same.mean() >= 0.995, "rays with identical bin sets: %.4f" % same.mean()
+    check_identical(same, "frame_fp32", residual_budget(w * h), case=name)
     np.testing.assert_allclose(rgb[same], ref["rgb"][same], rtol=0, atol=3e-4)
     assert O.psnr(rgb[same], ref["rgb"][same]) > 60.0
 
@@ -462,7 +462,7 @@ def test_frame_low_precision_psnr(cases, name, prec, min_psnr):
         r.set_camera(z["pose"], z["rot"])
         rgb, rgba, st = r.render_numpy()
         cnt, same = same_bin_sets(r, ref, w * h, sc.num_samples)
-    assert same.mean() >= 0.995            # selection runs in exact fp32 regardless of the shading precision
+    check_identical(same, "frame_low_precision", residual_budget(w * h), case=name, prec=prec)      # the selection does not depend on the shading precision
     p = O.psnr(rgb[same], ref["rgb"][same])
     record("frame_low_precision", case=name, prec=prec, psnr_db=p, max_abs=float(np.abs(rgb[same] - ref["rgb"][same]).max()),
            identical_bin_sets=float(same.mean()))
@@ -719,7 +719,7 @@ def test_full_size_frame_properties(cases):
         same = cnt[sl] == ref["count"]
         record("full_size_rows_config2", row=row, identical_counts=float(same.mean()), psnr_db=O.psnr(rgb[sl][same], ref["rgb"][same]),
                max_abs=float(np.abs(rgb[sl][same] - ref["rgb"][same]).max()))
-        assert same.mean() >= 0.999                                   # measured 1.0 on both rows
+        check_identical(same, "full_size_rows_config2", residual_budget(w), row=row)      # measured: no residual ray on either row
         assert O.psnr(rgb[sl][same], ref["rgb"][same]) > 55.0        # measured 60.1 / 62.3 dB
 
 
@@ -808,7 +808,7 @@ def test_ndc_1080p_threshold_sweep_properties(cases):
         sl = slice(row * w, (row + 1) * w)
         same = cnt[sl] == ref["count"]
         record("ndc_1080p_sweep", thr=thr, identical_counts=float(same.mean()), psnr_db=O.psnr(rgb[sl][same], ref["rgb"][same]))
-        assert same.mean() >= 0.999                                   # measured 1.0 at every threshold
+        check_identical(same, "ndc_1080p_sweep", residual_budget(same.size))             # measured: no residual ray at any threshold
         assert O.psnr(rgb[sl][same], ref["rgb"][same]) > 78.0        # measured 83.6 - 88.1 dB (fp16 shading)
 
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import adanerf_oracle as O
-from conftest import ROOT, TOPOLOGY_CASES, case_weights, load_case
+from conftest import ENCODING_CASES, ROOT, TOPOLOGY_CASES, case_weights, load_case
 from mfma_emulation import (PackedNet, pack_weights, run_sampling_net, run_sampling_net_generic, run_shading_net,
                             run_shading_net_generic)
 
@@ -112,7 +112,11 @@ def test_error_codes_and_messages(lib, tmp_path):
     assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == 0 and info.n_in0 == 90 + 128 * 63
     open(os.path.join(d, "config.ini"), "w").write(cfg.replace("raySampleInput = [0, 0]", "raySampleInput = [-3, 0]"))
     assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == -4
-    open(os.path.join(d, "config.ini"), "w").write(cfg.replace("posEncArgs = [10-4, 10-4]", "posEncArgs = [6-3, 10-4]"))
+    # any F_pos-F_dir up to 16 bands parses (the network input widths follow); beyond that: unsupported
+    open(os.path.join(d, "config.ini"), "w").write(cfg.replace("posEncArgs = [10-4, 10-4]", "posEncArgs = [6-3, 12-2]"))
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == 0
+    assert (info.n_in0, info.n_in1) == (3 + 36 + 3 + 18, 3 + 72 + 3 + 12)
+    open(os.path.join(d, "config.ini"), "w").write(cfg.replace("posEncArgs = [10-4, 10-4]", "posEncArgs = [17-3, 10-4]"))
     assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == -4
     assert lib.adanerf_host_parse_model(None, C.byref(o), C.byref(info)) == -1
 
@@ -236,6 +240,44 @@ def test_generic_topologies_pack_and_reproduce_the_reference(lib, tmp_path, name
             assert b"16-bit" in lib.adanerf_last_error(None)
 
 
+@pytest.mark.parametrize("name", ENCODING_CASES)
+def test_other_encodings_pack_into_the_catch_all_layout(lib, tmp_path, name):
+    """SURVEY 8f N4, encodings: posEncArgs other than 10-4 / 2-2 (here 6-3 / 12-2 and the extremes 16-1 / 1-16, fixtures
+    generated by the reference).  Such networks are packed into the 16-band slot layout of the run-time-shaped kernels --
+    the bands the model does not have get zero weights (layout.hpp pe_col) -- and, replayed through the kernels' dataflow
+    in numpy with all 16 bands evaluated as the device does, reproduce the reference's sampling-network outputs and the
+    oracle's shading outputs.  The 16-bit packings refuse them with a message."""
+    z, meta, sc = load_case(name)
+    wts = case_weights(meta)
+    d, _, _ = _model_dir(tmp_path, sc, wts, name=name.replace("-", "_"))
+    lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+    info = R.Info()
+    o = _opts(width=meta["w"], height=meta["h"])
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info)) == 0
+    (fp0, fd0), (fp1, fd1) = sc.pos_enc
+    assert (info.n_in0, info.n_in1) == (6 + 6 * (fp0 + fd0), 6 + 6 * (fp1 + fd1))
+    n = 48
+    nds = z["nds"][:n]
+    u = (nds / np.sqrt(np.sum(nds * nds, -1, keepdims=True))).astype(np.float32)
+    w, b, lay = pack_weights(lib, d, 0, 2)
+    assert int(lay[0, 2]) == 2 * 56                        # layer 0: [dir PE | pos PE] in the 16-band layout (56 slots each)
+    orc = run_sampling_net_generic(PackedNet(w, b, lay, 2), u, z["p"][:n], nds, 16, 16)
+    np.testing.assert_allclose(orc, z["oracle_out"][:n], rtol=0, atol=2e-4)
+    count = z["sel_count"].astype(np.int32)
+    off, sray, sbin, sw = O.compact(count, z["sel_bins"], z["sel_weight"])
+    feat = O.shading_inputs(z["p"], z["nds"], sray[:n], O.to_world_depth(O.bin_t(sbin[:n].astype(np.int64)), sc), sc)
+    np.testing.assert_allclose(feat, z["shade_in"][:n], rtol=0, atol=2e-3 * 2 ** max(fp1 - 10, 0))   # the oracle's features are the reference's
+    ref = O.shading_mlp(feat, wts.net1, n_pos=3 + 6 * fp1)
+    w1, b1, lay1 = pack_weights(lib, d, 1, 2)
+    out = run_shading_net_generic(PackedNet(w1, b1, lay1, 2), feat[:, 0:3], feat[:, 3 + 6 * fp1:6 + 6 * fp1], 8, 256, 4, fp=16, fd=16)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=3e-4)
+    f = lib.adanerf_host_pack_weights
+    wb, bf, nl = C.c_size_t(0), C.c_size_t(0), C.c_int32(0)
+    for net in (0, 1):
+        assert f(d.encode(), net, 0 if net else 3, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl)) != 0
+        assert b"16-bit" in lib.adanerf_last_error(None)
+
+
 def test_product_path_fails_loudly_without_gpu(lib, tmp_path):
     """No CPU fallback: on a box without a HIP device create() must fail with EDEVICE (on the GPU box
     this test is a no-op)."""
@@ -345,6 +387,45 @@ def test_evaluator_dataset_loader(tmp_path):
     assert np.allclose(frames[0]["pose"], [1, 2, 3]) and np.allclose(frames[0]["rot"], np.eye(3))
     assert frames[0]["image"].endswith(os.path.join("test", "00000.png"))
     assert abs(psnr_from_mse(0.01) - 20.0) < 1e-9
+
+
+def test_dataset_reader_matches_the_reference_readers(lib, tmp_path):
+    """SURVEY 8f N1 pinned: tests/golden/dataset_reader.npz holds a tiny dataset directory (file by file) together with what
+    the reference's DatasetInfo / FullyLoadedViewCellDataset (src/datasets.py:146-213, 263-287, 361-365, 479-542) derived
+    from it (oracle/gen_golden.py: gen_dataset_reader).  The evaluator's reader and PNG decoder must derive the same:
+    resolution, field of view, poses, rotations, image paths and the [0, 1] float colour images bit for bit; the focal
+    length is the library's (adanerf_info.focal for that field of view and width)."""
+    from conftest import GOLD
+    from adanerf_amd.evaluate import load_dataset
+    from adanerf_amd.png import read_png
+    z = np.load(os.path.join(GOLD, "dataset_reader.npz"))
+    d = tmp_path / "ds"
+    for k in z.files:
+        if k.startswith("file:"):
+            f = d / k[5:]
+            f.parent.mkdir(parents=True, exist_ok=True)
+            f.write_bytes(z[k].tobytes())
+    meta, frames = load_dataset(str(d), "test")
+    assert (meta["w"], meta["h"]) == (int(z["w"]), int(z["h"])) and meta["fov"] == float(z["fov"])
+    names = bytes(z["image_names"]).decode().split("\n")
+    assert len(frames) == len(names) == z["poses"].shape[0]
+    for i, fr in enumerate(frames):
+        assert os.path.relpath(fr["image"], str(d)) == names[i]
+        assert fr["pose"].dtype == np.float32 and np.array_equal(fr["pose"], z["poses"][i])
+        assert np.array_equal(fr["rot"], z["rotations"][i])
+        img = read_png(fr["image"])
+        mine = img[:, :, :3].astype(np.float32) / np.float32(255.0)          # what evaluate() compares against (datasets.py:286-287)
+        assert np.array_equal(mine, z["color_images"][i])
+    # focal length of that camera as the library derives it (src/datasets.py:182)
+    sc = O.Scene(view_cell_center=tuple(z["view_cell_center"]), view_cell_size=tuple(z["view_cell_size"]),
+                 depth_range=tuple(z["depth_range"]), fov=float(z["fov"]), max_depth=float(z["depth_max"]), num_samples=8, threshold=0.2)
+    md = str(tmp_path / "model")
+    O.write_model_dir(md, sc, O.synthetic_weights(0))
+    info = R.Info()
+    lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+    o = _opts(width=int(z["w"]), height=int(z["h"]))
+    assert lib.adanerf_host_parse_model(md.encode(), C.byref(o), C.byref(info)) == 0
+    assert info.focal == np.float32(z["focal"]) and abs(info.fov - float(z["fov"])) < 1e-7
 
 
 def test_header_is_plain_c_and_links_from_c(lib, tmp_path):
@@ -609,7 +690,7 @@ def test_coarse_fine_model_directory_parses(lib, tmp_path):
         wb, bf, nl = C.c_size_t(0), C.c_size_t(0), C.c_int32(0)
         assert lib.adanerf_host_pack_weights(d.encode(), 1, prec, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl)) == 0
         assert wb.value > 0 and nl.value == 11
-    for key, val, msg in [("rayMarchSampler", "[UnitSphereLinearOutsideLog, none]", "LinearlySpacedZNearZFar"), ("useNDC", "True", "useNDC"),
+    for key, val, msg in [("rayMarchSampler", "[UnitSphereLinearOutsideLog, none]", "LinearlySpacedZNearZFar"),
                           ("numRaymarchSamples", "[2, 8]", "3..128"), ("numRaymarchSamples", "[64, 2000]", "1024")]:
         bad = str(tmp_path / ("cf_bad_" + key + str(len(val))))
         O.write_model_dir(bad, sc, wts)
