@@ -16,6 +16,7 @@
 #include "kernels.hip.hpp"
 #include "launch_f32.hpp"
 #include "k_generic_f32.hip.hpp"   // GenericTopo (the kernels themselves live in launch_f32.hip)
+#include "k_generic16.hip.hpp"     // the 16-bit form of the run-time-shaped shading kernel
 #include "pack.hpp"
 
 using namespace adanerf;
@@ -766,7 +767,6 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
   const NetTopology& topo = coarse ? c->topoc : c->topo1;
   const GenericTopo& gen = coarse ? c->genc : c->gen1;
   int& gen_grid = coarse ? c->shade_gen_grid_c : c->shade_gen_grid;
-  if (generic) prec = ADANERF_PREC_FP32;      // other topologies run on the fp32 engine whatever precision is asked for
   int rc = coarse ? ensure_netc(c, prec) : ensure_net1(c, prec);
   if (rc) return rc;
   ShadeArgs a{};
@@ -778,7 +778,28 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
   a.total = d_total;
   a.max_samples = max_samples;
   a.raw_out = d_raw;
-  if (generic) {
+  if (generic && prec != ADANERF_PREC_FP32) {
+    // any topology / encoding layout on the 16-bit MFMA pipe (k_generic16.hip.hpp): fragments straight from L2
+    const int enc = coarse ? enc_layout(c->fp0, c->fd0, false) : c->enc1;
+    const int tiles = (max_samples + 127) / 128;
+    const int grid = std::min(tiles, 2 * c->info.compute_units);
+#define ADN_GEN16(ET, FPv, FDv, Wv) hipLaunchKernelGGL((shade_mlp16_gen_kernel<ET, FPv, FDv, Wv>), dim3(grid), dim3(256), 0, c->stream, a, gen)
+#define ADN_GEN16_W(ET, FPv, FDv)                                  \
+  do {                                                             \
+    if (topo.width == 64) ADN_GEN16(ET, FPv, FDv, 64);             \
+    else if (topo.width == 128) ADN_GEN16(ET, FPv, FDv, 128);      \
+    else ADN_GEN16(ET, FPv, FDv, 256);                             \
+  } while (0)
+    if (prec == ADANERF_PREC_BF16) {
+      if (enc == kEnc10_4) ADN_GEN16_W(Bf16, 10, 4);
+      else ADN_GEN16_W(Bf16, kMaxBands, kMaxBands);
+    } else {
+      if (enc == kEnc10_4) ADN_GEN16_W(Fp16, 10, 4);
+      else ADN_GEN16_W(Fp16, kMaxBands, kMaxBands);
+    }
+#undef ADN_GEN16_W
+#undef ADN_GEN16
+  } else if (generic) {
     const int enc = coarse ? enc_layout(c->fp0, c->fd0, false) : c->enc1;
     if (!gen_grid) HIP_TRY(c, shade_mlp_gen_grid(c->info.compute_units, enc, topo.width, &gen_grid));
     const int tiles = (max_samples + 127) / 128;
@@ -940,7 +961,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     if (!pack_shading_net(n0, shc, Elem::F32, &p0, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
     c->topoc = p0.topo;
     c->genericc = !p0.topo.is_default(true) || c->enc0 == kEncMax;
-    if (!c->genericc && opt->precision != ADANERF_PREC_FP32 && !pack_shading_net(n0, shc, elem_of(opt->precision), &p0, &err))
+    if (opt->precision != ADANERF_PREC_FP32 && !pack_shading_net(n0, shc, elem_of(opt->precision), &p0, &err))
       return bail(ADANERF_EIO, "model0.onnx: " + err);
   } else {
     if (!pack_sampling_net(n0, sh, Elem::F32, &p0, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
@@ -956,8 +977,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     if (!pack_shading_net(c->net1_host, sh, Elem::F32, &probe, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
     c->topo1 = probe.topo;
     c->generic1 = !probe.topo.is_default(true) || c->enc1 == kEncMax;
-    if (c->generic1) c->info.precision = ADANERF_PREC_FP32;      // what actually runs; the caller asked for opt->precision
-    if (c->generic1 || opt->precision == ADANERF_PREC_FP32) p1 = std::move(probe);
+    if (opt->precision == ADANERF_PREC_FP32) p1 = std::move(probe);
     else if (!pack_shading_net(c->net1_host, sh, elem_of(opt->precision), &p1, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
   }
   // the run-time-shaped fp32 kernels are instantiated for these widths (k_generic_f32.hip.hpp)
@@ -986,7 +1006,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     return bail(ADANERF_EDEVICE, "ztab upload failed");
   c->sp.ztab = reinterpret_cast<const float*>(c->ztab.p);
   if (c->coarse_fine) {
-    if ((rc = upload_net(c, p0, &c->netc[c->genericc ? ADANERF_PREC_FP32 : opt->precision]))) return bail(rc, c->err);
+    if ((rc = upload_net(c, p0, &c->netc[opt->precision]))) return bail(rc, c->err);
     if ((rc = dev_alloc(c, &c->ztab_coarse, kMaxCoarse * sizeof(float)))) return bail(rc, c->err);
     if (hipMemcpy(c->ztab_coarse.p, ms.ztab_coarse.data(), ms.ztab_coarse.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
       return bail(ADANERF_EDEVICE, "coarse depth table upload failed");
@@ -1008,7 +1028,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   c->gen1 = GenericTopo{c->topo1.depth, c->topo1.skip, 0, 0, nullptr, 0.f};
   if ((rc = dev_alloc(c, &c->overflow, 64))) return bail(rc, c->err);
   if (hipMemset(c->overflow.p, 0, 64) != hipSuccess) return bail(ADANERF_EDEVICE, "hipMemset failed");
-  if ((rc = upload_net(c, p1, &c->net1[c->generic1 ? ADANERF_PREC_FP32 : opt->precision]))) return bail(rc, c->err);
+  if ((rc = upload_net(c, p1, &c->net1[opt->precision]))) return bail(rc, c->err);
   if ((rc = ensure_batch_buffers(c, c->info.batch_rays, c->info.num_samples))) return bail(rc, c->err);
   *out = c;
   return ADANERF_OK;

@@ -258,8 +258,6 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
       T.skip = i - 1;
     }
   }
-  if ((!T.is_default(true) || sh.lp1 || sh.ld1) && elem != Elem::F32)
-    return fail(err, "shading net: only the 8 x 256 / skip 4 topology with the 10-4 encoding runs on the 16-bit engine");
   for (int i = 0; i < T.depth; ++i) {
     const std::string nm = "pts_linears." + std::to_string(i);
     const Tensor* W = find(net1, nm + ".weight", err);

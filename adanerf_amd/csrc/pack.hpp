@@ -57,8 +57,8 @@ struct NetShape {
 bool pack_sampling_net(const TensorMap& net0, const NetShape& shape, Elem elem, PackedNet* out, std::string* err);
 
 // pts_linears.{0..D-1}, feature_linear(+alpha_linear as row W), views_linears.0, rgb_linear
-// (src/models.py:199-277).  Layer order in the blob: 0..D-1, feature+alpha, views, rgb.  Other than 8 x 256 / skip 4
-// (W % 64 == 0, W <= 512, D in 1..8, one skip or none): Elem::F32 only, as above.
+// (src/models.py:199-277).  Layer order in the blob: 0..D-1, feature+alpha, views, rgb.  Any topology (W % 64 == 0, W <= 512,
+// D in 1..8, one skip or none) and encoding layout packs for every element type (16-bit: k_generic16.hip.hpp).
 bool pack_shading_net(const TensorMap& net1, const NetShape& shape, Elem elem, PackedNet* out, std::string* err);
 
 uint16_t f32_to_bf16(float f);

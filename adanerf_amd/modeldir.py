@@ -101,9 +101,10 @@ def camera_rotation(yaw_deg: float, pitch_deg: float) -> np.ndarray:
 
 
 def random_init_weights(seed: int = 0, n_in0: int = 90, n_pos: int = 63, n_dir: int = 27, oracle_bias: float = 0.1,
-                        oracle_scale: float = 0.3):
+                        oracle_scale: float = 0.3, layers=(8, 8), widths=(256, 256), skip1: int = 4):
     """Seeded Kaiming-normal weights of the two architectures in the exported naming
-    (layers.{0..7}; pts_linears.{0..7}, feature_linear, alpha_linear, views_linears.0, rgb_linear)."""
+    (layers.{0..D0-1}; pts_linears.{0..D1-1}, feature_linear, alpha_linear, views_linears.0, rgb_linear); ``layers`` / ``widths``
+    / ``skip1``: depth and width of the two networks and the trunk's skip index (defaults = every shipped config)."""
     rng = np.random.default_rng(seed)
 
     def lin(n_out, n_in, scale=1.0):
@@ -112,14 +113,15 @@ def random_init_weights(seed: int = 0, n_in0: int = 90, n_pos: int = 63, n_dir: 
         return w, b
 
     n0, n1 = {}, {}
-    dims = [n_in0] + [256] * 7 + [128]
-    for i in range(8):
-        w, b = lin(dims[i + 1], dims[i], oracle_scale if i == 7 else 1.0)
-        n0["layers.%d.weight" % i], n0["layers.%d.bias" % i] = w, (b + (oracle_bias if i == 7 else 0.0)).astype(np.float32)
-    for i in range(8):
-        n1["pts_linears.%d.weight" % i], n1["pts_linears.%d.bias" % i] = lin(256, n_pos if i == 0 else (256 + n_pos if i == 5 else 256))
-    for nm, (o, k) in {"views_linears.0": (128, 256 + n_dir), "feature_linear": (256, 256), "alpha_linear": (1, 256),
-                       "rgb_linear": (3, 128)}.items():
+    d0, w0, d1, w1 = layers[0], widths[0], layers[1], widths[1]
+    dims = [n_in0] + [w0] * (d0 - 1) + [128]
+    for i in range(d0):
+        w, b = lin(dims[i + 1], dims[i], oracle_scale if i == d0 - 1 else 1.0)
+        n0["layers.%d.weight" % i], n0["layers.%d.bias" % i] = w, (b + (oracle_bias if i == d0 - 1 else 0.0)).astype(np.float32)
+    for i in range(d1):
+        n1["pts_linears.%d.weight" % i], n1["pts_linears.%d.bias" % i] = lin(w1, n_pos if i == 0 else (w1 + n_pos if i == skip1 + 1 else w1))
+    for nm, (o, k) in {"views_linears.0": (w1 // 2, w1 + n_dir), "feature_linear": (w1, w1), "alpha_linear": (1, w1),
+                       "rgb_linear": (3, w1 // 2)}.items():
         n1[nm + ".weight"], n1[nm + ".bias"] = lin(o, k)
     return n0, n1
 

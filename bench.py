@@ -41,7 +41,19 @@ WORKLOADS = {
     # vanilla NeRF with hierarchical sampling, the original paper's 64 coarse + 128 more samples per ray through two
     # 8 x 256 networks (64 + 192 = 256 network evaluations per ray); random-init weights.  Not a BASELINE configuration.
     "nerf_coarse_fine": (800, 800, 128, 1.0, "nerf_pair_random_init"),
+    # a topology other than 8 x 256 / skip 4 -- both networks 6 x 128 (skip 2), random init.  The sampling network runs
+    # on the run-time-shaped exact-fp32 kernel, the shading network on the run-time-shaped 16-bit kernel.  Not a BASELINE configuration.
+    "generic_6x128": (800, 800, 8, 0.65, "generic_6x128_random_init"),
 }
+
+
+def shade_flop_per_sample(tag):
+    """2 x MACs of the shading network per sample (SURVEY 8d counts the 8 x 256 one: 593 408 MAC)"""
+    if tag == "generic_6x128_random_init":
+        w, d, skip, n_pos, n_dir = 128, 6, 2, 63, 27
+        mac = n_pos * w + sum((w + n_pos if i == skip + 1 else w) * w for i in range(1, d)) + w * w + w + (w + n_dir) * (w // 2) + (w // 2) * 3
+        return 2 * mac
+    return SHADE_FLOP_PER_SAMPLE
 
 
 def build_model_dir(td, tag, n, thr):
@@ -60,6 +72,11 @@ def build_model_dir(td, tag, n, thr):
         n0, n1 = M.random_init_weights(7, n_in0=30, oracle_bias=-0.55, oracle_scale=0.5)
         s = dict(view_cell_center=(0.0, 0.0, 0.0), view_cell_size=(2.0, 2.0, 1.0), depth_range=(0.9, 12.0), fov=1.0, max_depth=12.0)
         data = "synthetic rays; random-init weights (seed 7), NDC / linear depth / 2-2 oracle encoding"
+    elif tag == "generic_6x128_random_init":
+        n0, n1 = M.random_init_weights(21, layers=(6, 6), widths=(128, 128), skip1=2)
+        s = dict(view_cell_center=(0.783, -3.19, 1.39), view_cell_size=(0.7, 0.7, 0.2),
+                 depth_range=(0.1542200982570648, 8.358194804191589), fov=1.1386263370513916, max_depth=8.79825210571289)
+        data = "synthetic rays; random-init weights (seed 21), both networks 6 x 128 / skip 2"
     elif tag == "nerf_pair_random_init":
         n0, n1 = M.random_init_nerf_pair(3)
         s = dict(view_cell_center=(0.783, -3.19, 1.39), view_cell_size=(0.7, 0.7, 0.2),
@@ -193,6 +210,7 @@ def main():
         dist.barrier()
 
     w, h, n_max, thr, tag = WORKLOADS[args.workload]
+    generic_wl = args.workload == "generic_6x128"
     if args.threshold is not None:
         thr = args.threshold
     td = tempfile.mkdtemp(prefix="adanerf_bench_%d_" % rank)
@@ -327,10 +345,13 @@ def main():
         # roofline of the dominant kernel (fused PE + shading MLP), this rank's launches
         launches = max(st.shade_launches, 1)
         shade_ms = st.ms_shade_mlp / launches
-        flop_per_launch = SHADE_FLOP_PER_SAMPLE * (st.total_samples / launches)
+        flop_per_sample = shade_flop_per_sample(tag)
+        flop_per_launch = flop_per_sample * (st.total_samples / launches)
         achieved = flop_per_launch / (shade_ms * 1e-3) / 1e12 if shade_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
-        kname = "shade_mlp%s_kernel" % ("32" if args.precision == "fp32" else "16")
+        kname = "shade_mlp%s_kernel" % ("32" if args.precision == "fp32" else ("16x2" if tag != "generic_6x128_random_init" else "16_gen"))
+        if tag == "generic_6x128_random_init" and args.precision == "fp32":
+            kname = "shade_mlp32_gen_kernel"
         # HBM bytes per launch of this kernel: PMC counters cannot be read from inside this process, so they come from the
         # committed rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh -> profiles/).  A summary is used
         # only if it was taken with the very sources this library is built from (source_hash), else traffic is null.
@@ -353,7 +374,7 @@ def main():
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "avg_launch_ms": shade_ms, "samples_per_launch": st.total_samples / launches,
-                    "flop_per_sample": SHADE_FLOP_PER_SAMPLE}
+                    "flop_per_sample": flop_per_sample}
         stage_ms = {"sample_mlp": st.ms_sample_mlp / frames, "compact": st.ms_compact / frames,
                     "shade_mlp": st.ms_shade_mlp / frames, "composite": st.ms_composite / frames}
         smp_launch = max(st.sample_launches, 1)
@@ -366,15 +387,20 @@ def main():
         refined = (st.rays_refined / frames) if args.sampling == "guarded" else 0.0
         exec_mult = {"split": 3.0, "fp16": 1.0, "fp32": 1.0, "guarded": 1.0 + 3.0 * refined / max(R, 1)}[args.sampling]
         smp_peak = PEAK_TFLOPS["fp32" if args.sampling == "fp32" else "fp16"]
+        smp_flop = SAMPLE_FLOP_PER_RAY
+        if generic_wl:      # 6 x 128 oracle net on the exact-fp32 engine whatever --sampling says
+            smp_flop = 2 * (90 * 128 + 4 * 128 * 128 + 128 * 128)
+            smp_tflops *= smp_flop / SAMPLE_FLOP_PER_RAY
+            exec_mult, smp_peak = 1.0, PEAK_TFLOPS["fp32"]
         smp_ms = st.ms_sample_mlp / frames
         sampling_roofline = {"bound": "mfma", "stage": "ray generation + encoding + sampling MLP (+ fused selection; guarded: + list + refinement pass)",
-                             "engine": args.sampling, "avg_ms_per_frame": smp_ms, "flop_per_ray": SAMPLE_FLOP_PER_RAY,
+                             "engine": "fp32 (run-time-shaped)" if generic_wl else args.sampling, "avg_ms_per_frame": smp_ms, "flop_per_ray": smp_flop,
                              "achieved_algorithmic": smp_tflops, "achieved_executed": smp_tflops * exec_mult, "peak": smp_peak, "unit": "TFLOP/s",
                              "frac_algorithmic": smp_tflops / smp_peak, "frac_executed": smp_tflops * exec_mult / smp_peak,
                              "rays_refined_per_frame": refined if args.sampling == "guarded" else None}
         # HBM-side view of the two bandwidth-bound stages: bytes the stage's kernels move by construction
         S_loc = samples_per_frame_local
-        fused = args.sampling in ("split", "fp16", "guarded") and 0.0 < thr and n_max <= 16 and args.workload != "nerf_coarse_fine"
+        fused = args.sampling in ("split", "fp16", "guarded") and 0.0 < thr and n_max <= 16 and args.workload not in ("nerf_coarse_fine", "generic_6x128")
         if args.workload == "nerf_coarse_fine":
             comp_bytes, comp_what = None, "fine sampler (not an HBM-bound stage)"
         elif thr == 0.0:
@@ -412,7 +438,7 @@ def main():
         # opt-in speed mode, reported beside the headline (never as it): the same frame with the sampling MLP in plain
         # fp16 (the viewer's TensorRT arithmetic); selection then deviates from the fp32 path on ~1 % of rays
         speed = None
-        if world == 1 and args.sampling in ("split", "guarded") and not args.no_speed_mode:
+        if world == 1 and args.sampling in ("split", "guarded") and not args.no_speed_mode and not generic_wl:
             with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision,
                                            sampling="fp16", device_id=local_rank) as r2:
                 r2.set_camera(pose, rot)
@@ -437,8 +463,9 @@ def main():
         rec = {"metric": "FPS at %dx%d" % (w, h), "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": args.precision, "data": data,
-               "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, 8x256 shading MLP %s, sampling MLP %s" %
-                                      (args.workload, w, h, n_max, thr, args.precision,
+               "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, %s shading MLP %s, sampling MLP %s" %
+                                      (args.workload, w, h, n_max, thr, "6x128" if generic_wl else "8x256", args.precision,
+                                       "6x128 on the run-time-shaped exact-fp32 kernel" if generic_wl else
                                        {"split": "split-fp16 (3 MFMAs per term)", "fp32": "fp32 MFMA", "fp16": "plain fp16 (opt-in speed mode)",
                                         "guarded": "guarded two-precision (plain fp16, split-fp16 on the rays inside the band)"}[args.sampling]),
                           "parallelism": ("image-strip shard x%d (%d-row strips, round-robin) + %s gather overlapped with the next frame" %

@@ -144,8 +144,8 @@ typedef struct adanerf_info {
   float   threshold;
   int32_t dense;            /* threshold == 0: all 128 bins, no selection */
   int32_t use_ndc;
-  int32_t precision;        /* the shading engine that runs: options.precision, or ADANERF_PREC_FP32 for a topology other
-                               than 8 x 256 / skip 4 (run-time-shaped fp32 kernels) */
+  int32_t precision;        /* the shading engine that runs: options.precision (every topology / encoding has a 16-bit and an
+                               fp32 form since ABI 3) */
   int32_t compute_units;
   float   fov, focal;
   float   view_cell_center[3];
@@ -384,8 +384,9 @@ int adanerf_host_parse_model(const char* model_dir, const adanerf_options* opt, 
  *   layer_out    per layer {w_off (16-B units), b_off (floats), slots per lane-half, 32-row tiles}
  *                as int32[4] each                (*n_layers); a sampling net with raySampleInput = A > 0 has one more
  *                record {w_off of layer 0's K-major block for the A extra points, A, slots per point, tiles}.
- * Topologies other than 8 x 256 (/ skip 4) and raySampleInput pack for ADANERF_PREC_FP32 only (they run on the
- * run-time-shaped fp32 kernels); the 16-bit precisions then return ADANERF_EIO with a message. */
+ * The shading net packs in every precision for every topology; a sampling net other than 8 x 256 with a 10-4 / 2-2 encoding
+ * and without raySampleInput packs for ADANERF_PREC_FP32 only (it runs on the run-time-shaped fp32 kernel) and the 16-bit
+ * precisions return ADANERF_EIO with a message. */
 int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precision, void* weights_out,
                               size_t* weights_bytes, float* bias_out, size_t* bias_floats, int32_t* layer_out,
                               int32_t* n_layers);

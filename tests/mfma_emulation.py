@@ -202,7 +202,7 @@ def run_sampling_net_generic(net: PackedNet, dir_unit, p, nds, fp, fd, rsi_z=Non
 
 
 def run_shading_net_generic(net: PackedNet, x, dpe, depth, width, skip, fp=10, fd=4):
-    assert net.precision == 2 and net.lay.shape[0] == depth + 3
+    assert net.precision in (0, 1, 2) and net.lay.shape[0] == depth + 3      # 16-bit: the same fragment order, 8 slots per k-step
     pts, dirs = pe_eval(x, fp), pe_eval(dpe, fd)
     h = net.layer(0, pts, True)
     for l in range(1, depth):

@@ -321,11 +321,9 @@ def test_generic_topologies_match_the_reference(name, tmp_path_factory):
     z, meta, sc = load_case(name)
     wts = case_weights(meta)
     d = _dir(tmp_path_factory, sc, wts, "topo_" + name)
-    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, meta["w"], meta["h"]), precision="bf16") as r:     # bf16 asked for:
-        r.set_camera(z["pose"], z["rot"])                                                                     # the generic nets run in fp32
-        assert r.info.n_in0 == sc.n_in0
-        if "rsi" not in name:
-            assert r.info.precision == R.PREC_FP32          # reported: what runs, not what was asked for
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, meta["w"], meta["h"]), precision="bf16") as r:
+        r.set_camera(z["pose"], z["rot"])
+        assert r.info.n_in0 == sc.n_in0 and r.info.precision == R.PREC_BF16      # generic shading nets run on the 16-bit engine too
         orc = run_rows(r, meta, lambda f, n, b: r.sample_mlp(f, n, b, None), 128)
         feat = run_rows(r, meta, lambda f, n, b: r.ray_features(f, n, b, None), sc.n_in0)
     n = z["oracle_in"].shape[0]
@@ -340,17 +338,20 @@ def test_generic_topologies_match_the_reference(name, tmp_path_factory):
     # whole small frames against the oracle, both precisions requested
     w, h = 96, 64
     ref = O.render_rays(O.generate_ray_directions(w, h, sc.fov), z["pose"], z["rot"], sc, wts, w, h, keep=True)
-    for prec in ("fp32", "bf16"):
+    # the sampling net of these models runs on the exact fp32 engine whatever is asked; the shading net in the precision asked for
+    for prec, min_psnr in (("fp32", 90.0), ("fp16", 72.0), ("bf16", 50.0)):
         with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=2500), precision=prec) as r:
             r.set_camera(z["pose"], z["rot"])
             rgb, rgba, st = r.render_numpy()
-        same = np.abs(rgb - ref["rgb"]).max(axis=1) < 3e-3
-        record("generic_topology_frame", case=name, prec=prec, agree=float(same.mean()), psnr_db=O.psnr(rgb[same], ref["rgb"][same]),
+        # batched: the count buffer holds the last batch only -> identify the rays whose selection agrees through the fp32 image
+        if prec == "fp32":
+            same = np.abs(rgb - ref["rgb"]).max(axis=1) < 3e-4
+            check_identical(same, "generic_topology_frame", residual_budget(w * h), case=name)
+        p = O.psnr(rgb[same], ref["rgb"][same])
+        record("generic_topology_frame", case=name, prec=prec, psnr_db=p, max_abs=float(np.abs(rgb[same] - ref["rgb"][same]).max()),
                samples=int(st.total_samples), ref_samples=int(ref["count"].sum()))
-        assert same.mean() >= 0.99
-        # the rsi case keeps the default 8 x 256 shading net: bf16 there is the 16-bit engine (55 dB class); generic nets are fp32
-        assert O.psnr(rgb[same], ref["rgb"][same]) > (50.0 if (prec == "bf16" and "rsi" in name) else 60.0)
-    assert abs(int(st.total_samples) - int(ref["count"].sum())) <= 0.01 * ref["count"].sum()
+        assert p > min_psnr, (prec, p)
+        assert abs(int(st.total_samples) - int(ref["count"].sum())) <= residual_budget(w * h) * sc.num_samples
 
 
 # ---------------------------------------------------------------------------------------------
@@ -495,7 +496,7 @@ def test_other_encodings_match_the_reference(name, tmp_path_factory):
     extreme = max(fp0, fp1) > 12
     with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, meta["w"], meta["h"]), precision="bf16") as r:
         r.set_camera(z["pose"], z["rot"])
-        assert (r.info.n_in0, r.info.n_in1) == (sc.n_in0, 6 + 6 * (fp1 + fd1)) and r.info.precision == R.PREC_FP32
+        assert (r.info.n_in0, r.info.n_in1) == (sc.n_in0, 6 + 6 * (fp1 + fd1)) and r.info.precision == R.PREC_BF16
         orc = run_rows(r, meta, lambda f, n, b: r.sample_mlp(f, n, b, None), 128)
         feat = run_rows(r, meta, lambda f, n, b: r.ray_features(f, n, b, None), sc.n_in0)
         rays = run_rows(r, meta, lambda f, n, b: r.ray_features(f, n, None, b), 8)
@@ -523,16 +524,20 @@ def test_other_encodings_match_the_reference(name, tmp_path_factory):
         check_identical((cnt == z["sel_count"]) & (bins == z["sel_bins"]).all(axis=1), "encoding_selection", 0, case=name)
     # 3. shading inputs and network
     exp_sfeat = O.shading_inputs(p_dev, nds_dev, sray[:m], O.to_world_depth(O.bin_t(sbin[:m].astype(np.int64)), sc), sc)
-    np.testing.assert_allclose(sfeat, exp_sfeat, rtol=0, atol=2e-3 if extreme else 1e-4)
+    np.testing.assert_allclose(sfeat, exp_sfeat, rtol=0, atol=2e-3 if extreme else 1e-3)      # 2^11 band x a few ulp of the normalised position (measured 3.7e-4)
     np.testing.assert_allclose(raw, O.shading_mlp(sfeat, wts.net1, n_pos=3 + 6 * fp1), rtol=1e-4, atol=1.2e-3)
     # 4. frames
     if not extreme:
         w, h = 96, 64
         ref = O.render_rays(O.generate_ray_directions(w, h, sc.fov), z["pose"], z["rot"], sc, wts, w, h, keep=True)
-        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=2500), precision="bf16") as r:
-            r.set_camera(z["pose"], z["rot"])
-            rgb, rgba, st = r.render_numpy()
-        same = np.abs(rgb - ref["rgb"]).max(axis=1) < 3e-3
-        record("encoding_frame", case=name, agree=float(same.mean()), psnr_db=O.psnr(rgb[same], ref["rgb"][same]))
-        assert same.mean() >= 0.99 and O.psnr(rgb[same], ref["rgb"][same]) > 60.0
-        assert abs(int(st.total_samples) - int(ref["count"].sum())) <= 0.01 * ref["count"].sum()
+        for prec, min_psnr in (("fp32", 80.0), ("fp16", 70.0), ("bf16", 50.0)):
+            with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=2500), precision=prec) as r:
+                r.set_camera(z["pose"], z["rot"])
+                rgb, rgba, st = r.render_numpy()
+            if prec == "fp32":
+                same = np.abs(rgb - ref["rgb"]).max(axis=1) < 1e-3
+                check_identical(same, "encoding_frame", residual_budget(w * h), case=name)
+            p = O.psnr(rgb[same], ref["rgb"][same])
+            record("encoding_frame", case=name, prec=prec, psnr_db=p)
+            assert p > min_psnr, (prec, p)
+            assert abs(int(st.total_samples) - int(ref["count"].sum())) <= residual_budget(w * h) * sc.num_samples

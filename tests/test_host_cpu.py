@@ -201,7 +201,7 @@ def test_generic_topologies_pack_and_reproduce_the_reference(lib, tmp_path, name
     """networks the reference's model classes built in other shapes (6 x 128 skip 2; 2 x 128 with 3 x 256
     skip 1; 4 x 128 with raySampleInput = 128) load, pack into fp32 MFMA fragments (topology read off the initializers)
     and -- replayed through the kernels' dataflow in numpy -- reproduce the reference's own sampling-network outputs
-    and the oracle's shading outputs.  The 16-bit packings refuse these shapes with a message."""
+    and the oracle's shading outputs; the shading net also in the 16-bit packings."""
     z, meta, sc = load_case(name)
     wts = case_weights(meta)
     d, _, _ = _model_dir(tmp_path, sc, wts, name=name)
@@ -229,15 +229,20 @@ def test_generic_topologies_pack_and_reproduce_the_reference(lib, tmp_path, name
     depth, skips = O.shading_topology(wts.net1, 63)
     out = run_shading_net_generic(PackedNet(w1, b1, lay1, 2), feat[:, 0:3], feat[:, 63:66], depth, syn["widths"][1], skips[0] if skips else -1)
     np.testing.assert_allclose(out, ref, rtol=0, atol=2e-4)
-    # the 16-bit engines are specialised to 8 x 256 (/ skip 4) without raySampleInput
+    # the shading net packs for the 16-bit engines in every topology (k_generic16.hip.hpp); replayed in bf16 / fp16 it stays
+    # within the operand rounding of the oracle
+    for prec, tol in ((0, 0.25), (1, 0.03)):
+        wq, bq, layq = pack_weights(lib, d, 1, prec)
+        outq = run_shading_net_generic(PackedNet(wq, bq, layq, prec), feat[:, 0:3], feat[:, 63:66], depth, syn["widths"][1], skips[0] if skips else -1)
+        assert np.abs(outq - ref).max() < tol and np.sqrt(np.mean((outq - ref) ** 2)) < tol / 6
+    # the sampling net's 16-bit engines are specialised to 8 x 256 without raySampleInput
     f = lib.adanerf_host_pack_weights
     wb, bf, nl = C.c_size_t(0), C.c_size_t(0), C.c_int32(0)
-    for net in (0, 1):
-        default = (syn["layers"][net], syn["widths"][net]) == (8, 256) and (net == 1 or not sc.ray_sample_input) and (net == 0 or syn["skip1"] == 4)
-        rc = f(d.encode(), net, 0 if net else 3, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl))
-        assert (rc == 0) == default, (net, rc)
-        if not default:
-            assert b"16-bit" in lib.adanerf_last_error(None)
+    default0 = (syn["layers"][0], syn["widths"][0]) == (8, 256) and not sc.ray_sample_input
+    rc = f(d.encode(), 0, 3, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl))
+    assert (rc == 0) == default0, rc
+    if not default0:
+        assert b"16-bit" in lib.adanerf_last_error(None)
 
 
 @pytest.mark.parametrize("name", ENCODING_CASES)
@@ -246,7 +251,7 @@ def test_other_encodings_pack_into_the_catch_all_layout(lib, tmp_path, name):
     generated by the reference).  Such networks are packed into the 16-band slot layout of the run-time-shaped kernels --
     the bands the model does not have get zero weights (layout.hpp pe_col) -- and, replayed through the kernels' dataflow
     in numpy with all 16 bands evaluated as the device does, reproduce the reference's sampling-network outputs and the
-    oracle's shading outputs.  The 16-bit packings refuse them with a message."""
+    oracle's shading outputs (the shading net also in bf16 / fp16)."""
     z, meta, sc = load_case(name)
     wts = case_weights(meta)
     d, _, _ = _model_dir(tmp_path, sc, wts, name=name.replace("-", "_"))
@@ -271,11 +276,14 @@ def test_other_encodings_pack_into_the_catch_all_layout(lib, tmp_path, name):
     w1, b1, lay1 = pack_weights(lib, d, 1, 2)
     out = run_shading_net_generic(PackedNet(w1, b1, lay1, 2), feat[:, 0:3], feat[:, 3 + 6 * fp1:6 + 6 * fp1], 8, 256, 4, fp=16, fd=16)
     np.testing.assert_allclose(out, ref, rtol=0, atol=3e-4)
+    for prec, tol in ((0, 0.25), (1, 0.03)):      # the shading net in the catch-all layout on the 16-bit engine
+        wq, bq, layq = pack_weights(lib, d, 1, prec)
+        outq = run_shading_net_generic(PackedNet(wq, bq, layq, prec), feat[:, 0:3], feat[:, 3 + 6 * fp1:6 + 6 * fp1], 8, 256, 4, fp=16, fd=16)
+        assert np.abs(outq - ref).max() < tol and np.sqrt(np.mean((outq - ref) ** 2)) < tol / 6
     f = lib.adanerf_host_pack_weights
     wb, bf, nl = C.c_size_t(0), C.c_size_t(0), C.c_int32(0)
-    for net in (0, 1):
-        assert f(d.encode(), net, 0 if net else 3, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl)) != 0
-        assert b"16-bit" in lib.adanerf_last_error(None)
+    assert f(d.encode(), 0, 3, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl)) != 0      # sampling net: split engine is 10-4 / 2-2 only
+    assert b"16-bit" in lib.adanerf_last_error(None)
 
 
 def test_product_path_fails_loudly_without_gpu(lib, tmp_path):

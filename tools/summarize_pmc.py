@@ -17,7 +17,9 @@ import sys
 
 root = sys.argv[1]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-names = {"shade_mlp16": "shade_mlp16_kernel", "shade_mlp32": "shade_mlp32_kernel", "sample_mlp16x3": "sample_mlp16x3_kernel",
+names = {"shade_mlp16x2": "shade_mlp16x2_kernel", "shade_mlp16_gen": "shade_mlp16_gen_kernel", "shade_mlp32_gen": "shade_mlp32_gen_kernel",
+         "sample_mlp_gen": "sample_mlp_gen_kernel", "refine_list": "refine_list_kernel",
+         "shade_mlp16": "shade_mlp16_kernel", "shade_mlp32": "shade_mlp32_kernel", "sample_mlp16x3": "sample_mlp16x3_kernel",
          "sample_mlp16_kernel": "sample_mlp16_kernel", "sample_mlp_kernel": "sample_mlp_kernel", "select_kernel": "select_kernel",
          "select_rows": "select_rows_kernel", "expand_kernel": "expand_kernel", "scan_blocks": "scan_blocks_kernel",
          "composite_kernel": "composite_kernel", "composite_wave": "composite_wave_kernel", "dense_expand": "dense_expand_kernel"}
