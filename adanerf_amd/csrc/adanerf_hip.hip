@@ -566,6 +566,7 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
                     : occupancy_grid(c, sample_mlp16_kernel<2, 2>, 512, &c->sample16_grid);
       if (rc) return rc;
     }
+    // wave tiles are dealt out evenly over the grid (sample_mlp16_kernel): every workgroup of a small batch gets a share
     dim3 g16(std::min<unsigned>((n_rays + 255) / 256, static_cast<unsigned>(c->sample16_grid))), b16(512);
     if (full) hipLaunchKernelGGL((sample_mlp16_kernel<10, 4>), g16, b16, 0, c->stream, a);
     else hipLaunchKernelGGL((sample_mlp16_kernel<2, 2>), g16, b16, 0, c->stream, a);
@@ -1069,7 +1070,15 @@ int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precis
   TensorMap tm;
   if (!read_onnx_initializers(join_path(model_dir, net == 0 ? "model0.onnx" : "model1.onnx"), &tm, &err)) return fail(nullptr, ADANERF_EIO, err);
   PackedNet pn;
-  bool ok = net == 0 ? pack_sampling_net(tm, sh, elem_of(precision), &pn, &err) : pack_shading_net(tm, sh, elem_of(precision), &pn, &err);
+  // a coarse/fine directory holds two NeRF nets: model0.onnx packs like a shading net with the encoding posEncArgs[0]
+  bool ok;
+  if (net == 0 && cfm) {
+    if (precision == 3) return fail(nullptr, ADANERF_EINVAL, "coarse/fine model: net 0 is a NeRF net (precision 0..2)");
+    const NetShape shc = shape_of(sh.fp0, sh.fd0, sh.fp0, sh.fd0, 0, false);
+    ok = pack_shading_net(tm, shc, elem_of(precision), &pn, &err);
+  } else {
+    ok = net == 0 ? pack_sampling_net(tm, sh, elem_of(precision), &pn, &err) : pack_shading_net(tm, sh, elem_of(precision), &pn, &err);
+  }
   if (!ok) return fail(nullptr, ADANERF_EIO, err);
   if (weights_out) {
     if (*weights_bytes < pn.weights.size()) return fail(nullptr, ADANERF_EINVAL, "weights_out too small");
@@ -1399,7 +1408,9 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     c->prof_frames = 0;
     c->folded = adanerf_stats{};
   }
-  const bool record = stats || c->profiling;
+  // a single frame of more batches than the event pool may hold is rendered without per-stage timing (stats then carry the
+  // sample totals of nothing and zero times) rather than growing the pool without bound
+  const bool record = (stats || c->profiling) && static_cast<size_t>(n_batches) <= kMaxProfiledBatches;
   if (record && c->events_used && c->events_used / 5 + n_batches > kMaxProfiledBatches) {
     // the event pool is full: fold what it holds into the running record (one synchronisation per 65 536 batches)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1496,7 +1507,7 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if ((rc = sum_stats(c, stats))) return rc;
     stats->rays = R;
-    if (n_batches > 0) {   // wall span of this frame, first launch -> last kernel end
+    if (n_batches > 0 && record) {   // wall span of this frame, first launch -> last kernel end
       const size_t e0 = c->events_used - static_cast<size_t>(n_batches) * 5;
       HIP_TRY(c, hipEventElapsedTime(&stats->ms_total, c->events[e0], c->events[c->events_used - 1]));
     }

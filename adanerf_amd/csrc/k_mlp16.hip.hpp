@@ -146,8 +146,8 @@ __device__ __forceinline__ void ws_advance(WStream<CF, RS, LPW, NR>& st) {
 // compiler, and on the short side of such a branch it came out too small (7 wait states between the last MFMA of a
 // tile and the first v_cvt_pk of its epilogue, hipcc / ROCm 7.2 with -amdgpu-mfma-vgpr-form: the epilogue then read
 // accumulator rows the last MFMA had not written yet -- wrong rgb for waves 4-7 in the variants of
-// profiles/r02_stagger_hazard.md).  16 explicit wait states on the short side make the distance independent of what the
-// scheduler puts after the join.
+// profiles/r02_stagger_hazard.md).  s_nop kSkipPad = 12 explicit wait states on the short side (11 are required) make the
+// distance independent of what the scheduler puts after the join.
 
 // tile_start: the instruction stream in front of this position ends with the last MFMA of an output tile (whose epilogue
 // the compiler may have moved behind the branch); mid-tile, the next consumer of the accumulator is the next MFMA of the chain.

@@ -246,6 +246,9 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
 template <int FP, int FD>
 constexpr int sample16_frags() { return ((pe_slots(FD) + pe_slots(FP)) / 8) * 8 + 6 * 128 + 64; }
 
+// Occupancy: one 8-wave workgroup per CU by design (two waves per SIMD from the SAME workgroup, staggered half a chunk apart):
+// __launch_bounds__(512, 2) = two waves per SIMD = 256 registers; the LDS footprint (64 KB ring + 7.5 KB biases + 8 x 8 KB
+// selection staging = 135.5 KB) admits no second workgroup either, with or without the fused selection.
 template <int FP, int FD>
 __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
   constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP;
@@ -259,8 +262,16 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int j = lane & 31, h = lane >> 5;
-  const int ntiles = (a.n_rays + TILE - 1) / TILE;
-  if (static_cast<int>(blockIdx.x) >= ntiles) return;
+  // Work is dealt out in wave tiles (32 rays): q full rounds of 8 wave tiles per workgroup, then the remaining rem < 8 G wave tiles
+  // in ONE partial round of k = ceil(rem / G) waves per workgroup instead of a full round on some workgroups and none on the
+  // others.  A round with <= 4 active waves has every SIMD to itself and takes a little over half a full round, which is what a
+  // small batch (an 80 000-ray shard of an 8-GPU frame: 1.22 rounds) gains.  The idle waves of that round only keep the weight
+  // ring's barriers and DMA going (ring_walk).
+  const int WT = (a.n_rays + 31) >> 5, G = static_cast<int>(gridDim.x);
+  const int q = WT / (WAVES * G), rem = WT - WAVES * G * q, k = (rem + G - 1) / G;
+  const bool has_partial = static_cast<int>(blockIdx.x) * k < rem;          // workgroup-uniform
+  const int rounds = q + (has_partial ? 1 : 0);
+  if (rounds == 0) return;
   const uint32_t sel_stage = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + kBiasFloats * 4 +
                              wave * kPairLdsBytesPerWave + lane * 16;
   {
@@ -274,8 +285,17 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
   const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
   const uint32_t* bo = a.net16.b_off;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int local = tile * TILE + wave * 32 + j;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int wt = rd < q ? (rd * G + static_cast<int>(blockIdx.x)) * WAVES + wave : WAVES * G * q + static_cast<int>(blockIdx.x) * k + wave;
+    if (rd >= q && (wave >= k || wt >= WT)) {      // wave-uniform: an idle wave of the partial round
+#pragma unroll 1
+      for (int c = 0; c < FRAGS / CF; ++c) {
+        ws_position<0>(st, 0, false);
+        ws_position<0>(st, CF / 2, false);
+      }
+      continue;
+    }
+    const int local = wt * 32 + j;
     const bool valid = local < a.n_rays;
     const int ray = a.first_ray + (valid ? local : a.n_rays - 1);
     int col, row;

@@ -14,6 +14,7 @@ if len(sys.argv) > 2:
     thr = float(sys.argv[2])
 worlds = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (1, 2, 4, 8)
 prec = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+sampling = sys.argv[5] if len(sys.argv) > 5 else "guarded"      # what bench.py measures by default
 from adanerf_amd import sharding
 td = tempfile.mkdtemp()
 scene, _ = Bn.build_model_dir(td, tag, n_max, thr)
@@ -22,7 +23,7 @@ rot = M.camera_rotation(100.0, 0.0) if tag != "ndc_random_init" else np.eye(3, d
 rows = []
 for world in worlds:
     for rank in range(world):
-        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h), precision=prec, shard_rank=rank, shard_world=world,
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h), precision=prec, sampling=sampling, shard_rank=rank, shard_world=world,
                                        strip_rows=sharding.balanced_strip_rows(h, world)) as r:
             r.set_camera(pose, rot)
             out = r.empty((r.info.rays_local_max, 4), np.uint8)
