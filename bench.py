@@ -356,7 +356,7 @@ def main():
         # committed rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh -> profiles/).  A summary is used
         # only if it was taken with the very sources this library is built from (source_hash), else traffic is null.
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_summary_%s.json" % args.workload)
+        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_summary_%s.json" % args.workload)
         if os.path.exists(pmc_path) and world == 1 and r.info.batch_rays >= r.info.rays_local:
             try:
                 pmc = json.load(open(pmc_path))

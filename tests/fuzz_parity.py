@@ -42,6 +42,9 @@ def one_case(rng, idx):
     if os.environ.get("FUZZ_ROUND2"):       # round-2 features: oracle transforms, multiplier modes, other topologies, raySampleInput
         kinds += ["transform", "mult", "topo", "rsi", "pdf_ce", "coarse_fine"]
         probs = [0.1, 0.05, 0.05, 0.05, 0.05, 0.15, 0.1, 0.15, 0.1, 0.05, 0.15]
+    if os.environ.get("FUZZ_ROUND3"):       # round-3 features: any posEncArgs (catch-all slot layout), NDC coarse / fine; every eligible
+        kinds += ["enc", "cf_ndc"]          # case is also rendered in the guarded sampling mode and compared with the split engine
+        probs = [p * 0.75 for p in probs] + [0.17, 0.08]
     kind = rng.choice(kinds, p=probs)
     if kind == "classroom":
         z, meta, sc = load_case("classroom_n8_thr02"); wts = case_weights(meta)
@@ -63,6 +66,24 @@ def one_case(rng, idx):
         skips = tuple(int(rng.integers(-1, l - 1)) if l > 2 else -1 for l in layers) if generic else (4, 4)
         wts = O.synthetic_coarse_fine_weights(int(rng.integers(1 << 30)), alpha_bias=float(rng.uniform(0.0, 2.5)), layers=layers,
                                               widths=widths, skips=skips)
+    elif kind == "cf_ndc":                           # vanilla NeRF in normalised device coordinates, any encodings
+        z, meta, sc = load_case("ndc_coarse_fine_12_20")
+        pe = ((int(rng.integers(1, 11)), int(rng.integers(1, 7))), (int(rng.integers(1, 11)), int(rng.integers(1, 7))))
+        if rng.random() < 0.4:
+            pe = ((10, 4), (10, 4))
+        sc = dataclasses.replace(sc, pos_enc=pe)
+        wts = O.synthetic_coarse_fine_weights(int(rng.integers(1 << 30)), pos_enc=pe, alpha_bias=float(rng.uniform(-1.0, 1.0)))
+    elif kind == "enc":                              # posEncArgs other than 10-4 / 2-2, default or other topology
+        z, meta, sc = load_case("synthetic_fixed8")
+        pe = ((int(rng.integers(1, 13)), int(rng.integers(1, 9))), (int(rng.integers(1, 13)), int(rng.integers(1, 9))))
+        sc = dataclasses.replace(sc, pos_enc=pe)
+        generic = rng.random() < 0.3
+        layers = (int(rng.integers(2, 9)), int(rng.integers(2, 9))) if generic else (8, 8)
+        widths = (int(rng.choice([64, 128, 256])), int(rng.choice([64, 128, 256]))) if generic else (256, 256)
+        skip1 = (int(rng.integers(-1, layers[1] - 1)) if layers[1] > 2 else -1) if generic else 4
+        wts = O.synthetic_weights(int(rng.integers(1 << 30)), n_in0=sc.n_in0, n_in1_pos=3 + 6 * pe[1][0], n_in1_dir=3 + 6 * pe[1][1],
+                                  oracle_bias=float(rng.uniform(-0.3, 0.5)), oracle_scale=float(rng.uniform(0.2, 1.0)), layers=layers,
+                                  widths=widths, skip1=skip1)
     elif kind in ("topo", "rsi"):                    # any exportable topology / raySampleInput (generic fp32 kernels)
         z, meta, sc = load_case("synthetic_fixed8")
         rsi = int(rng.choice([1, 3, 8, 32])) if kind == "rsi" else 0
@@ -86,21 +107,21 @@ def one_case(rng, idx):
     if kind == "mult":
         sc = dataclasses.replace(sc, accumulation_mult=str(rng.choice(["weights", "", "alpha"])),
                                  losses0=str(rng.choice(["NeRFWeightMultiplicationLoss", "NeRFWeightMultiplicationLoss", "MSE"])))
-    if rng.random() < 0.08 and kind not in ("ndc", "pdf", "pdf_ce", "transform", "coarse_fine"):
+    if rng.random() < 0.08 and kind not in ("ndc", "pdf", "pdf_ce", "transform", "coarse_fine", "cf_ndc"):
         n_max, thr = 128, 0.0                     # dense mode
     if kind in ("pdf", "pdf_ce"):
         n_max, thr = int(rng.choice([2, 4, 8, 16, 32])), sc.threshold
-    if kind == "coarse_fine":
+    if kind in ("coarse_fine", "cf_ndc"):
         nc = int(rng.choice([3, 4, 8, 16, 33, 64, 128]))
         sc = dataclasses.replace(sc, num_samples_coarse=nc)
         n_max, thr = int(rng.choice([1, 2, 8, 24, 64, 128])), 1.0
     sc = dataclasses.replace(sc, num_samples=n_max, threshold=thr)
     w = int(rng.integers(1, 97)); h = int(rng.integers(1, 65))
-    if n_max == 128 or (kind == "coarse_fine" and n_max + sc.num_samples_coarse > 48):
+    if n_max == 128 or (kind in ("coarse_fine", "cf_ndc") and n_max + sc.num_samples_coarse > 48):
         w, h = min(w, 40), min(h, 24)
     centre = np.array(sc.view_cell_center, np.float32); size = np.array(sc.view_cell_size, np.float32)
     pose = (centre + rng.uniform(-0.5, 0.5, 3).astype(np.float32) * size).astype(np.float32)
-    rot = O.camera_rotation(float(rng.uniform(0, 360)), float(rng.uniform(-40, 40))) if kind != "ndc" else z["rot"]
+    rot = O.camera_rotation(float(rng.uniform(0, 360)), float(rng.uniform(-40, 40))) if kind not in ("ndc", "cf_ndc") else z["rot"]
     batch = int(rng.choice([-1, -1, 1, 7, 64, 1000, 4096]))
     shard_world = int(rng.choice([1, 1, 2, 3, 5, 8]))
     shard_rows = int(rng.choice([1, 3, 5, 8]))
@@ -145,7 +166,7 @@ def one_case(rng, idx):
             return 0.0
         return float(e[same].max()) if (cnt is not None and same.any()) else float(np.quantile(e, 0.97))
     err32 = worst(rgb, ref["rgb"])
-    if kind in ("pdf", "pdf_ce", "coarse_fine"):
+    if kind in ("pdf", "pdf_ce", "coarse_fine", "cf_ndc"):
         # inverse-CDF samplers: where a bin's probability mass is ~0 the inverse is ill-conditioned and a sample may land at the
         # other edge of the (empty) bin in one of the two implementations (fp32 cumulative sums in different orders); the bulk
         # of the rays must agree tightly, the stragglers loosely
@@ -160,7 +181,7 @@ def one_case(rng, idx):
     elif err32 > 5e-4:
         ok = False; msg.append("fp32 rgb err %.2e" % err32)
     rgb16 = out["bf16"][0]
-    if kind in ("pdf", "pdf_ce", "coarse_fine"):
+    if kind in ("pdf", "pdf_ce", "coarse_fine", "cf_ndc"):
         # classic compositing gives the LAST sample of a ray the distance 1e10 (src/nerf_raymarch_common.py:36): its alpha
         # is a step function of the sign of its density, so a bf16-sized error on a density near zero turns a transparent
         # ray opaque.  The bound is therefore on the 97th percentile of the per-ray error in this mode.
@@ -170,6 +191,19 @@ def one_case(rng, idx):
         e16 = worst(rgb16, ref["rgb"])
     if e16 > 0.12:
         ok = False; msg.append("bf16 rgb err %.3f" % e16)
+    # guarded two-precision selection (round 3): where it applies (fused selection on the 8 x 256 / 10-4 or 2-2 sampling net, whole
+    # frame in one batch) its counts and bins must be the split engine's bit for bit and the monitor must not see its band violated
+    if os.environ.get("FUZZ_ROUND3") and cnt is not None and 0.0 < thr and n_max <= 16 and kind in ("classroom", "barbershop", "random", "ndc", "transform", "mult"):
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=batch), precision="bf16", sampling="guarded") as r:
+            r.set_camera(pose, rot)
+            rgb_g, rgba_g, st_g = r.render_numpy()
+            cnt_g, bins_g = bins_of(r, w * h, n_max)
+        cnt_s, bins_s = out["bf16"][3], out["bf16"][4]
+        if not (np.array_equal(cnt_g, cnt_s) and np.array_equal(bins_g, bins_s)):
+            ok = False; msg.append("guarded selection differs from the split engine on %d rays" % int(((cnt_g != cnt_s) | (bins_g != bins_s).any(axis=1)).sum()))
+        if st_g.guard_violations:
+            ok = False; msg.append("guard band violated on %d re-evaluated rays (max seen %.2e)" % (st_g.guard_violations, st_g.guard_max_seen))
+        msg.append("guarded: %d of %d rays refined" % (st_g.rays_refined, w * h))
     # sharded render of the same frame (random world size / strip height, all contexts on this GPU): byte-identical
     if shard_world > 1:
         rs = [adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=batch), precision="bf16", shard_rank=k,

@@ -20,3 +20,6 @@ for t in 0.05 0.1 0.2 0.3 0.4; do run config5_ndc_fp16_thr$t --steps 20 --worklo
 run config2_orbit16 --steps 32 --orbit 16 --no-cpu-baseline
 run nerf_coarse_fine --steps 5 --warmup 2 --workload nerf_coarse_fine --no-cpu-baseline
 run config2_speed_mode --steps 30 --sampling fp16 --no-cpu-baseline
+run config2_split_sampling --steps 30 --sampling split --no-cpu-baseline
+run generic_6x128_bf16 --steps 10 --workload generic_6x128 --no-cpu-baseline
+run generic_6x128_fp32 --steps 5 --workload generic_6x128 --precision fp32 --no-cpu-baseline
