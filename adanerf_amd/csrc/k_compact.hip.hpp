@@ -324,7 +324,15 @@ __global__ __launch_bounds__(256) void refine_list_kernel(const uint32_t* __rest
   const int t = static_cast<int>(threadIdx.x);
   const int b0 = blockIdx.x * 256;
   int s = 0;
-  for (int i = t; i < b0; i += 256) s += __popc(mask[i]);
+  {   // b0 is a multiple of 256 words: 16-byte loads, four in flight per thread (the loop is latency-, not bandwidth-bound)
+    const uint4* m4 = reinterpret_cast<const uint4*>(mask);
+    const int n4 = b0 >> 2;
+#pragma unroll 4
+    for (int i = t; i < n4; i += 256) {
+      const uint4 v = m4[i];
+      s += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   const int wi = b0 + t;

@@ -107,7 +107,9 @@ def one_case(rng, idx):
     if kind == "mult":
         sc = dataclasses.replace(sc, accumulation_mult=str(rng.choice(["weights", "", "alpha"])),
                                  losses0=str(rng.choice(["NeRFWeightMultiplicationLoss", "NeRFWeightMultiplicationLoss", "MSE"])))
-    if rng.random() < 0.08 and kind not in ("ndc", "pdf", "pdf_ce", "transform", "coarse_fine", "cf_ndc"):
+    # (not for "enc": a 128-term transmittance product over un-trained weights amplifies the 1e-3 differences the high bands of a
+    # 12-band encoding make in single raw outputs -- the stages are compared one by one in tests/test_gpu_configs.py instead)
+    if rng.random() < 0.08 and kind not in ("ndc", "pdf", "pdf_ce", "transform", "coarse_fine", "cf_ndc", "enc"):
         n_max, thr = 128, 0.0                     # dense mode
     if kind in ("pdf", "pdf_ce"):
         n_max, thr = int(rng.choice([2, 4, 8, 16, 32])), sc.threshold
