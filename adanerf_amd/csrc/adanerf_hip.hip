@@ -881,10 +881,10 @@ int launch_composite(adanerf_ctx* c, const float* d_raw, const float* d_w, const
                      float* d_rgb, void* d_rgba8, const uint32_t* d_key = nullptr, float* d_depth = nullptr, float* d_acc = nullptr) {
   if (n_rays <= 0) return ADANERF_OK;
   AuxOut aux{};
-  if (d_key && (d_depth || d_acc)) {
+  if ((d_key || c->info.dense) && (d_depth || d_acc)) {
     aux.depth = d_depth;
     aux.acc = d_acc;
-    aux.sample_key = d_key;
+    aux.sample_key = d_key;      // null in dense mode: the bin of sample i is i & 127
     aux.ztab = reinterpret_cast<const float*>(c->ztab.p);
   }
   if (c->info.num_samples > 32)   // long rays (dense mode): one wave per ray, coalesced
@@ -1474,11 +1474,18 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     if (cfm) rc = ADANERF_OK;
     else if (pdf) rc = launch_sample_pdf(c, oracle, n, N, off, cnt, key, sw, sz, total);
     else if (fused) rc = launch_expand(c, n, N, kPairSegShift, off, cnt, key, sw, total);
-    else rc = launch_compact(c, oracle, n, N, thr, off, cnt, key, sw, total);
+    else if (thr == 0.f) {      // dense: implicit keys, the oracle buffer is the weight array (dense_offsets_kernel)
+      hipLaunchKernelGGL(dense_offsets_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, off, cnt, total);
+      HIP_TRY(c, hipGetLastError());
+      rc = ADANERF_OK;
+    } else rc = launch_compact(c, oracle, n, N, thr, off, cnt, key, sw, total);
     if (rc) return rc;
+    const bool dense_implicit = !cfm && !pdf && !fused && thr == 0.f;
+    const uint32_t* key_s = dense_implicit ? nullptr : key;
+    const float* sw_s = dense_implicit ? oracle : sw;
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     const int64_t max_s = static_cast<int64_t>(n) * N;   // <= INT32_MAX: checked by setup_model
-    if ((rc = launch_shade_mlp(c, rays, key, total, static_cast<int>(max_s), c->info.precision, raw, pdf ? sz : nullptr))) return rc;
+    if ((rc = launch_shade_mlp(c, rays, key_s, total, static_cast<int>(max_s), c->info.precision, raw, pdf ? sz : nullptr))) return rc;
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     float* rgb_b = d_rgb ? d_rgb + static_cast<size_t>(first) * 3 : nullptr;
     void* rgba_b = d_rgba8 ? static_cast<char*>(d_rgba8) + static_cast<size_t>(first) * 4 : nullptr;
@@ -1490,7 +1497,7 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
       if (!acc_b) acc_b = reinterpret_cast<float*>(c->disp_scratch.p) + B;
     }
     if (pdf) rc = launch_composite_classic(c, raw, sz, rays, n, N, rgb_b, rgba_b, depth_b, acc_b);
-    else rc = launch_composite(c, raw, sw, off, cnt, n, rgb_b, rgba_b, key, depth_b, acc_b);
+    else rc = launch_composite(c, raw, sw_s, off, cnt, n, rgb_b, rgba_b, key_s, depth_b, acc_b);
     if (rc) return rc;
     if (c->aux_disp && n > 0) {
       hipLaunchKernelGGL(disp_map_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, depth_b, acc_b, n, c->aux_disp + first);

@@ -384,7 +384,19 @@ __global__ __launch_bounds__(256) void oracle_view_kernel(const float* __restric
   }
 }
 
-// thr == 0: every bin of every ray (src/nerf_raymarch_common.py:708-720); keys are implicit
+// thr == 0 inside adanerf_render: only what the compositing kernel needs per ray -- the samples' keys are their indices and their
+// kept values are the oracle buffer itself, so neither array is written (the shading / compositing kernels take a null key
+// array and the oracle buffer as the weights)
+__global__ __launch_bounds__(256) void dense_offsets_kernel(int n_rays, int32_t* __restrict__ ray_offsets, int32_t* __restrict__ counts,
+                                                            int32_t* __restrict__ total) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r == 0) *total = n_rays * kBins;
+  if (r >= n_rays) return;
+  ray_offsets[r] = r * kBins;
+  counts[r] = kBins;
+}
+
+// thr == 0, stage API (explicit arrays): every bin of every ray (src/nerf_raymarch_common.py:708-720)
 __global__ __launch_bounds__(256) void dense_expand_kernel(const float* __restrict__ oracle, int n_rays, int32_t* __restrict__ ray_offsets,
                                                            int32_t* __restrict__ counts, uint32_t* __restrict__ sample_key,
                                                            float* __restrict__ sample_w, int32_t* __restrict__ total) {

@@ -16,7 +16,8 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(
 struct AuxOut {
   float* depth;               // [R] or null
   float* acc;                 // [R] or null
-  const uint32_t* sample_key; // adaptive / dense path: z = ztab[key & 127]
+  const uint32_t* sample_key; // adaptive path: z = ztab[key & 127]; null with dense != 0: the bin is the sample index & 127
+  int32_t dense;
   const float* ztab;
 };
 
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(RB) void composite_kernel(const float4* __restrict_
     float dm = 0.f, am = 0.f;
     for (int k = 0; k < c; ++k) {
       const float wt = composite_step(raw[o + k], sample_w[o + k], mult_mode, cr, cg, cb, T);
-      dm = __fadd_rn(dm, __fmul_rn(wt, aux.ztab[aux.sample_key[o + k] & 127u]));
+      dm = __fadd_rn(dm, __fmul_rn(wt, aux.ztab[(aux.sample_key ? aux.sample_key[o + k] : static_cast<uint32_t>(o + k)) & 127u]));
       am = __fadd_rn(am, wt);
     }
     if (aux.depth) aux.depth[r] = dm;
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(256) void composite_wave_kernel(const float4* __res
       q0 *= (lane < c) ? sample_w[o + lane] : 0.f;
       q1 *= (lane + 64 < c) ? sample_w[o + lane + 64] : 0.f;
     }
-    float dm = q0 * ((lane < c) ? aux.ztab[aux.sample_key[o + lane] & 127u] : 0.f) +
-               q1 * ((lane + 64 < c) ? aux.ztab[aux.sample_key[o + lane + 64] & 127u] : 0.f);
+    float dm = q0 * ((lane < c) ? aux.ztab[(aux.sample_key ? aux.sample_key[o + lane] : static_cast<uint32_t>(o + lane)) & 127u] : 0.f) +
+               q1 * ((lane + 64 < c) ? aux.ztab[(aux.sample_key ? aux.sample_key[o + lane + 64] : static_cast<uint32_t>(o + lane + 64)) & 127u] : 0.f);
     float am = q0 + q1;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {

@@ -17,7 +17,7 @@ struct ShadeArgs {
   ShadeParams sp;
   NetParams net;
   const float* rays;          // [*,8]
-  const uint32_t* sample_key; // [S]
+  const uint32_t* sample_key; // [S]; null in dense mode (128 samples per ray in order: the key of sample i is i)
   const float* sample_z;      // [S] world depth per sample (inverse-CDF sampler); null -> ztab[bin]
   const int32_t* total;       // device S (may be null -> max_samples)
   int32_t max_samples;
@@ -343,7 +343,7 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
 // Loads the sample's ray record and evaluates position (+ optional unit direction).
 __device__ __forceinline__ void load_sample(const ShadeArgs& a, int s, int total, float x[3], float dpe[3]) {
   const int si = (s < total) ? s : (total > 0 ? total - 1 : 0);
-  const uint32_t key = a.sample_key[si];
+  const uint32_t key = a.sample_key ? a.sample_key[si] : static_cast<uint32_t>(si);      // null: dense mode, sample i = (ray i >> 7, bin i & 127)
   const uint32_t ray = key >> 7;
   const int bin = static_cast<int>(key & 127u);
   const float4* rr = reinterpret_cast<const float4*>(a.rays + static_cast<size_t>(ray) * 8);

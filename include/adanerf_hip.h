@@ -362,8 +362,8 @@ enum {
   ADANERF_BUF_ORACLE = 1,      /* [batch,128] fp32 */
   ADANERF_BUF_RAY_OFFSETS = 2, /* [batch] int32 */
   ADANERF_BUF_RAY_COUNTS = 3,  /* [batch] int32 */
-  ADANERF_BUF_SAMPLE_KEY = 4,  /* [S] uint32 */
-  ADANERF_BUF_SAMPLE_W = 5,    /* [S] fp32 */
+  ADANERF_BUF_SAMPLE_KEY = 4,  /* [S] uint32; not written in dense mode (threshold 0): sample i is ray i >> 7, bin i & 127 */
+  ADANERF_BUF_SAMPLE_W = 5,    /* [S] fp32; not written in dense mode: the kept values are ADANERF_BUF_ORACLE itself */
   ADANERF_BUF_RAW = 6,         /* [S,4] fp32 */
   ADANERF_BUF_TOTAL = 7,       /* [1] int32 */
   ADANERF_BUF_SAMPLE_Z = 8,    /* [S] fp32 (ADANERF_SAMPLER_PDF / _COARSE_FINE) */

@@ -427,7 +427,8 @@ def same_bin_sets(r, ref, n_rays, n_max):
     cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (n_rays,))
     off = r.buffer(R.BUF_RAY_OFFSETS, np.int32, (n_rays,))
     total = int(cnt.sum())
-    key = r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (total,))
+    # dense mode keeps no key array: sample i is (ray i >> 7, bin i & 127) by construction (include/adanerf_hip.h)
+    key = np.arange(total, dtype=np.uint32) if r.info.dense else r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (total,))
     bins = np.full((n_rays, n_max), -1, dtype=np.int16)
     slot = np.arange(total) - np.repeat(off, cnt)
     bins[(key >> 7).astype(np.int64), slot] = (key & 127).astype(np.int16)
