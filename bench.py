@@ -403,8 +403,8 @@ def main():
         fused = args.sampling in ("split", "fp16", "guarded") and 0.0 < thr and n_max <= 16 and args.workload not in ("nerf_coarse_fine", "generic_6x128")
         if args.workload == "nerf_coarse_fine":
             comp_bytes, comp_what = None, "fine sampler (not an HBM-bound stage)"
-        elif thr == 0.0:
-            comp_bytes, comp_what = R * 512 + S_loc * 8 + R * 8, "dense_expand_kernel: oracle values in, keys + weights + offsets + counts out"
+        elif thr == 0.0:      # dense: keys are implicit and the oracle buffer is the weight array; only offsets + counts are written
+            comp_bytes, comp_what = R * 8, "dense_offsets_kernel: offsets + counts out (a latency-sized launch, not a bandwidth measurement)"
         elif fused:      # selection ran inside the sampling kernel: the stage is expand_kernel alone
             comp_bytes = R * 4 + S_loc * 5 + R * 4 + S_loc * 8
             comp_what = "expand_kernel: counts + kept (bin, value) rows in, offsets + keys + weights out"
