@@ -170,6 +170,10 @@ def main():
     ap.add_argument("--orbit", type=int, default=0,
                     help="K > 0: step i renders pose i %% K of a K-pose orbit inside the view cell (yaw and position vary) instead of "
                          "the fixed camera; quality / cpu_baseline still refer to pose 0")
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2],
+                    help="N > 1 only: 2 (default there) renders alternate frames on two contexts / streams of the rank, so that the tail "
+                         "rounds, ring prologues and launch gaps of one frame's kernels overlap the next frame's (throughput; a frame's "
+                         "latency doubles); 1: one frame at a time, as on a single GPU")
     ap.add_argument("--dump-image", default=None, help="rank 0 writes the last frame's RGBA8 image [h,w,4] as .npy (tests)")
     args = ap.parse_args()
 
@@ -224,18 +228,34 @@ def main():
                                    guard_eps=args.guard_eps, device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=strip_rows)
     r.init()
     r.set_camera(pose, rot)
+    # N > 1: a share of the frame is a few rounds of each kernel's persistent grid, and what does not shrink with N (the last,
+    # partly filled round, the weight ring's prologue, dependent-launch gaps) is ~15 % of it at N = 8.  Two frames in
+    # flight on two contexts / streams let the next frame's kernels take the CUs a kernel's tail leaves idle.
+    fif = args.frames_in_flight or int(os.environ.get("ADANERF_BENCH_FRAMES_IN_FLIGHT", "0")) or (2 if use_dist else 1)
+    if not use_dist:
+        fif = 1
+    rs = [r]
+    if fif == 2:
+        r_b = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision, sampling=args.sampling,
+                                         guard_eps=args.guard_eps, device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=strip_rows)
+        r_b.init()
+        r_b.set_camera(pose, rot)
+        rs.append(r_b)
     dev = torch.device("cuda", local_rank)
     # Streams: the renderer enqueues on `tstream`; on N > 1 the exchange of frame k (RGBA8 strip payloads -> rank 0
     # over RCCL/xGMI) runs on `cstream` behind an event, so it overlaps the render of frame k+1.  Payload and gather
     # buffers are double-buffered; rank 0 de-interleaves frame k (adanerf_assemble_strips) on `tstream` right after it
     # has enqueued frame k+1.  No host sync anywhere in a step; flush() drains the last frame inside the timed region.
-    tstream = torch.cuda.Stream(device=dev)
-    r.set_stream(tstream.cuda_stream)
+    tstreams = [torch.cuda.Stream(device=dev) for _ in rs]
+    for q, ts in zip(rs, tstreams):
+        q.set_stream(ts.cuda_stream)
+    tstream = tstreams[0]
     n_buf = 2 if use_dist else 1
     outs = [torch.zeros((r.info.rays_local_max, 4), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
     out = outs[0]
-    rgb = torch.zeros((max(r.info.rays_local, 1), 3), dtype=torch.float32, device=dev)
-    gathered = image = cstream = None
+    rgbs = [torch.zeros((max(r.info.rays_local, 1), 3), dtype=torch.float32, device=dev) for _ in rs]
+    rgb = rgbs[0]
+    gathered = image = images = cstream = None
     ev_render = ev_gather = None
     if use_dist:
         cstream = torch.cuda.Stream(device=dev)
@@ -245,15 +265,18 @@ def main():
         if rank == 0:
             gathered = [torch.zeros((world, r.info.rays_local_max, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
             gather_lists = [list(g.unbind(0)) for g in gathered]
-            image = torch.zeros((h * w, 4), dtype=torch.uint8, device=dev)
-    state = {"k": 0, "pending": None, "gathers": 0}
+            images = [torch.zeros((h * w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]      # one per buffer: two frames may be assembling
+            image = images[0]
+    state = {"k": 0, "pending": None, "gathers": 0, "last": 0}
 
     def finish(b):
-        # frame in buffer b: its gather is complete -> de-interleave into the image on the render stream
-        with torch.cuda.stream(tstream):
-            tstream.wait_event(ev_gather[b])
+        # frame in buffer b: its gather is complete -> de-interleave into the image on the stream of the context that rendered it
+        ts, q = tstreams[b % fif], rs[b % fif]
+        with torch.cuda.stream(ts):
+            ts.wait_event(ev_gather[b])
             if rank == 0:
-                r.assemble_strips(gathered[b], image)
+                q.assemble_strips(gathered[b], images[b])
+        state["last"] = b
 
     poses = []
     if args.orbit > 0:
@@ -265,16 +288,17 @@ def main():
             poses.append((ppos.astype(np.float32), prot))
 
     def step():
-        if poses:
-            r.set_camera(*poses[state["k"] % len(poses)])
         b = state["k"] & (n_buf - 1)
+        q, ts = rs[b % fif], tstreams[b % fif]              # two frames in flight: buffer b belongs to context b
+        if poses:
+            q.set_camera(*poses[state["k"] % len(poses)])
         state["k"] += 1
-        with torch.cuda.stream(tstream):
+        with torch.cuda.stream(ts):
             if use_dist and state["k"] > 2:
-                tstream.wait_event(ev_gather[b])            # frame k-2's payload has left this buffer
-            r.render(outs[b], rgb)
+                ts.wait_event(ev_gather[b])                 # frame k-2's payload has left this buffer
+            q.render(outs[b], rgbs[b % fif])
             if use_dist:
-                ev_render[b].record(tstream)
+                ev_render[b].record(ts)
         if use_dist:
             with torch.cuda.stream(cstream):
                 cstream.wait_event(ev_render[b])
@@ -300,7 +324,8 @@ def main():
         step()
     flush()
     fence()
-    r.set_profiling(True)
+    for q in rs:
+        q.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -309,6 +334,15 @@ def main():
     dt = time.perf_counter() - t0
     st, frames = r.collect_stats()
     r.set_profiling(False)
+    for q in rs[1:]:                              # second context of the rank: same record, summed
+        st2, f2 = q.collect_stats()
+        q.set_profiling(False)
+        frames += f2
+        for fld in ("total_samples", "batches", "ms_total", "ms_sample_mlp", "ms_compact", "ms_shade_mlp", "ms_composite", "shade_launches",
+                    "sample_launches", "rays_refined"):
+            setattr(st, fld, getattr(st, fld) + getattr(st2, fld))
+        st.guard_max_seen = max(st.guard_max_seen, st2.guard_max_seen)
+        st.guard_violations += st2.guard_violations
     r.lib.adanerf_get_info(r.handle, r.info)      # the guard band is calibrated at the first guarded frame
     exchange = None
     if dist:
@@ -332,7 +366,7 @@ def main():
         shard_samples = shard_shade_ms = None
 
     if rank == 0 and args.dump_image:
-        np.save(args.dump_image, (image if use_dist else outs[0][:h * w]).cpu().numpy().reshape(h, w, 4))
+        np.save(args.dump_image, (images[state["last"]] if use_dist else outs[0][:h * w]).cpu().numpy().reshape(h, w, 4))
 
     ms_per_step = dt / args.steps * 1e3
     fps = args.steps / dt
@@ -471,6 +505,7 @@ def main():
                           "parallelism": ("image-strip shard x%d (%d-row strips, round-robin) + %s gather overlapped with the next frame" %
                                           (world, strip_rows, "RCCL" if backend == "nccl" else backend)) if use_dist else "single GPU",
                           "exchange": exchange,
+                          "frames_in_flight": fif,
                           "rays_refined_per_frame": (st.rays_refined / frames) if args.sampling == "guarded" else None,
                           "guard": ({"eps": float(r.info.guard_eps), "monitor_max_seen": float(st.guard_max_seen),
                                      "monitor_violations": int(st.guard_violations)} if args.sampling == "guarded" else None),
@@ -483,7 +518,8 @@ def main():
             rec["shards"] = {"samples_per_frame": shard_samples, "shade_ms_per_frame": shard_shade_ms,
                              "sample_imbalance_max_over_mean": max(shard_samples) / mean_s if mean_s > 0 else None}
         print(json.dumps(rec))
-    r.close()
+    for q in rs:
+        q.close()
     if dist:
         dist.destroy_process_group()
 
