@@ -112,8 +112,12 @@ def cpu_baseline(model_dir, w, h, pose, rot, budget_s=10.0):
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
-    T = 4 if avail >= 8 else max(1, avail // 2)
-    P = max(1, min(avail // T, 64, h // 2))
+    # Threads in total = half the logical CPUs (the hosts of this pool are SMT-2: 256 logical = 128 cores; measured on one,
+    # profiles/r03_cpu_baseline_split.log: 64 x 2 threads 0.119 frames/s, 32 x 4 0.113, 64 x 4 0.088, 128 x 2 0.081, 16 x 16 0.058)
+    T = 2 if avail >= 8 else 1
+    P = max(1, min((avail // 2) // T if avail >= 8 else avail, 64, h // 2))
+    if os.environ.get("ADANERF_CPU_PT"):      # "P,T": try another split of the host's cores (tools/r03_call11.sh)
+        P, T = (int(x) for x in os.environ["ADANERF_CPU_PT"].split(","))
     band = h // P
     sync = tempfile.mkdtemp(prefix="adanerf_cpu_")
     cam = os.path.join(sync, "cam.npy")
