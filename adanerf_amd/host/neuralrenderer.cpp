@@ -32,6 +32,8 @@ static adanerf_options options_of(const Settings& settings) {
   opt.batch_rays = static_cast<int32_t>(settings.batch_size);
   opt.num_samples = settings.num_samples;
   opt.threshold = settings.threshold;
+  opt.sampling_mode = settings.sampling == "split" ? ADANERF_SAMPLING_SPLIT_FP16 : (settings.sampling == "fp32" ? ADANERF_SAMPLING_FP32
+                      : (settings.sampling == "fp16" ? ADANERF_SAMPLING_FP16 : ADANERF_SAMPLING_GUARDED));
   opt.shard_world = 1;
   return opt;
 }
@@ -59,6 +61,8 @@ bool NeuralRenderer::init() {
   opt.precision = settings.precision == "fp32" ? ADANERF_PREC_FP32 : (settings.precision == "fp16" ? ADANERF_PREC_FP16 : ADANERF_PREC_BF16);
   opt.num_samples = settings.num_samples;
   opt.threshold = settings.threshold;
+  opt.sampling_mode = settings.sampling == "split" ? ADANERF_SAMPLING_SPLIT_FP16 : (settings.sampling == "fp32" ? ADANERF_SAMPLING_FP32
+                      : (settings.sampling == "fp16" ? ADANERF_SAMPLING_FP16 : ADANERF_SAMPLING_GUARDED));
   // --gpus N: rows are cut into strips, strip s belongs to GPU s % N; largest strip height <= 8 rows that
   // gives every GPU the same number of strips
   const int world = settings.gpus;

@@ -14,6 +14,8 @@ class Settings {
   // headless extras (not in the reference)
   int frames = 100;             // --frames: frames to render before exiting
   std::string precision = "bf16";
+  std::string sampling = "guarded";   // --sampling guarded|split|fp32|fp16: arithmetic of the sampling network (ADANERF_SAMPLING_*); the
+                                      // viewer itself has one (TensorRT kFP16 = "fp16"); "guarded" keeps the exact engine's selections
   float yaw = -80.f, pitch = 0.f;   // Camera::init defaults (camera.cpp:90-91)
   int num_samples = 0;
   float threshold = -1.f;

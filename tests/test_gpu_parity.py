@@ -832,7 +832,7 @@ def test_headless_cli_matches_library(cases, tmp_path):
     row_bytes = (w * 3 + 3) & ~3
     px = np.frombuffer(bmp[off:off + row_bytes * h], dtype=np.uint8).reshape(h, row_bytes)[:, :w * 3].reshape(h, w, 3)
     img = px[::-1, :, ::-1]                                                       # bottom-up BGR -> top-down RGB
-    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, w, h, batch_size=5000), precision="bf16") as r:
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, w, h, batch_size=5000), precision="bf16", sampling="guarded") as r:      # the CLI's default
         pose = np.array(sc.view_cell_center, dtype=np.float32)
         r.set_camera(pose, O.camera_rotation(100.0, 0.0))
         _, rgba, _ = r.render_numpy()
@@ -875,7 +875,7 @@ def test_headless_cli_scripted_input_session(cases, tmp_path, end_in_oracle_view
     assert abs(yaw - (-80.0 - 50 * 0.15)) < 1e-4 and abs(pitch - (-20 * 0.15)) < 1e-4
     assert last[11] == ("oracle" if end_in_oracle_view else "image")
     img = _bmp_pixels(os.path.join(md, "out.bmp"), w, h)
-    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, w, h), precision="bf16") as r:
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, w, h), precision="bf16", sampling="guarded") as r:      # the CLI's default
         r.set_camera(pos, O.camera_rotation(yaw, pitch))
         if end_in_oracle_view:
             image = r.empty((w * h, 4), np.uint8)
