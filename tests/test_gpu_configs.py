@@ -541,3 +541,48 @@ def test_other_encodings_match_the_reference(name, tmp_path_factory):
             record("encoding_frame", case=name, prec=prec, psnr_db=p)
             assert p > min_psnr, (prec, p)
             assert abs(int(st.total_samples) - int(ref["count"].sum())) <= residual_budget(w * h) * sc.num_samples
+
+
+# ---------------------------------------------------------------------------------------------
+# Guarded two-precision selection at BASELINE size: config 2 over several poses, config 4, config 5
+# ---------------------------------------------------------------------------------------------
+
+def _selection_of(r, n_rays):
+    st = r.render(None, None, stats=True)
+    cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (n_rays,))
+    key = r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (int(st.total_samples),))
+    return st, cnt, key
+
+
+@pytest.mark.parametrize("workload", ["config2_poses", "config4", "config5_thr02"])
+def test_guarded_selection_at_full_size(classroom, ndc, workload, tmp_path_factory):
+    """The bit-exact part of the contract for the mode bench.py measures: at 800 x 800 (config 2 at four poses inside the view cell,
+    config 4's threshold 0.1) and 1920 x 1080 NDC (config 5 shape) the guarded mode's sample counts and keys equal the
+    split-precision engine's on every ray, with the band calibrated by the library and the monitor silent."""
+    if workload == "config5_thr02":
+        z, meta, sc, wts, d = ndc
+        w, h = 1920, 1080
+        poses = [(z["pose"], z["rot"])]
+    else:
+        z, meta, sc, wts = classroom
+        sc = dataclasses.replace(sc, threshold=0.1) if workload == "config4" else sc
+        d = _dir(tmp_path_factory, sc, wts, "guard_" + workload)
+        w = h = 800
+        c, size = np.array(sc.view_cell_center, np.float32), np.array(sc.view_cell_size, np.float32)
+        poses = [(z["pose"], z["rot"])]
+        if workload == "config2_poses":
+            poses += [((c + 0.3 * size * np.array(o, np.float32)).astype(np.float32), O.camera_rotation(yaw, pitch))
+                      for o, yaw, pitch in (((0.4, -0.3, 0.2), 10.0, -15.0), ((-0.45, 0.4, -0.3), 200.0, 20.0), ((0.1, 0.45, 0.4), 300.0, 0.0))]
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="split") as rs, \
+            adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded") as rg:
+        for i, (pose, rot) in enumerate(poses):
+            rs.set_camera(pose, rot)
+            rg.set_camera(pose, rot)
+            st_s, cnt_s, key_s = _selection_of(rs, w * h)
+            st_g, cnt_g, key_g = _selection_of(rg, w * h)
+            rg.lib.adanerf_get_info(rg.handle, rg.info)
+            record("guarded_full_size", workload=workload, pose=i, rays=w * h, refined=int(st_g.rays_refined), eps=float(rg.info.guard_eps),
+                   monitor_max_seen=float(st_g.guard_max_seen), violations=int(st_g.guard_violations), samples=int(st_g.total_samples))
+            assert st_g.total_samples == st_s.total_samples and np.array_equal(cnt_g, cnt_s) and np.array_equal(key_g, key_s)
+            assert st_g.guard_violations == 0 and st_g.guard_max_seen <= rg.info.guard_eps
+            assert 0 < st_g.rays_refined < w * h
