@@ -1090,6 +1090,31 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_share_one_gpu(tmp_path):
+    """The driver's N = 8 launch line on this box's one GPU (gloo exchange): 5-row strips, two frames in flight per rank
+    (sixteen contexts on the device), eight gathers per frame set; the assembled frame equals the single-rank frame."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one, eight = str(tmp_path / "one.npy"), str(tmp_path / "eight.npy")
+    a = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--dump-image", one, "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-speed-mode"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0, a.stderr[-2000:]
+    env = dict(os.environ, ADANERF_BENCH_DIST_BACKEND="gloo", ADANERF_BENCH_ONE_DEVICE="1")
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29771", "bench.py", "--gpus", "8", "--dump-image", eight, "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-2000:]
+    lines = [ln for ln in b.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, b.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["config"]["frames_in_flight"] == 2 and rec["config"]["exchange"]["world_size"] == 8
+    assert len(rec["shards"]["samples_per_frame"]) == 8 and rec["shards"]["sample_imbalance_max_over_mean"] < 1.02
+    assert np.array_equal(np.load(one), np.load(eight))
+
+
+@pytest.mark.gpu
 def test_oracle_debug_view(cases):
     """adanerf_copy_result_sampling_network / adanerf_render_oracle (viewer 'O' key) vs the restated samplesToImage."""
     z, meta, sc, wts, d = cases["classroom_n8_thr02"]
