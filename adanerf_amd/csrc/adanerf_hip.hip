@@ -63,6 +63,7 @@ struct adanerf_ctx {
   GenericTopo gen0{}, gen1{};
   DevBuf rsi_z;                   // [ray_samples] world depths of the raySampleInput points
   int shade_gen_grid = 0;
+  int shade_gen16_grid[2][2] = {{0, 0}, {0, 0}};      // [fine | coarse net][bf16 | fp16]: resident workgroups of the run-time-shaped 16-bit kernel
 
   PackedDev net0;                 // sampling net, fp32 fragments (exact engine)
   PackedDev net0_split;           // sampling net, fp16 hi/lo' fragment pairs (split-precision engine)
@@ -530,9 +531,26 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
   a.rays_out = d_rays;
   dim3 grid((n_rays + 127) / 128), block(256);
   const bool full = c->fp0 == 10 && c->fd0 == 4;
-  if (c->generic0) {      // any other topology / raySampleInput: run-time-shaped fp32 kernel, whatever sampling_mode asks for
+  if (c->generic0) {      // any other topology / encoding layout / raySampleInput: run-time-shaped kernels, no fused selection
     if (sel) return fail(c, ADANERF_EINVAL, "fused selection is not available on the generic sampling kernel");
-    HIP_TRY(c, launch_sample_mlp_gen(a, c->gen0, c->enc0, c->topo0.width, grid.x, c->stream));
+    if (c->sampling_mode != ADANERF_SAMPLING_FP32 && c->ray_samples == 0 && c->net0_split.w.p) {
+      // split-precision engine (fp32-class accuracy at 3 / 16 of the fp32-MFMA cycle count), fragments straight from L2
+#define ADN_GENS(FPv, FDv, Wv) hipLaunchKernelGGL((sample_mlp16x3_gen_kernel<FPv, FDv, Wv, tune::kGenericStaged>), grid, block, 0, c->stream, a, c->gen0)
+#define ADN_GENS_W(FPv, FDv)                                   \
+  do {                                                         \
+    if (c->topo0.width == 64) ADN_GENS(FPv, FDv, 64);          \
+    else if (c->topo0.width == 128) ADN_GENS(FPv, FDv, 128);   \
+    else ADN_GENS(FPv, FDv, 256);                              \
+  } while (0)
+      if (c->enc0 == kEnc10_4) ADN_GENS_W(10, 4);
+      else if (c->enc0 == kEnc2_2) ADN_GENS_W(2, 2);
+      else ADN_GENS_W(kMaxBands, kMaxBands);
+#undef ADN_GENS_W
+#undef ADN_GENS
+      HIP_TRY(c, hipGetLastError());
+      return ADANERF_OK;
+    }
+    HIP_TRY(c, launch_sample_mlp_gen(a, c->gen0, c->enc0, c->topo0.width, grid.x, c->stream));      // exact fp32 MFMA (and raySampleInput)
     return ADANERF_OK;
   }
   // Guarded two-precision selection: plain fp16 for every ray, then the split engine on the rays the guard band flagged.
@@ -780,11 +798,30 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
   a.max_samples = max_samples;
   a.raw_out = d_raw;
   if (generic && prec != ADANERF_PREC_FP32) {
-    // any topology / encoding layout on the 16-bit MFMA pipe (k_generic16.hip.hpp): fragments straight from L2
+    // any topology / encoding layout on the 16-bit MFMA pipe (k_generic16.hip.hpp)
     const int enc = coarse ? enc_layout(c->fp0, c->fd0, false) : c->enc1;
-    const int tiles = (max_samples + 127) / 128;
-    const int grid = std::min(tiles, 2 * c->info.compute_units);
-#define ADN_GEN16(ET, FPv, FDv, Wv) hipLaunchKernelGGL((shade_mlp16_gen_kernel<ET, FPv, FDv, Wv>), dim3(grid), dim3(256), 0, c->stream, a, gen)
+    // staged: one copy of every weight tile per workgroup through LDS, NB 32-sample blocks per wave; else fragments straight from L2.
+    // Persistent grid = the workgroups the chosen instantiation really keeps resident (registers and LDS differ per width / layout).
+    const bool st = tune::kGenericStaged;
+    const int nb_wg = !st ? 1 : topo.width == 64 ? gen_blocks<64>() : topo.width == 128 ? gen_blocks<128>() : gen_blocks<256>();
+    const int per_wg = 128 * nb_wg;
+    const int tiles = (max_samples + per_wg - 1) / per_wg;
+    int& grid16 = c->shade_gen16_grid[coarse ? 1 : 0][prec == ADANERF_PREC_BF16 ? 0 : 1];
+#define ADN_GEN16_GO(KERNEL)                                                                                             \
+  do {                                                                                                                   \
+    if (!grid16) {                                                                                                       \
+      int per_cu = 0;                                                                                                    \
+      HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 256, 0));                                 \
+      grid16 = (per_cu < 1 ? 1 : per_cu) * c->info.compute_units;                                                        \
+    }                                                                                                                    \
+    hipLaunchKernelGGL(KERNEL, dim3(std::min(tiles, grid16)), dim3(256), 0, c->stream, a, gen);                          \
+  } while (0)
+#define ADN_GEN16(ET, FPv, FDv, Wv)                                                                                      \
+  do {                                                                                                                   \
+    if constexpr (tune::kGenericStaged)                                                                                  \
+      ADN_GEN16_GO((shade_mlp16_gen_staged_kernel<ET, FPv, FDv, Wv, gen_blocks<Wv>(), gen_occupancy<Wv>()>));            \
+    else ADN_GEN16_GO((shade_mlp16_gen_kernel<ET, FPv, FDv, Wv>));                                                       \
+  } while (0)
 #define ADN_GEN16_W(ET, FPv, FDv)                                  \
   do {                                                             \
     if (topo.width == 64) ADN_GEN16(ET, FPv, FDv, 64);             \
@@ -800,6 +837,8 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
     }
 #undef ADN_GEN16_W
 #undef ADN_GEN16
+#undef ADN_GEN16_GO
+    HIP_TRY(c, hipGetLastError());
   } else if (generic) {
     const int enc = coarse ? enc_layout(c->fp0, c->fd0, false) : c->enc1;
     if (!gen_grid) HIP_TRY(c, shade_mlp_gen_grid(c->info.compute_units, enc, topo.width, &gen_grid));
@@ -968,7 +1007,8 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     if (!pack_sampling_net(n0, sh, Elem::F32, &p0, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
     c->topo0 = p0.topo;
     c->generic0 = !p0.topo.is_default(false) || c->enc0 == kEncMax;
-    if (!c->generic0 && !pack_sampling_net(n0, sh, Elem::F16_SPLIT, &p0s, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
+    // the split-precision packing: the ring-streamed kernel's for the 8 x 256 net, the run-time-shaped kernel's otherwise (not with raySampleInput)
+    if ((!c->generic0 || c->ray_samples == 0) && !pack_sampling_net(n0, sh, Elem::F16_SPLIT, &p0s, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
   }
   c->sampling_mode = opt->sampling_mode;
   c->guard_eps = opt->guard_eps > 0.f ? opt->guard_eps : 0.f;      // 0: calibrated before the first guarded frame
@@ -1018,7 +1058,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     c->genc = GenericTopo{c->topoc.depth, c->topoc.skip, 0, 0, nullptr, 0.f};
   } else {
     if ((rc = upload_net(c, p0, &c->net0))) return bail(rc, c->err);
-    if (!c->generic0 && (rc = upload_net(c, p0s, &c->net0_split))) return bail(rc, c->err);
+    if ((!c->generic0 || c->ray_samples == 0) && (rc = upload_net(c, p0s, &c->net0_split))) return bail(rc, c->err);
   }
   if (c->ray_samples > 0) {
     if ((rc = dev_alloc(c, &c->rsi_z, ms.rsi_z.size() * sizeof(float)))) return bail(rc, c->err);

@@ -212,8 +212,12 @@ bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, Pac
   T.width = find(net0, "layers.0.weight", err)->rows();     // exists: depth >= 2
   T.ray_samples = sh.ray_samples;
   if (T.width % 32 != 0 || T.width < 32 || T.width > 512) return fail(err, "sampling net: width " + std::to_string(T.width) + " (multiples of 32 up to 512 supported)");
-  if ((!T.is_default(false) || sh.lp0 || sh.ld0) && elem != Elem::F32)
-    return fail(err, "sampling net: only the 8 x 256 topology without raySampleInput and with a 10-4 or 2-2 encoding runs on the 16-bit engines");
+  // plain 16-bit fragments: the ring-streamed kernel of the 8 x 256 / 10-4 or 2-2 net only; the (hi, lo') split pairs pack for any
+  // topology and layout without raySampleInput (k_generic16.hip.hpp); raySampleInput is fp32 only (K-major block, emit_ray_samples)
+  const bool special = T.is_default(false) && !sh.lp0 && !sh.ld0;
+  if (!special && elem != Elem::F32 && !(elem == Elem::F16_SPLIT && sh.ray_samples == 0))
+    return fail(err, "sampling net: only the 8 x 256 topology without raySampleInput and with a 10-4 or 2-2 encoding runs on the plain 16-bit engine "
+                     "(the split-precision packing exists for every topology without raySampleInput)");
   for (int i = 0; i < T.depth; ++i) {
     const Tensor* W = find(net0, "layers." + std::to_string(i) + ".weight", err);
     const Tensor* B = find(net0, "layers." + std::to_string(i) + ".bias", err);

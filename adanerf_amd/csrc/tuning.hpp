@@ -39,6 +39,34 @@ constexpr int kRingSlotsSampling = ADN_RS_S;
 #else
 constexpr int kRingSlotsSampling = 6;
 #endif
+// ---- run-time-shaped 16-bit kernels (k_generic16.hip.hpp) -------------------------------------------------------------
+// kGenericStaged: weights of one output tile staged through LDS for the whole workgroup (false: every wave fetches its own
+// fragments from L2 -- the experiment baseline of profiles/r03_generic_staged.md); kGenericBlocks128 / 256: 32-sample blocks per
+// wave of the staged shading kernel at that width (2: one workgroup per CU with 512 registers per wave; 1 at width 128: two
+// workgroups per CU).  Measured: 1 at width 128 (0.94 vs 1.03 ms), 2 at width 256 (2.82 vs 3.42 ms).
+#if ADN_OVERRIDABLE && defined(ADN_GEN_STAGED)
+constexpr bool kGenericStaged = ADN_GEN_STAGED != 0;
+#else
+constexpr bool kGenericStaged = true;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_GEN_NB128)
+constexpr int kGenericBlocks128 = ADN_GEN_NB128;
+#else
+constexpr int kGenericBlocks128 = 1;
+#endif
+// workgroups per CU asked of the compiler at width 128 (0: 1 with two blocks per wave, 2 with one).  Measured on 6 x 128: one block,
+// 2 per CU 0.944 ms; two blocks, 1 per CU 1.03; two blocks, 2 per CU (45 registers spilled) 0.875; one block, 3 per CU (168
+// registers, the 10-4 layout only -- the 16-band layout needs 184 and stays at 2) 0.889: shipped
+#if ADN_OVERRIDABLE && defined(ADN_GEN_OCC128)
+constexpr int kGenericOcc128 = ADN_GEN_OCC128;
+#else
+constexpr int kGenericOcc128 = 3;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_GEN_NB256)
+constexpr int kGenericBlocks256 = ADN_GEN_NB256;
+#else
+constexpr int kGenericBlocks256 = 2;
+#endif
 // layer_16 / layer_16x3 with every LDS read and wait issued by hand (HsLayer, HsLayer3) instead of compiler-scheduled
 // re-fills (the compiler-scheduled forms remain as the experiment baseline)
 #if ADN_OVERRIDABLE && defined(ADN_HANDSCHED)

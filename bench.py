@@ -15,6 +15,7 @@ Rank 0 prints ONE JSON line (see README / DESIGN.md for the field meanings).
 """
 import argparse
 import json
+import re
 import os
 import sys
 import tempfile
@@ -44,13 +45,22 @@ WORKLOADS = {
     # a topology other than 8 x 256 / skip 4 -- both networks 6 x 128 (skip 2), random init.  The sampling network runs
     # on the run-time-shaped exact-fp32 kernel, the shading network on the run-time-shaped 16-bit kernel.  Not a BASELINE configuration.
     "generic_6x128": (800, 800, 8, 0.65, "generic_6x128_random_init"),
+    "generic_4x64": (800, 800, 8, 0.65, "generic_4x64_random_init"),        # the other two widths of the run-time-shaped kernels
+    "generic_5x256": (800, 800, 8, 0.65, "generic_5x256_random_init"),
 }
+
+
+def generic_shape(tag):
+    """(layers, width, skip) of a generic_<L>x<W>_random_init workload, None for the others"""
+    m = re.match(r"generic_(\d+)x(\d+)_random_init$", tag)
+    return (int(m.group(1)), int(m.group(2)), int(m.group(1)) // 3) if m else None
 
 
 def shade_flop_per_sample(tag):
     """2 x MACs of the shading network per sample (SURVEY 8d counts the 8 x 256 one: 593 408 MAC)"""
-    if tag == "generic_6x128_random_init":
-        w, d, skip, n_pos, n_dir = 128, 6, 2, 63, 27
+    if generic_shape(tag):
+        d, w, skip = generic_shape(tag)
+        n_pos, n_dir = 63, 27
         mac = n_pos * w + sum((w + n_pos if i == skip + 1 else w) * w for i in range(1, d)) + w * w + w + (w + n_dir) * (w // 2) + (w // 2) * 3
         return 2 * mac
     return SHADE_FLOP_PER_SAMPLE
@@ -72,11 +82,12 @@ def build_model_dir(td, tag, n, thr):
         n0, n1 = M.random_init_weights(7, n_in0=30, oracle_bias=-0.55, oracle_scale=0.5)
         s = dict(view_cell_center=(0.0, 0.0, 0.0), view_cell_size=(2.0, 2.0, 1.0), depth_range=(0.9, 12.0), fov=1.0, max_depth=12.0)
         data = "synthetic rays; random-init weights (seed 7), NDC / linear depth / 2-2 oracle encoding"
-    elif tag == "generic_6x128_random_init":
-        n0, n1 = M.random_init_weights(21, layers=(6, 6), widths=(128, 128), skip1=2)
+    elif generic_shape(tag):
+        gl, gw, gs = generic_shape(tag)
+        n0, n1 = M.random_init_weights(21, layers=(gl, gl), widths=(gw, gw), skip1=gs)
         s = dict(view_cell_center=(0.783, -3.19, 1.39), view_cell_size=(0.7, 0.7, 0.2),
                  depth_range=(0.1542200982570648, 8.358194804191589), fov=1.1386263370513916, max_depth=8.79825210571289)
-        data = "synthetic rays; random-init weights (seed 21), both networks 6 x 128 / skip 2"
+        data = "synthetic rays; random-init weights (seed 21), both networks %d x %d / skip %d" % (gl, gw, gs)
     elif tag == "nerf_pair_random_init":
         n0, n1 = M.random_init_nerf_pair(3)
         s = dict(view_cell_center=(0.783, -3.19, 1.39), view_cell_size=(0.7, 0.7, 0.2),
@@ -218,7 +229,7 @@ def main():
         dist.barrier()
 
     w, h, n_max, thr, tag = WORKLOADS[args.workload]
-    generic_wl = args.workload == "generic_6x128"
+    generic_wl = args.workload.startswith("generic_")
     if args.threshold is not None:
         thr = args.threshold
     td = tempfile.mkdtemp(prefix="adanerf_bench_%d_" % rank)
@@ -387,8 +398,8 @@ def main():
         flop_per_launch = flop_per_sample * (st.total_samples / launches)
         achieved = flop_per_launch / (shade_ms * 1e-3) / 1e12 if shade_ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
-        kname = "shade_mlp%s_kernel" % ("32" if args.precision == "fp32" else ("16x2" if tag != "generic_6x128_random_init" else "16_gen"))
-        if tag == "generic_6x128_random_init" and args.precision == "fp32":
+        kname = "shade_mlp%s_kernel" % ("32" if args.precision == "fp32" else ("16x2" if not generic_shape(tag) else "16_gen_staged"))
+        if generic_shape(tag) and args.precision == "fp32":
             kname = "shade_mlp32_gen_kernel"
         # HBM bytes per launch of this kernel: PMC counters cannot be read from inside this process, so they come from the
         # committed rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh -> profiles/).  A summary is used
@@ -426,19 +437,21 @@ def main():
         exec_mult = {"split": 3.0, "fp16": 1.0, "fp32": 1.0, "guarded": 1.0 + 3.0 * refined / max(R, 1)}[args.sampling]
         smp_peak = PEAK_TFLOPS["fp32" if args.sampling == "fp32" else "fp16"]
         smp_flop = SAMPLE_FLOP_PER_RAY
-        if generic_wl:      # 6 x 128 oracle net on the exact-fp32 engine whatever --sampling says
-            smp_flop = 2 * (90 * 128 + 4 * 128 * 128 + 128 * 128)
+        gen_fp32 = generic_wl and args.sampling == "fp32"
+        if generic_wl:      # 6 x 128 oracle net: run-time-shaped kernels, split-precision pairs unless --sampling fp32 (no plain-fp16 pass)
+            gl, gw, _ = generic_shape(tag)
+            smp_flop = 2 * (90 * gw + (gl - 2) * gw * gw + gw * 128)
             smp_tflops *= smp_flop / SAMPLE_FLOP_PER_RAY
-            exec_mult, smp_peak = 1.0, PEAK_TFLOPS["fp32"]
+            exec_mult, smp_peak = (1.0, PEAK_TFLOPS["fp32"]) if gen_fp32 else (3.0, PEAK_TFLOPS["fp16"])
         smp_ms = st.ms_sample_mlp / frames
         sampling_roofline = {"bound": "mfma", "stage": "ray generation + encoding + sampling MLP (+ fused selection; guarded: + list + refinement pass)",
-                             "engine": "fp32 (run-time-shaped)" if generic_wl else args.sampling, "avg_ms_per_frame": smp_ms, "flop_per_ray": smp_flop,
+                             "engine": ("fp32 (run-time-shaped)" if gen_fp32 else "split-fp16 (run-time-shaped)") if generic_wl else args.sampling, "avg_ms_per_frame": smp_ms, "flop_per_ray": smp_flop,
                              "achieved_algorithmic": smp_tflops, "achieved_executed": smp_tflops * exec_mult, "peak": smp_peak, "unit": "TFLOP/s",
                              "frac_algorithmic": smp_tflops / smp_peak, "frac_executed": smp_tflops * exec_mult / smp_peak,
                              "rays_refined_per_frame": refined if args.sampling == "guarded" else None}
         # HBM-side view of the two bandwidth-bound stages: bytes the stage's kernels move by construction
         S_loc = samples_per_frame_local
-        fused = args.sampling in ("split", "fp16", "guarded") and 0.0 < thr and n_max <= 16 and args.workload not in ("nerf_coarse_fine", "generic_6x128")
+        fused = args.sampling in ("split", "fp16", "guarded") and 0.0 < thr and n_max <= 16 and args.workload != "nerf_coarse_fine" and not generic_wl
         if args.workload == "nerf_coarse_fine":
             comp_bytes, comp_what = None, "fine sampler (not an HBM-bound stage)"
         elif thr == 0.0:      # dense: keys are implicit and the oracle buffer is the weight array; only offsets + counts are written
@@ -502,8 +515,8 @@ def main():
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": args.precision, "data": data,
                "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, %s shading MLP %s, sampling MLP %s" %
-                                      (args.workload, w, h, n_max, thr, "6x128" if generic_wl else "8x256", args.precision,
-                                       "6x128 on the run-time-shaped exact-fp32 kernel" if generic_wl else
+                                      (args.workload, w, h, n_max, thr, args.workload[8:] if generic_wl else "8x256", args.precision,
+                                       ("%s on the run-time-shaped %s kernel" % (args.workload[8:], "exact-fp32" if args.sampling == "fp32" else "split-fp16")) if generic_wl else
                                        {"split": "split-fp16 (3 MFMAs per term)", "fp32": "fp32 MFMA", "fp16": "plain fp16 (opt-in speed mode)",
                                         "guarded": "guarded two-precision (plain fp16, split-fp16 on the rays inside the band)"}[args.sampling]),
                           "parallelism": ("image-strip shard x%d (%d-row strips, round-robin) + %s gather overlapped with the next frame" %

@@ -162,9 +162,9 @@ def run_shading_net(net: PackedNet, x, dpe, fp=10, fd=4):
 def run_sampling_net_generic(net: PackedNet, dir_unit, p, nds, fp, fd, rsi_z=None, rsi_d1=1.0):
     """depth = number of layer records (minus the raySampleInput record); layer 0 optionally extended by the K-major
     block of the A extra points p + nds z_a (encode(x / d1), identity slots scaled back by d1)."""
-    assert net.precision == 2
     lay = net.lay
     has_rsi = rsi_z is not None and len(rsi_z) > 0
+    assert net.precision == 2 or (net.precision == 3 and not has_rsi)      # split pairs: sample_mlp16x3_gen_kernel
     depth = lay.shape[0] - (1 if has_rsi else 0)
     act0 = np.concatenate([pe_eval(dir_unit, fd), pe_eval(p, fp)], axis=1)
     if not has_rsi:

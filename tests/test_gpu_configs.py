@@ -335,10 +335,18 @@ def test_generic_topologies_match_the_reference(name, tmp_path_factory):
     cnt, bins, _ = O.select_adaptive(orc, sc.num_samples, sc.threshold)
     same = (cnt == z["sel_count"]) & (bins == z["sel_bins"]).all(axis=1)
     check_identical(same, "generic_topology_selection", 0, case=name)      # against the reference's own selection (fixture)
+    # the sampling net on the two run-time-shaped engines: split-precision pairs (default) vs exact fp32 MFMA -- same selection
+    if not sc.ray_sample_input:
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, meta["w"], meta["h"]), precision="bf16", sampling="fp32") as r:
+            r.set_camera(z["pose"], z["rot"])
+            orc32 = run_rows(r, meta, lambda f, n, b: r.sample_mlp(f, n, b, None), 128)
+        assert 0 < np.abs(orc32 - orc).max() < 3e-5            # two different engines, 22-bit vs 24-bit operands
+        c32, b32, _ = O.select_adaptive(orc32, sc.num_samples, sc.threshold)
+        assert (c32 == cnt).all() and (b32 == bins).all()
     # whole small frames against the oracle, both precisions requested
     w, h = 96, 64
     ref = O.render_rays(O.generate_ray_directions(w, h, sc.fov), z["pose"], z["rot"], sc, wts, w, h, keep=True)
-    # the sampling net of these models runs on the exact fp32 engine whatever is asked; the shading net in the precision asked for
+    # the sampling net of these models runs on the split-precision (raySampleInput: fp32) run-time-shaped kernel; the shading net in the precision asked for
     for prec, min_psnr in (("fp32", 90.0), ("fp16", 72.0), ("bf16", 50.0)):
         with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=2500), precision=prec) as r:
             r.set_camera(z["pose"], z["rot"])

@@ -235,14 +235,22 @@ def test_generic_topologies_pack_and_reproduce_the_reference(lib, tmp_path, name
         wq, bq, layq = pack_weights(lib, d, 1, prec)
         outq = run_shading_net_generic(PackedNet(wq, bq, layq, prec), feat[:, 0:3], feat[:, 63:66], depth, syn["widths"][1], skips[0] if skips else -1)
         assert np.abs(outq - ref).max() < tol and np.sqrt(np.mean((outq - ref) ** 2)) < tol / 6
-    # the sampling net's 16-bit engines are specialised to 8 x 256 without raySampleInput
+    # the sampling net: plain 16-bit fragments only for 8 x 256 (ring-streamed kernel); the split-precision pairs for every
+    # topology without raySampleInput (sample_mlp16x3_gen_kernel), reproducing the reference's outputs like the fp32 packing
     f = lib.adanerf_host_pack_weights
     wb, bf, nl = C.c_size_t(0), C.c_size_t(0), C.c_int32(0)
     default0 = (syn["layers"][0], syn["widths"][0]) == (8, 256) and not sc.ray_sample_input
-    rc = f(d.encode(), 0, 3, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl))
+    rc = f(d.encode(), 0, 1, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl))
     assert (rc == 0) == default0, rc
     if not default0:
         assert b"16-bit" in lib.adanerf_last_error(None)
+    rc = f(d.encode(), 0, 3, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl))
+    assert (rc == 0) == (default0 or not sc.ray_sample_input), rc
+    if rc == 0:
+        ws, bs, lays = pack_weights(lib, d, 0, 3)
+        orc_s = run_sampling_net_generic(PackedNet(ws, bs, lays, 3), u, z["p"][:n], nds, fp, fd)
+        np.testing.assert_allclose(orc_s, z["oracle_out"][:n], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(orc_s, orc, rtol=0, atol=2e-5)        # 22-bit operands vs the fp32 fragments
 
 
 @pytest.mark.parametrize("name", ENCODING_CASES)
@@ -282,8 +290,13 @@ def test_other_encodings_pack_into_the_catch_all_layout(lib, tmp_path, name):
         assert np.abs(outq - ref).max() < tol and np.sqrt(np.mean((outq - ref) ** 2)) < tol / 6
     f = lib.adanerf_host_pack_weights
     wb, bf, nl = C.c_size_t(0), C.c_size_t(0), C.c_int32(0)
-    assert f(d.encode(), 0, 3, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl)) != 0      # sampling net: split engine is 10-4 / 2-2 only
+    assert f(d.encode(), 0, 1, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl)) != 0      # plain fp16 sampling: 10-4 / 2-2 only
     assert b"16-bit" in lib.adanerf_last_error(None)
+    ws, bs, lays = pack_weights(lib, d, 0, 3)              # the split-precision pairs in the 16-band layout (sample_mlp16x3_gen_kernel)
+    assert int(lays[0, 2]) == 2 * 56
+    orc_s = run_sampling_net_generic(PackedNet(ws, bs, lays, 3), u, z["p"][:n], nds, 16, 16)
+    np.testing.assert_allclose(orc_s, z["oracle_out"][:n], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(orc_s, orc, rtol=0, atol=3e-5)
 
 
 def test_product_path_fails_loudly_without_gpu(lib, tmp_path):
