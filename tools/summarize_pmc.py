@@ -17,7 +17,8 @@ import sys
 
 root = sys.argv[1]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-names = {"shade_mlp16x2": "shade_mlp16x2_kernel", "shade_mlp16_gen": "shade_mlp16_gen_kernel", "shade_mlp32_gen": "shade_mlp32_gen_kernel",
+names = {"shade_mlp16x2": "shade_mlp16x2_kernel", "shade_mlp16_gen_staged": "shade_mlp16_gen_staged_kernel", "sample_mlp16x3_gen": "sample_mlp16x3_gen_kernel",
+         "shade_mlp16_gen": "shade_mlp16_gen_kernel", "shade_mlp32_gen": "shade_mlp32_gen_kernel",
          "sample_mlp_gen": "sample_mlp_gen_kernel", "refine_list": "refine_list_kernel",
          "shade_mlp16": "shade_mlp16_kernel", "shade_mlp32": "shade_mlp32_kernel", "sample_mlp16x3": "sample_mlp16x3_kernel",
          "sample_mlp16_kernel": "sample_mlp16_kernel", "sample_mlp_kernel": "sample_mlp_kernel", "select_kernel": "select_kernel",
