@@ -513,6 +513,11 @@ int occupancy_grid(adanerf_ctx* c, K kernel, int threads, int* out) {
 
 int calibrate_guard(adanerf_ctx* c, int n_poses, uint32_t seed, bool install, float* max_diff);
 
+// a sampling net of another topology / layout on the split-precision run-time-shaped kernel (else: the fp32 one)
+bool generic_split_sampling(const adanerf_ctx* c) {
+  return c->generic0 && c->sampling_mode != ADANERF_SAMPLING_FP32 && c->ray_samples == 0 && c->net0_split.w.p != nullptr;
+}
+
 // sel != nullptr: the adaptive selection runs in the kernel's epilogue (k_select_pair.hip.hpp) and d_oracle may be null
 int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle, float* d_rays, const SelectOut* sel = nullptr) {
   if (n_rays <= 0) return ADANERF_OK;
@@ -532,8 +537,7 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
   dim3 grid((n_rays + 127) / 128), block(256);
   const bool full = c->fp0 == 10 && c->fd0 == 4;
   if (c->generic0) {      // any other topology / encoding layout / raySampleInput: run-time-shaped kernels, no fused selection
-    if (sel) return fail(c, ADANERF_EINVAL, "fused selection is not available on the generic sampling kernel");
-    if (c->sampling_mode != ADANERF_SAMPLING_FP32 && c->ray_samples == 0 && c->net0_split.w.p) {
+    if (generic_split_sampling(c)) {
       // split-precision engine (fp32-class accuracy at 3 / 16 of the fp32-MFMA cycle count), fragments straight from L2
 #define ADN_GENS(FPv, FDv, Wv) hipLaunchKernelGGL((sample_mlp16x3_gen_kernel<FPv, FDv, Wv, tune::kGenericStaged>), grid, block, 0, c->stream, a, c->gen0)
 #define ADN_GENS_W(FPv, FDv)                                   \
@@ -550,6 +554,7 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
       HIP_TRY(c, hipGetLastError());
       return ADANERF_OK;
     }
+    if (sel) return fail(c, ADANERF_EINVAL, "fused selection is not available on the fp32 run-time-shaped sampling kernel");
     HIP_TRY(c, launch_sample_mlp_gen(a, c->gen0, c->enc0, c->topo0.width, grid.x, c->stream));      // exact fp32 MFMA (and raySampleInput)
     return ADANERF_OK;
   }
@@ -1499,7 +1504,8 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
       if ((rc = launch_sample_fine(c, rawc, rays, n, off, cnt, key, reinterpret_cast<float*>(c->sample_z.p), total))) return rc;
     }
     // adaptive selection in the epilogue of the sampling kernel: the [R,128] oracle values never reach HBM
-    const bool fused = !pdf && thr > 0.f && use_pair_select(c, N) && c->sampling_mode != 1 && !c->generic0 && !(c->opt.flags & ADANERF_FLAG_KEEP_ORACLE);
+    const bool fused = !pdf && thr > 0.f && use_pair_select(c, N) && c->sampling_mode != 1 && (!c->generic0 || generic_split_sampling(c)) &&
+                       !(c->opt.flags & ADANERF_FLAG_KEEP_ORACLE);
     if (cfm) {
       rc = ADANERF_OK;
     } else if (fused) {

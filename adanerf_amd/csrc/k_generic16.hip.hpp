@@ -402,7 +402,7 @@ template <int FP, int FD, int W, bool STAGED>
 __global__ __launch_bounds__(256, (STAGED && (W == 64 || (W == 128 && FP <= 10))) ? 2 : 1) void sample_mlp16x3_gen_kernel(SampleArgs a, GenericTopo t) {
   constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP, MT = W / 32, KW = W / 16;
   constexpr int BUF = (Q0 / 8 > KW ? Q0 / 8 : KW) * 2048;
-  __shared__ __attribute__((aligned(1024))) char stage_mem[STAGED ? 2 * BUF : 16];
+  __shared__ __attribute__((aligned(1024))) char stage_mem[(STAGED ? 2 * BUF : 0) + 4 * kPairLdsBytesPerWave];      // + staging block of the fused selection
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -470,6 +470,16 @@ __global__ __launch_bounds__(256, (STAGED && (W == 64 || (W == 128 && FP <= 10))
       }
     }
     layer_16x3_direct<KW, 4, true>(w + a.net16.w_off[t.depth - 1], b + a.net16.b_off[t.depth - 1], lane, bH, bL, nullptr, nullptr, out);
+  }
+  if (a.fused_select) {
+    // A4 in the epilogue, as in sample_mlp16x3_kernel: the 128 raw outputs of ray j sit in lanes j and j + 32 (k_select_pair.hip.hpp)
+    const uint32_t sel_stage = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(stage_mem)) + (STAGED ? 2 * BUF : 0) + wave * kPairLdsBytesPerWave + lane * 16;
+    float z = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) z = __builtin_fmaf(out[i], 0.f, z);    // NaN iff some output is inf / NaN (fp16 range left)
+    const bool bad_ray = (z != z) | (__shfl_xor(static_cast<int>(z != z), 32) != 0);
+    if (bad_ray && valid && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
+    pair_epilogue(out, lane, local, valid, sel_stage, a.sel);
   }
   if (valid) {
     if (a.oracle_out) {

@@ -451,7 +451,8 @@ def main():
                              "rays_refined_per_frame": refined if args.sampling == "guarded" else None}
         # HBM-side view of the two bandwidth-bound stages: bytes the stage's kernels move by construction
         S_loc = samples_per_frame_local
-        fused = args.sampling in ("split", "fp16", "guarded") and 0.0 < thr and n_max <= 16 and args.workload != "nerf_coarse_fine" and not generic_wl
+        fused = args.sampling in ("split", "fp16", "guarded") and 0.0 < thr and n_max <= 16 and args.workload != "nerf_coarse_fine" and \
+            not (generic_wl and args.sampling == "fp32")      # (the run-time-shaped split-precision sampling kernel fuses it too)
         if args.workload == "nerf_coarse_fine":
             comp_bytes, comp_what = None, "fine sampler (not an HBM-bound stage)"
         elif thr == 0.0:      # dense: keys are implicit and the oracle buffer is the weight array; only offsets + counts are written

@@ -78,6 +78,9 @@ enum {
                                       is fused into the sampling kernel (adaptive sampler, N <= 16, threshold > 0, 8 x 256
                                       net); everywhere else this mode runs the split-precision engine alone. */
 };
+/* Sampling nets of another topology / encoding layout (run-time-shaped kernels): ADANERF_SAMPLING_FP32 runs the exact fp32
+ * kernel, every other mode the split-precision one (same arithmetic as ADANERF_SAMPLING_SPLIT_FP16; no plain-fp16 pass);
+ * with raySampleInput always the fp32 kernel. */
 
 /* sample placement (config.ini rayMarchSampler[1]) */
 enum {
@@ -384,9 +387,9 @@ int adanerf_host_parse_model(const char* model_dir, const adanerf_options* opt, 
  *   layer_out    per layer {w_off (16-B units), b_off (floats), slots per lane-half, 32-row tiles}
  *                as int32[4] each                (*n_layers); a sampling net with raySampleInput = A > 0 has one more
  *                record {w_off of layer 0's K-major block for the A extra points, A, slots per point, tiles}.
- * The shading net packs in every precision for every topology; a sampling net other than 8 x 256 with a 10-4 / 2-2 encoding
- * and without raySampleInput packs for ADANERF_PREC_FP32 only (it runs on the run-time-shaped fp32 kernel) and the 16-bit
- * precisions return ADANERF_EIO with a message. */
+ * The shading net packs in every precision for every topology.  A sampling net other than 8 x 256 with a 10-4 / 2-2 encoding
+ * packs for ADANERF_PREC_FP32 (run-time-shaped fp32 kernel) and, without raySampleInput, as split pairs (3: run-time-shaped
+ * split-precision kernel); the plain 16-bit precisions -- and the split pairs with raySampleInput -- return ADANERF_EIO with a message. */
 int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precision, void* weights_out,
                               size_t* weights_bytes, float* bias_out, size_t* bias_floats, int32_t* layer_out,
                               int32_t* n_layers);

@@ -112,8 +112,12 @@ def one_case(rng, idx):
         sc = dataclasses.replace(sc, accumulation_mult=str(rng.choice(["weights", "", "alpha"])),
                                  losses0=str(rng.choice(["NeRFWeightMultiplicationLoss", "NeRFWeightMultiplicationLoss", "MSE"])))
     # (not for "enc": a 128-term transmittance product over un-trained weights amplifies the 1e-3 differences the high bands of a
-    # 12-band encoding make in single raw outputs -- the stages are compared one by one in tests/test_gpu_configs.py instead)
-    if rng.random() < 0.08 and kind not in ("ndc", "pdf", "pdf_ce", "transform", "coarse_fine", "cf_ndc", "enc"):
+    # 12-band encoding make in single raw outputs -- the stages are compared one by one in tests/test_gpu_configs.py instead.
+    # Not for "rsi" either: the un-trained sampling net with 90 + 63 A inputs emits values of several units, which dense mode uses
+    # as the 128 weights of a ray -- factors 1 - alpha w far outside [0, 1], colours up to |1e5| (seed 4102 case 36, seed 4103
+    # case 19), and the 2e-3 feature differences of the 2^9 band (tests/test_gpu_configs.py) come out as 2e-3 .. 4e-3 relative in
+    # fp32.  Same numbers to the last digit from the library of the round before the staged kernels: profiles/r03_fuzz_case19_ab.log.)
+    if rng.random() < 0.08 and kind not in ("ndc", "pdf", "pdf_ce", "transform", "coarse_fine", "cf_ndc", "enc", "rsi"):
         n_max, thr = 128, 0.0                     # dense mode
     if kind in ("pdf", "pdf_ce"):
         n_max, thr = int(rng.choice([2, 4, 8, 16, 32])), sc.threshold
@@ -168,10 +172,6 @@ def one_case(rng, idx):
         # random sampling nets emit weights outside [0, 1]: alpha * w then leaves [0, 1], the transmittance product
         # can grow and colours reach |10| -- bounds are relative to the ray's colour magnitude there
         e = np.abs(a - b).max(axis=1) / np.maximum(1.0, np.abs(b).max(axis=1))
-        # ... and past |1e3| the composite has diverged (128 factors 1 - alpha w > 1 each: seed 4102 case 36 reaches -3.4e6 on one
-        # ray, where the fp32 kernels and the oracle agree to 1.7e-3 relative and every library build to the last bit): such a
-        # colour measures the conditioning of that product, not the renderer -- those rays are left out of the bound
-        e = np.where(np.abs(b).max(axis=1) > 1e3, 0.0, e)
         if e.size == 0:
             return 0.0
         return float(e[same].max()) if (cnt is not None and same.any()) else float(np.quantile(e, 0.97))
