@@ -313,8 +313,8 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
     uint32_t hA[64], hB[64];
     {
       float t[Q0];
-      pe_eval<FD, !(tune::kAblateSample & 128)>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
-      pe_eval<FP, !(tune::kAblateSample & 128)>(p, h, t + QD);
+      pe_eval<FD, !(tune::kAblateSample & 128) && !tune::kFastPeFp16Pass>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
+      pe_eval<FP, !(tune::kAblateSample & 128) && !tune::kFastPeFp16Pass>(p, h, t + QD);
       uint32_t in0[Q0 / 2];
 #pragma unroll
       for (int q = 0; q < Q0 / 2; ++q) in0[q] = Fp16::pack(t[2 * q], t[2 * q + 1]);

@@ -39,6 +39,15 @@ constexpr int kRingSlotsSampling = ADN_RS_S;
 #else
 constexpr int kRingSlotsSampling = 6;
 #endif
+// plain-fp16 sampling kernel (speed mode, first pass of the guarded mode): encoding through one v_sin_f32 per slot instead of the
+// fp32-parity sin_or_cos -- its values are rounded to fp16 right after (2.4e-4), the guard band is calibrated with whatever this
+// kernel computes.  Measured (profiles/r03_variants_fast_pe.log): sampling stage 1.014 -> 0.980 ms, calibrated band and refined
+// rays unchanged (6.5525e-3 / 249 183 -> 6.5535e-3 / 249 226)
+#if ADN_OVERRIDABLE && defined(ADN_FAST_PE16)
+constexpr bool kFastPeFp16Pass = ADN_FAST_PE16 != 0;
+#else
+constexpr bool kFastPeFp16Pass = true;
+#endif
 // ---- run-time-shaped 16-bit kernels (k_generic16.hip.hpp) -------------------------------------------------------------
 // kGenericStaged: weights of one output tile staged through LDS for the whole workgroup (false: every wave fetches its own
 // fragments from L2 -- the experiment baseline of profiles/r03_generic_staged.md); kGenericBlocks128 / 256: 32-sample blocks per
