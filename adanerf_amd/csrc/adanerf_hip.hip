@@ -49,6 +49,13 @@ struct adanerf_ctx {
   bool profiling = false;
   int prof_frames = 0;
   std::vector<int32_t*> pinned_totals;   // one pinned int32 per recorded batch
+  // always-on monitor of the guarded selection (ADANERF_SAMPLING_GUARDED): the device's running {largest difference seen, violations} copied
+  // to pinned memory after every frame and looked at before the next one -- a violated band is widened (poll_guard)
+  int32_t* guard_host = nullptr;
+  hipEvent_t guard_ev = nullptr;
+  bool guard_ev_pending = false;
+  int guard_viol_seen = 0;
+  int guard_widened = 0;
   adanerf_stats folded{};                // profiling record folded out of a full event pool (see adanerf_render)
 
   RayGenParams rg{};
@@ -1164,6 +1171,8 @@ int adanerf_destroy(adanerf_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
   for (int32_t* p : c->pinned_totals) (void)hipHostFree(p);
+  if (c->guard_host) (void)hipHostFree(c->guard_host);
+  if (c->guard_ev) (void)hipEventDestroy(c->guard_ev);
   DevBuf* bufs[] = {&c->net0_split.w, &c->net0_split.b, &c->net0_f16.w, &c->net0_f16.b, &c->overflow, &c->net0.w, &c->net0.b, &c->net1[0].w, &c->net1[0].b, &c->net1[1].w, &c->net1[1].b, &c->net1[2].w, &c->net1[2].b,
                     &c->ztab, &c->rays, &c->oracle, &c->ray_offsets, &c->ray_counts, &c->selbin, &c->selw, &c->block_total,
                     &c->block_offset, &c->total, &c->sample_key, &c->sample_w, &c->raw, &c->sample_z, &c->rsi_z,
@@ -1397,6 +1406,7 @@ int sum_stats(adanerf_ctx* c, adanerf_stats* stats) {
   stats->rays_refined += f.rays_refined;
   stats->guard_max_seen = std::max(stats->guard_max_seen, f.guard_max_seen);
   stats->guard_violations = std::max(stats->guard_violations, f.guard_violations);
+  stats->guard_widened = c->guard_widened;
   stats->ms_total += f.ms_total;
   stats->ms_sample_mlp += f.ms_sample_mlp;
   stats->ms_compact += f.ms_compact;
@@ -1439,9 +1449,38 @@ int adanerf_render_oracle(adanerf_ctx* c, void* d_rgba8) {
   return ADANERF_OK;
 }
 
+namespace {
+
+// The band of the guarded selection is an assumption (|fp16 output - split output| <= guard_eps) that the second pass samples on every
+// re-evaluated ray.  If a frame saw it violated, every later frame runs with a band of ADANERF_GUARD_CALIB_MARGIN x the largest
+// difference seen so far (adanerf_info.guard_eps follows, adanerf_stats.guard_widened counts).  Non-blocking: looks only at a copy
+// that has already arrived.
+void poll_guard(adanerf_ctx* c) {
+  if (!c->guard_ev_pending) return;
+  const hipError_t q = hipEventQuery(c->guard_ev);
+  (void)hipGetLastError();      // hipErrorNotReady is not a failure of this context
+  if (q != hipSuccess) return;
+  c->guard_ev_pending = false;
+  float seen;
+  std::memcpy(&seen, &c->guard_host[0], sizeof(seen));
+  const int viol = c->guard_host[1];
+  if (viol > c->guard_viol_seen) {
+    c->guard_viol_seen = viol;
+    const float wider = ADANERF_GUARD_CALIB_MARGIN * seen;
+    if (wider > c->guard_eps) {
+      c->guard_eps = wider;
+      c->info.guard_eps = wider;
+      ++c->guard_widened;
+    }
+  }
+}
+
+}  // namespace
+
 int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* stats) {
   if (!c) return ADANERF_EINVAL;
   BIND(c);
+  poll_guard(c);
   const int R = c->info.rays_local, B = c->info.batch_rays, N = c->info.num_samples;
   const float thr = c->info.threshold;
   const int n_batches = R > 0 ? (R + B - 1) / B : 0;
@@ -1555,9 +1594,20 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
       c->events_used += 5;
     }
   }
+  if (c->sampling_mode == ADANERF_SAMPLING_GUARDED && c->guard_mask.p && n_batches > 0 && !c->guard_ev_pending) {
+    if (!c->guard_host) {
+      HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->guard_host), 2 * sizeof(int32_t)));
+      c->guard_host[0] = c->guard_host[1] = 0;
+      HIP_TRY(c, hipEventCreateWithFlags(&c->guard_ev, hipEventDisableTiming));
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->guard_host, total + 8, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(c->guard_ev, c->stream));
+    c->guard_ev_pending = true;
+  }
   if (record) c->prof_frames++;
   if (stats) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    poll_guard(c);
     if ((rc = sum_stats(c, stats))) return rc;
     stats->rays = R;
     if (n_batches > 0 && record) {   // wall span of this frame, first launch -> last kernel end

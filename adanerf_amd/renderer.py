@@ -52,7 +52,7 @@ class Stats(C.Structure):
                 ("ms_sample_mlp", C.c_float), ("ms_compact", C.c_float), ("ms_shade_mlp", C.c_float),
                 ("ms_composite", C.c_float), ("shade_launches", C.c_int32), ("sample_launches", C.c_int32),
                 ("sampling_overflow", C.c_int32), ("rays_refined", C.c_int32), ("guard_max_seen", C.c_float),
-                ("guard_violations", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("guard_violations", C.c_int32), ("guard_widened", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_last_error", "adanerf_set_camera",
@@ -344,6 +344,11 @@ class NeuralRenderer:
         self._check(self.lib.adanerf_compact_guarded(self.handle, _ptr(oracle_approx), _ptr(oracle_exact), n_rays, n_max, thr, eps,
                                                      _ptr(ray_offsets), _ptr(ray_counts), _ptr(sample_key), _ptr(sample_w), _ptr(total),
                                                      _ptr(refined)))
+
+    def refresh_info(self) -> "Info":
+        """Re-reads adanerf_info (guard_eps moves when the band is calibrated or widened after a violation)."""
+        self._check(self.lib.adanerf_get_info(self.handle, C.byref(self.info)))
+        return self.info
 
     def calibrate_guard(self, n_poses: int = 8, seed: int = 1, install: bool = False) -> float:
         """Largest |plain-fp16 - split-precision| raw output over n_poses x 4096 calibration rays; install=True makes

@@ -526,7 +526,7 @@ def main():
                           "frames_in_flight": fif,
                           "rays_refined_per_frame": (st.rays_refined / frames) if args.sampling == "guarded" else None,
                           "guard": ({"eps": float(r.info.guard_eps), "monitor_max_seen": float(st.guard_max_seen),
-                                     "monitor_violations": int(st.guard_violations)} if args.sampling == "guarded" else None),
+                                     "monitor_violations": int(st.guard_violations), "band_widened": int(st.guard_widened)} if args.sampling == "guarded" else None),
                           "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame,
                           "camera": ("%d-pose orbit inside the view cell" % args.orbit) if poses else "fixed: view-cell centre, yaw 100 deg"},
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,

@@ -181,8 +181,12 @@ typedef struct adanerf_stats {
   float   guard_max_seen;     /* ... largest |fp16 - split| seen since create on the re-evaluated rays' top value (the
                                  assumption behind the band, sampled on every frame) */
   int32_t guard_violations;   /* ... re-evaluated rays (since create) where that difference exceeded the band: if this is
-                                 not 0 the band is too narrow for this model -- raise guard_eps or use SPLIT_FP16 */
-  int32_t reserved[2];
+                                 not 0 the band was too narrow for this model; the library widens it for the frames that
+                                 follow (guard_widened), frames before that may hold rays selected by the fp16 engine */
+  int32_t guard_widened;      /* ... times (since create) the library widened the band after a frame reported violations: every
+                                 later frame runs with ADANERF_GUARD_CALIB_MARGIN x the largest difference seen
+                                 (adanerf_info.guard_eps is the band in force) */
+  int32_t reserved[1];
 } adanerf_stats;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */

@@ -662,6 +662,39 @@ def test_guard_calibration(cases):
     assert O.psnr(rgb, rgb_s) > 60.0
 
 
+def test_guard_band_widens_itself_after_a_violation(cases):
+    """The always-on monitor: a context created with a band that is too narrow for the model (1e-3: the config-2 frame has
+    rays whose fp16 outputs are off by up to 4.7e-3) sees violations on its first frame, widens the band to 2 x the largest
+    difference seen before a later frame, and from then on selects exactly what the split engine selects."""
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    w, h = 400, 320
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="split") as r:
+        r.set_camera(z["pose"], z["rot"])
+        r.render_numpy()
+        cnt_s = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,)).copy()
+        key_s = r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (int(cnt_s.sum()),)).copy()
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded", guard_eps=1e-3) as r:
+        r.set_camera(z["pose"], z["rot"])
+        assert abs(r.info.guard_eps - 1e-3) < 1e-9
+        rgb, rgba, st0 = r.render_numpy()                   # synchronous: the monitor's copy of this frame is looked at right away
+        assert st0.guard_violations > 0 and st0.guard_widened == 1
+        eps = r.refresh_info().guard_eps
+        assert abs(eps - 2.0 * st0.guard_max_seen) < 1e-7 and eps > 2e-3
+        rgb, rgba, st1 = r.render_numpy()                   # rendered with the wider band
+        cnt_g = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,)).copy()
+        key_g = r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (int(cnt_g.sum()),)).copy()
+        out = r.empty((w * h, 4), np.uint8)
+        for _ in range(3):                                  # asynchronous frames: the band is polled, never waited for
+            r.render(out, None)
+        r.sync()
+        rgb, rgba, st2 = r.render_numpy()
+    record("guard_self_widening", first_band=1e-3, violations_first_frame=int(st0.guard_violations), band_after=eps,
+           violations_after=int(st2.guard_violations), widened=int(st2.guard_widened), rays_refined=int(st1.rays_refined))
+    assert st1.guard_violations == st0.guard_violations == st2.guard_violations      # cumulative counter: no new ones under the wider band
+    assert st2.guard_widened == 1
+    assert np.array_equal(cnt_g, cnt_s) and np.array_equal(key_g, key_s)
+
+
 def test_render_is_deterministic(cases):
     z, meta, sc, wts, d = cases["classroom_n8_thr02"]
     with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, 200, 160), precision="bf16") as r:
