@@ -175,6 +175,13 @@ bool NeuralRenderer::render() {
     err = adanerf_last_error(ctx);
     return false;
   }
+  if (st.guard_widened > guard_widened_seen) {      // the guarded selection's monitor saw its band violated and widened it (adanerf_hip.h)
+    guard_widened_seen = st.guard_widened;
+    adanerf_info now;
+    if (adanerf_get_info(ctx, &now) == ADANERF_OK)
+      std::cout << "guarded sampling: " << st.guard_violations << " re-evaluated rays differed by more than the band (largest " << st.guard_max_seen
+                << "); band widened to " << now.guard_eps << " for the following frames" << std::endl;
+  }
   s_inference1 += st.ms_sample_mlp;
   s_inference2 += st.ms_shade_mlp;
   s_fc2 += st.ms_compact;

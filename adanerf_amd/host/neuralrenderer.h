@@ -38,5 +38,6 @@ class NeuralRenderer {
   // 100-frame running sums
   int logging_interval = 100, sample_count = 0;
   double s_inference1 = 0, s_inference2 = 0, s_fc2 = 0, s_rm = 0, s_total = 0;
+  int guard_widened_seen = 0;        // adanerf_stats.guard_widened already reported on the console
   long long s_num_total_samples = 0;
 };
