@@ -203,6 +203,55 @@ __device__ __forceinline__ float wave_max_f32(float v) {
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// ---- wave64 float reductions / scans on DPP --------------------------------------------------------------------------------------
+// The float butterflies of the one-wave-per-ray compositing kernels used to go through __shfl_xor / __shfl_up (ds_bpermute_b32).
+// Next to OTHER kernels on the same GPU (several contexts: strip shards on one device, two frames in flight) composite_wave_kernel
+// then dropped one lane's contribution from the first of its three sums on about one ray in 10^4 -- same inputs, every kernel alone
+// reproducible (tools/probes/dense_stage_isolation.py, profiles/r03_dense_shard_flake.md).  These forms stay inside the VALU:
+// in-row DPP steps, then readlane across the four rows.  Fixed association, so results are reproducible by construction.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float old, float v) {      // lanes without a source (or outside ROW_MASK) keep `old`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// sum over the wave, every lane gets it: ((row sums by 4 butterflies) r0 + r1) + (r2 + r3)
+__device__ __forceinline__ float wave_sum_dpp_f32(float v) {
+  v += dpp_f32<0xB1>(0.f, v);       // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(0.f, v);       // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(0.f, v);      // row_half_mirror
+  v += dpp_f32<0x140>(0.f, v);      // row_mirror
+  const int x = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+// inclusive scans over the wave (lane i: op of lanes 0..i): four row_shr steps inside each row of 16, then row_bcast:15 into rows 1 / 3
+// and row_bcast:31 into rows 2 / 3 (the gfx9 scan of LLVM's AMDGPUAtomicOptimizer)
+__device__ __forceinline__ float wave_incl_prod_dpp_f32(float v) {
+  v *= dpp_f32<0x111>(1.f, v);
+  v *= dpp_f32<0x112>(1.f, v);
+  v *= dpp_f32<0x114>(1.f, v);
+  v *= dpp_f32<0x118>(1.f, v);
+  v *= dpp_f32<0x142, 0xA>(1.f, v);
+  v *= dpp_f32<0x143, 0xC>(1.f, v);
+  return v;
+}
+__device__ __forceinline__ float wave_incl_sum_dpp_f32(float v) {
+  v += dpp_f32<0x111>(0.f, v);
+  v += dpp_f32<0x112>(0.f, v);
+  v += dpp_f32<0x114>(0.f, v);
+  v += dpp_f32<0x118>(0.f, v);
+  v += dpp_f32<0x142, 0xA>(0.f, v);
+  v += dpp_f32<0x143, 0xC>(0.f, v);
+  return v;
+}
+// lane i gets lane i - 1's value, lane 0 gets `first` (wave_shr:1)
+__device__ __forceinline__ float wave_shift_up1_f32(float first, float v) { return dpp_f32<0x138>(first, v); }
+__device__ __forceinline__ float wave_last_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ int mbcnt64(uint64_t mask) {

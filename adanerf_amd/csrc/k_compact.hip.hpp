@@ -95,11 +95,7 @@ __device__ __forceinline__ void select_ray(float v0, float v1, int lane, int n_m
 }
 
 // wave-wide sum (every lane gets it)
-__device__ __forceinline__ float wave_sum_all_f32(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
+__device__ __forceinline__ float wave_sum_all_f32(float v) { return wave_sum_dpp_f32(v); }
 
 // the sampler's transform of a ray's 128 raw outputs held two per lane (kOracle*, k_select_pair.hip.hpp)
 __device__ __forceinline__ void oracle_transform_wave(int transform, float* v0, float* v1) {

@@ -106,17 +106,8 @@ __global__ __launch_bounds__(RB) void composite_kernel(const float4* __restrict_
 }
 
 // Long rays (dense mode: 128 samples each): one wave per ray, lane holds samples (lane, lane + 64);
-// transmittance = exclusive product scan of (1 - alpha + 1e-10) across the wave, colour = wave sum.
+// transmittance = exclusive product scan of (1 - alpha + 1e-10) across the wave, colour = wave sum (DPP forms of k_common.hip.hpp).
 // Coalesced 16-byte loads instead of one thread striding through 2 KiB per ray.
-__device__ __forceinline__ float wave_incl_prod_f32(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float t = __shfl_up(v, off);
-    if (lane >= off) v *= t;
-  }
-  return v;
-}
-
 __global__ __launch_bounds__(256) void composite_wave_kernel(const float4* __restrict__ raw, const float* __restrict__ sample_w,
                                                              const int32_t* __restrict__ ray_offsets, const int32_t* __restrict__ counts,
                                                              int n_rays, int mult_mode, float* __restrict__ rgb_out, uchar4* __restrict__ rgba8_out,
@@ -144,14 +135,10 @@ __global__ __launch_bounds__(256) void composite_wave_kernel(const float4* __res
     }
   }
   const float f0 = __fadd_rn(__fsub_rn(1.0f, al[0]), 1e-10f), f1 = __fadd_rn(__fsub_rn(1.0f, al[1]), 1e-10f);
-  const float p0 = wave_incl_prod_f32(lane + 0 < c ? f0 : 1.0f, lane);
-  const float tot0 = __shfl(p0, 63);
-  const float p1 = wave_incl_prod_f32(lane + 64 < c ? f1 : 1.0f, lane);
-  float e0 = __shfl_up(p0, 1), e1 = __shfl_up(p1, 1);      // exclusive products
-  if (lane == 0) {
-    e0 = 1.0f;
-    e1 = 1.0f;
-  }
+  const float p0 = wave_incl_prod_dpp_f32(lane + 0 < c ? f0 : 1.0f);
+  const float tot0 = wave_last_f32(p0);
+  const float p1 = wave_incl_prod_dpp_f32(lane + 64 < c ? f1 : 1.0f);
+  const float e0 = wave_shift_up1_f32(1.0f, p0), e1 = wave_shift_up1_f32(1.0f, p1);      // exclusive products
   const float w0 = al[0] * e0, w1 = al[1] * (tot0 * e1);
   float cr = w0 * col[0][0] + w1 * col[1][0], cg = w0 * col[0][1] + w1 * col[1][1], cb = w0 * col[0][2] + w1 * col[1][2];
   if (aux.depth || aux.acc) {      // weights of the two samples of this lane (mult_mode 2 scales the weight, not alpha)
@@ -163,22 +150,16 @@ __global__ __launch_bounds__(256) void composite_wave_kernel(const float4* __res
     float dm = q0 * ((lane < c) ? aux.ztab[(aux.sample_key ? aux.sample_key[o + lane] : static_cast<uint32_t>(o + lane)) & 127u] : 0.f) +
                q1 * ((lane + 64 < c) ? aux.ztab[(aux.sample_key ? aux.sample_key[o + lane + 64] : static_cast<uint32_t>(o + lane + 64)) & 127u] : 0.f);
     float am = q0 + q1;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      dm += __shfl_xor(dm, off);
-      am += __shfl_xor(am, off);
-    }
+    dm = wave_sum_dpp_f32(dm);
+    am = wave_sum_dpp_f32(am);
     if (lane == 0) {
       if (aux.depth) aux.depth[r] = dm;
       if (aux.acc) aux.acc[r] = am;
     }
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    cr += __shfl_xor(cr, off);
-    cg += __shfl_xor(cg, off);
-    cb += __shfl_xor(cb, off);
-  }
+  cr = wave_sum_dpp_f32(cr);
+  cg = wave_sum_dpp_f32(cg);
+  cb = wave_sum_dpp_f32(cb);
   if (lane == 0) {
     if (rgb_out) {
       rgb_out[3 * static_cast<size_t>(r) + 0] = cr;

@@ -3,7 +3,7 @@
 #pragma once
 #include "k_common.hip.hpp"
 #include "k_compact.hip.hpp"
-#include "k_composite.hip.hpp"      // wave_incl_prod_f32
+#include "k_composite.hip.hpp"
 
 namespace adanerf {
 
@@ -16,19 +16,9 @@ struct DepthMap {          // warped depth t in [0,1] -> world depth (src/util/d
   int32_t log_transform;   // 1: (d1-d0+1)^t - 1 + d0, 0: t (d1-d0) + d0
 };
 
-__device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-__device__ __forceinline__ float wave_incl_scan_f32(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float t = __shfl_up(v, off);
-    if (lane >= off) v += t;
-  }
-  return v;
-}
+// wave sums / scans: the DPP forms of k_common.hip.hpp (see there for why not __shfl)
+__device__ __forceinline__ float wave_sum_f32(float v) { return wave_sum_dpp_f32(v); }
+__device__ __forceinline__ float wave_incl_scan_f32(float v, int) { return wave_incl_sum_dpp_f32(v); }
 
 // FromClassifiedDepth.generate + nerf_sample_pdf(det=True) (src/nerf_raymarch_common.py:606-660, 160-192):
 // transform(oracle) + 1e-5 (sigmoid for DONeRF's BCEWithLogitsLoss; softmax / none for the other losses) -> pdf -> cdf over
@@ -51,7 +41,7 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const float* __restrict
     const float tot = wave_sum_f32(w0 + w1);
     const float p0 = w0 / tot, p1 = w1 / tot;
     const float cA = wave_incl_scan_f32(p0, lane);
-    const float totA = __shfl(cA, 63);
+    const float totA = wave_last_f32(cA);
     const float cB = totA + wave_incl_scan_f32(p1, lane);
     if (lane == 0) cdf[0] = 0.f;
     cdf[1 + lane] = cA;
@@ -157,25 +147,21 @@ __global__ __launch_bounds__(256) void composite_classic_wave_kernel(const float
       al = __fsub_rn(1.0f, expf(-__fmul_rn(fmaxf(v.w, 0.f), dist)));
     }
     const float f = (k < n) ? __fadd_rn(__fsub_rn(1.0f, al), 1e-10f) : 1.0f;
-    const float p = wave_incl_prod_f32(f, lane);
-    float e = __shfl_up(p, 1);
-    if (lane == 0) e = 1.0f;
+    const float p = wave_incl_prod_dpp_f32(f);
+    const float e = wave_shift_up1_f32(1.0f, p);
     const float wt = __fmul_rn(al, __fmul_rn(T, e));
     cr += wt * sigmoidf_dev(v.x);
     cg += wt * sigmoidf_dev(v.y);
     cb += wt * sigmoidf_dev(v.z);
     dm += wt * zk;
     am += wt;
-    T = __fmul_rn(T, __shfl(p, 63));
+    T = __fmul_rn(T, wave_last_f32(p));
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    cr += __shfl_xor(cr, off);
-    cg += __shfl_xor(cg, off);
-    cb += __shfl_xor(cb, off);
-    dm += __shfl_xor(dm, off);
-    am += __shfl_xor(am, off);
-  }
+  cr = wave_sum_dpp_f32(cr);
+  cg = wave_sum_dpp_f32(cg);
+  cb = wave_sum_dpp_f32(cb);
+  dm = wave_sum_dpp_f32(dm);
+  am = wave_sum_dpp_f32(am);
   if (lane != 0) return;
   if (depth_out) depth_out[r] = dm;
   if (acc_out) acc_out[r] = am;

@@ -196,6 +196,16 @@ def one_case(rng, idx):
         # is a step function of the sign of its density, so a bf16-sized error on a density near zero turns a transparent
         # ray opaque.  The bound is therefore on the 97th percentile of the per-ray error in this mode.
         e = np.abs(rgb16 - ref["rgb"]).max(axis=1) / np.maximum(1.0, np.abs(ref["rgb"]).max(axis=1))
+        # ... and the rays the reference itself marks as sitting on that step -- last-sample density within the bf16 engine's raw
+        # error bound (0.25: tests/test_host_cpu.py, shading net replayed in bf16) of zero -- are left out before the percentile is taken: with un-trained nets and few rays they can be more
+        # than 3 % of the frame (seed 5301 case 88: 63 x 6 rays, 97th percentile 0.126 against the 0.12 bound, worst ray a
+        # transparent one turned opaque; same numbers from the library of the commit before the staged kernels,
+        # profiles/r03_fuzz_case88_ab.log)
+        if "raw" in ref and e.size and len(ref["raw"]) == int(ref["count"].sum()) and (ref["count"] == ref["count"][0]).all():
+            sig_last = ref["raw"].reshape(e.size, int(ref["count"][0]), 4)[:, -1, 3]
+            keep = np.abs(sig_last) >= 0.25
+            if keep.sum() >= 0.5 * e.size:
+                e = e[keep]
         e16 = float(np.quantile(e, 0.97)) if e.size else 0.0
     else:
         e16 = worst(rgb16, ref["rgb"])

@@ -695,6 +695,48 @@ def test_guard_band_widens_itself_after_a_violation(cases):
     assert np.array_equal(cnt_g, cnt_s) and np.array_equal(key_g, key_s)
 
 
+def test_dense_frames_next_to_other_contexts(cases):
+    """Regression for profiles/r03_dense_shard_flake.md: three strip shards of a dense frame rendered by three contexts on this GPU,
+    launches interleaved, 40 frames each -- every frame of a context must be the context's first frame (the one-wave-per-ray
+    compositing kernel used to drop a term of its first sum about once per 10^4 rays next to other kernels), and the assembled
+    frame must be the unsharded one."""
+    import dataclasses
+    z, meta, sc, wts, d0 = cases["barbershop_n4_thr015"]
+    sc = dataclasses.replace(sc, num_samples=128, threshold=0.0)
+    import tempfile
+    d = tempfile.mkdtemp()
+    O.write_model_dir(d, sc, wts)
+    w, h, world, rows, M = 40, 24, 3, 8, 40
+    pose = np.array(sc.view_cell_center, np.float32)
+    rot = O.camera_rotation(30.0, 5.0)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16") as r:
+        r.set_camera(pose, rot)
+        base = r.render_numpy()[1].copy()
+    rs = [adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", shard_rank=k, shard_world=world, strip_rows=rows)
+          for k in range(world)]
+    try:
+        for q in rs:
+            q.init()
+            q.set_camera(pose, rot)
+        bufs = [[q.empty((q.info.rays_local, 4), np.uint8) for _ in range(M)] for q in rs]
+        for i in range(M):
+            for q, b in zip(rs, bufs):
+                q.render(b[i], None)
+        for q in rs:
+            q.sync()
+        from adanerf_amd import sharding
+        bad = 0
+        for k, bb in enumerate(bufs):
+            o = [b.numpy() for b in bb]
+            bad += sum(not np.array_equal(x, o[0]) for x in o[1:])
+            assert np.array_equal(o[0], base[sharding.local_to_pixel(w, h, rows, world, k)])
+        record("dense_frames_next_to_other_contexts", contexts=world, frames_each=M, frames_differing=int(bad))
+        assert bad == 0
+    finally:
+        for q in rs:
+            q.close()
+
+
 def test_render_is_deterministic(cases):
     z, meta, sc, wts, d = cases["classroom_n8_thr02"]
     with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, 200, 160), precision="bf16") as r:
