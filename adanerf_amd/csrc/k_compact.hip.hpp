@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const float* __restric
     float z = 0.f;
 #pragma unroll
     for (int i = 0; i < 64; ++i) z = __builtin_fmaf(x[i], 0.f, z);
-    bad = (z != z) | (__shfl_xor(static_cast<int>(z != z), 32) != 0);
+    bad = (z != z) | (pair_xchg(static_cast<uint32_t>(z != z)) != 0u);
   }
   pair_epilogue(x, lane, local, valid, stage, so, bad);
 }

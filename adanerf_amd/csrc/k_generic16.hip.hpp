@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256, (STAGED && (W == 64 || (W == 128 && FP <= 10))
     float z = 0.f;
 #pragma unroll
     for (int i = 0; i < 64; ++i) z = __builtin_fmaf(out[i], 0.f, z);    // NaN iff some output is inf / NaN (fp16 range left)
-    const bool bad_ray = (z != z) | (__shfl_xor(static_cast<int>(z != z), 32) != 0);
+    const bool bad_ray = (z != z) | (pair_xchg(static_cast<uint32_t>(z != z)) != 0u);
     if (bad_ray && valid && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
     pair_epilogue(out, lane, local, valid, sel_stage, a.sel);
   }
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256, (STAGED && (W == 64 || (W == 128 && FP <= 10))
           bad |= !(fabsf(v.x) < 3.0e38f) | !(fabsf(v.y) < 3.0e38f) | !(fabsf(v.z) < 3.0e38f) | !(fabsf(v.w) < 3.0e38f);
           *reinterpret_cast<float4*>(o + 32 * m + 8 * g + 4 * h) = v;
         }
-      const bool bad_ray = bad | (__shfl_xor(static_cast<int>(bad), 32) != 0);      // an activation left the fp16 range
+      const bool bad_ray = bad | (pair_xchg(static_cast<uint32_t>(bad)) != 0u);      // an activation left the fp16 range
       if (bad_ray && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
     }
     if (a.rays_out) {

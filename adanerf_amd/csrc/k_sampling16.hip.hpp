@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
       float z = 0.f;
 #pragma unroll
       for (int i = 0; i < 64; ++i) z = __builtin_fmaf(out[i], 0.f, z);    // NaN iff some output is inf / NaN (fp16 range left)
-      const bool bad_ray = (z != z) | (__shfl_xor(static_cast<int>(z != z), 32) != 0);
+      const bool bad_ray = (z != z) | (pair_xchg(static_cast<uint32_t>(z != z)) != 0u);
       if (bad_ray && valid && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
       pair_epilogue(out, lane, local, valid, sel_stage, a.sel);
     }
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
           }
         // an activation beyond the fp16 range (65504) shows up as inf/NaN here; a ray is owned by lanes j and j + 32
         // (64 outputs each), counted once
-        const bool bad_ray = bad | (__shfl_xor(static_cast<int>(bad), 32) != 0);
+        const bool bad_ray = bad | (pair_xchg(static_cast<uint32_t>(bad)) != 0u);
         if (bad_ray && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
       }
       if (a.rays_out) {
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
         x[i] = out[i >> 4][i & 15];
         z = __builtin_fmaf(x[i], 0.f, z);
       }
-      const bool bad_ray = (z != z) | (__shfl_xor(static_cast<int>(z != z), 32) != 0);
+      const bool bad_ray = (z != z) | (pair_xchg(static_cast<uint32_t>(z != z)) != 0u);
       // guard mode: a non-finite ray goes to the refinement pass, which does the counting
       if (bad_ray && valid && h == 0 && a.overflow_flag && !a.sel.guard_mask) atomicAdd(a.overflow_flag, 1);
       pair_epilogue(x, lane, local, valid, sel_stage, a.sel, bad_ray);
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
           bad |= !(fabsf(v.x) < 3.0e38f) | !(fabsf(v.y) < 3.0e38f) | !(fabsf(v.z) < 3.0e38f) | !(fabsf(v.w) < 3.0e38f);
           *reinterpret_cast<float4*>(o + 32 * m + 8 * g + 4 * h) = v;
         }
-      const bool bad_ray = bad | (__shfl_xor(static_cast<int>(bad), 32) != 0);   // lanes j and j + 32 own one ray
+      const bool bad_ray = bad | (pair_xchg(static_cast<uint32_t>(bad)) != 0u);   // lanes j and j + 32 own one ray
       if (bad_ray && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);    // an activation left the fp16 range
     }
   }

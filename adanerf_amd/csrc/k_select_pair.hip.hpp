@@ -47,8 +47,15 @@ constexpr int kPairLdsBytesPerWave = 32 * 64 * 4;   // staging of 32 values per 
 // bins the first four sit in lane j, the next four in lane j + 32.  All set arithmetic below is per lane on 64-bit masks over i
 // plus one exchange with the partner lane.
 
-__device__ __forceinline__ uint32_t pair_xchg(uint32_t v) { return static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 32)); }
-__device__ __forceinline__ float pair_xchg(float v) { return __shfl_xor(v, 32); }
+// the partner lane's value (lane ^ 32): v_permlane32_swap_b32 (gfx950) swaps lanes 32..63 of one register with lanes 0..31 of another --
+// applied to two copies of v it leaves v[0..31] | v[0..31] in the first and v[32..63] | v[32..63] in the second; each half picks the
+// one that holds its partner.  Stays in the VALU (the __shfl_xor form was a ds_bpermute round trip through the LDS crossbar).
+__device__ __forceinline__ uint32_t pair_xchg(uint32_t v) {
+  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+  const u32x2_t r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return (lane_id() < 32) ? r[1] : r[0];
+}
+__device__ __forceinline__ float pair_xchg(float v) { return __builtin_bit_cast(float, pair_xchg(__builtin_bit_cast(uint32_t, v))); }
 
 // bits [0, n) of a 32-bit word, 0 <= n <= 32
 __device__ __forceinline__ uint32_t low_bits32(int n) { return static_cast<uint32_t>((1ull << n) - 1ull); }
