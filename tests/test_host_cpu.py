@@ -4,6 +4,7 @@ the oracle), and that the product path refuses to run without a GPU."""
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -720,3 +721,16 @@ def test_coarse_fine_model_directory_parses(lib, tmp_path):
         open(os.path.join(bad, "config.ini"), "w").write(ini)
         rc = lib.adanerf_host_parse_model(bad.encode(), C.byref(opt), C.byref(info))
         assert rc != 0 and msg in lib.adanerf_last_error(None).decode(), (key, val, lib.adanerf_last_error(None))
+
+
+def test_bench_flop_models_match_the_survey_figures():
+    """bench.py's algorithmic-FLOP models (the numerators of `roofline.achieved` / `sampling_roofline`): SURVEY 8d's 1 186 816 FLOP per
+    shading sample and 898 048 per ray for the 8 x 256 networks, and the general-topology formula reproduces the first at L x W = 8 x 256."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.SHADE_FLOP_PER_SAMPLE == 2 * (63 * 256 + 4 * 256 ** 2 + 319 * 256 + 2 * 256 ** 2 + 256 + 256 ** 2 + 283 * 128 + 128 * 3) == 1186816
+    assert bench.SAMPLE_FLOP_PER_RAY == 2 * (90 * 256 + 6 * 256 ** 2 + 256 * 128) == 898048
+    assert bench.generic_shape("generic_6x128_random_init") == (6, 128, 2) and bench.generic_shape("classroom") is None
+    assert bench.shade_flop_per_sample("generic_8x256_random_init") == bench.SHADE_FLOP_PER_SAMPLE
+    w, d = 128, 6
+    assert bench.shade_flop_per_sample("generic_6x128_random_init") == 2 * (63 * w + (d - 2) * w * w + (w + 63) * w + w * w + w + (w + 27) * (w // 2) + (w // 2) * 3)
