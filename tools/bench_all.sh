@@ -10,7 +10,7 @@ print("%-22s %7.1f FPS  spp %.2f  stages %s  frac %.3f  psnr %s" % (sys.argv[2],
       {k: round(v, 3) for k, v in d["stage_ms_per_frame"].items()}, d["roofline"]["frac"], round(q.get("psnr_vs_oracle_db", 0), 1) if q else "-"))
 PY
 }
-run config2_bf16 --steps 30
+run config2_bf16 --steps 30 --no-cpu-baseline
 run config2_fp16 --steps 30 --precision fp16 --no-cpu-baseline
 run config2_fp32 --steps 10 --precision fp32 --no-cpu-baseline
 run config2_fp32sampling --steps 20 --sampling fp32 --no-cpu-baseline
@@ -23,3 +23,6 @@ run config2_speed_mode --steps 30 --sampling fp16 --no-cpu-baseline
 run config2_split_sampling --steps 30 --sampling split --no-cpu-baseline
 run generic_6x128_bf16 --steps 10 --workload generic_6x128 --no-cpu-baseline
 run generic_6x128_fp32 --steps 5 --workload generic_6x128 --precision fp32 --no-cpu-baseline
+run generic_4x64_bf16 --steps 20 --workload generic_4x64 --no-cpu-baseline
+run generic_5x256_bf16 --steps 20 --workload generic_5x256 --no-cpu-baseline
+run generic_6x128_bf16_fp32sampling --steps 20 --workload generic_6x128 --sampling fp32 --no-cpu-baseline
