@@ -1,5 +1,6 @@
 """In-tree build of the HIP shared library and the host CLI (hipcc, gfx950 only)."""
 import os
+import re
 import shutil
 import subprocess
 
@@ -9,9 +10,28 @@ HOST = os.path.join(HERE, "host")
 LIBDIR = os.path.join(HERE, "lib")
 BINDIR = os.path.join(HERE, "bin")
 LIB_SOURCES = ["adanerf_hip.hip", "launch_f32.hip", "format.cpp", "pack.cpp"]
-KERNEL_HEADERS = ["kernels.hip.hpp", "k_common.hip.hpp", "k_mlp_f32.hip.hpp", "k_compact.hip.hpp", "k_select_pair.hip.hpp", "k_generic_f32.hip.hpp", "k_mlp16.hip.hpp",
-                  "k_sampling16.hip.hpp", "k_donerf.hip.hpp", "k_coarse_fine.hip.hpp", "k_composite.hip.hpp", "launch_f32.hpp", "x_handsched.hip.hpp"]
-LIB_DEPS = LIB_SOURCES + KERNEL_HEADERS + ["tuning.hpp", "layout.hpp", "format.hpp", "pack.hpp", os.path.join("..", "..", "include", "adanerf_hip.h")]
+_INCLUDE = re.compile(r'^[ \t]*#[ \t]*include[ \t]+"([^"]+)"', re.M)
+
+
+def include_closure(sources=None):
+    """Every file the library's translation units reach through `#include "..."` (paths relative to csrc/, sources included),
+    sorted.  This IS the dependency list: a header that is included but not listed here cannot exist, so `_stale()` rebuilds on
+    any edit and `source_hash()` covers every kernel a profile may have been taken with (round 3 missed k_generic16.hip.hpp)."""
+    seen, todo = set(), list(sources or LIB_SOURCES)
+    while todo:
+        rel = os.path.normpath(todo.pop())
+        if rel in seen:
+            continue
+        path = os.path.join(CSRC, rel)
+        if not os.path.exists(path):
+            raise RuntimeError("%s: included by the library sources but missing" % path)
+        seen.add(rel)
+        for inc in _INCLUDE.findall(open(path, encoding="utf-8", errors="replace").read()):
+            todo.append(os.path.join(os.path.dirname(rel), inc))
+    return sorted(seen)
+
+
+LIB_DEPS = include_closure()
 ARCH = "gfx950"
 # -ffp-contract=off: the fused and the debug kernels must generate bit-identical rays (DESIGN 1).
 HIPCC_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off"]
