@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <type_traits>
 #include <cmath>
@@ -49,13 +51,18 @@ struct adanerf_ctx {
   bool profiling = false;
   int prof_frames = 0;
   std::vector<int32_t*> pinned_totals;   // one pinned int32 per recorded batch
-  // always-on monitor of the guarded selection (ADANERF_SAMPLING_GUARDED): the device's running {largest difference seen, violations} copied
-  // to pinned memory after every frame and looked at before the next one -- a violated band is widened (poll_guard)
+  // always-on monitor of the guarded selection (ADANERF_SAMPLING_GUARDED): the device's running {largest difference seen, violations,
+  // largest pair error seen, audit mismatches, audited rays} copied to pinned memory after every frame and looked at before the next
+  // one -- a violated band (or a failed audit) widens it (poll_guard)
   int32_t* guard_host = nullptr;
   hipEvent_t guard_ev = nullptr;
   bool guard_ev_pending = false;
   int guard_viol_seen = 0;
+  int guard_mism_seen = 0;
   int guard_widened = 0;
+  uint32_t guard_frame = 0;              // frames rendered in guarded mode: the audit's rotating phase
+  std::string model_dir;
+  uint64_t model0_hash = 0;              // FNV-1a 64 of model0.onnx: key of the calibration record
   adanerf_stats folded{};                // profiling record folded out of a full event pool (see adanerf_render)
 
   RayGenParams rg{};
@@ -101,6 +108,8 @@ struct adanerf_ctx {
   DevBuf guard_mask, refine_list, guard_probe;   // ADANERF_SAMPLING_GUARDED: undecided bit per ray (one word per 32), ids of the
                                                  // rays to re-evaluate, first-pass top value of each undecided ray (monitor)
   float guard_eps = 0.f;             // the band in raw-output units; 0: not calibrated yet
+  float guard_eps_pair = 0.f;        // bound on the error of a (kept - candidate) difference, raw-output units; 0: 2 x guard_eps
+  int guard_audit_period = 0;        // 0: no audit; else a power of two <= 32
   DepthMap dm{};
   int shade_grid[3] = {0, 0, 0};
   int device = 0;                 // HIP device ordinal this context lives on
@@ -302,6 +311,11 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   if (opt->precision < 0 || opt->precision > 2) return bad(ADANERF_EINVAL, "precision must be ADANERF_PREC_{BF16,FP16,FP32}");
   if (opt->sampling_mode < 0 || opt->sampling_mode > 3) return bad(ADANERF_EINVAL, "sampling_mode must be ADANERF_SAMPLING_{SPLIT_FP16,FP32,FP16,GUARDED}");
   if (!(opt->guard_eps <= 1.0f)) return bad(ADANERF_EINVAL, "guard_eps must be <= 1 (<= 0 selects the default)");
+  if (!(opt->guard_eps_pair <= 2.0f)) return bad(ADANERF_EINVAL, "guard_eps_pair must be <= 2 (<= 0 selects the default)");
+  {
+    const int ap = opt->guard_audit_period;
+    if (ap > 32 || (ap > 0 && (ap & (ap - 1)) != 0)) return bad(ADANERF_EINVAL, "guard_audit_period must be a power of two <= 32 (0: default, < 0: off)");
+  }
 
   // ---- info / ray generation constants (A1: src/util/raygeneration.py:10-26, float64) ----
   const int w = opt->width, h = opt->height;
@@ -471,14 +485,15 @@ int ensure_batch_buffers(adanerf_ctx* c, int n_rays, int n_max) {
     if (c->sampling_mode == ADANERF_SAMPLING_GUARDED) {
       if ((rc = dev_alloc(c, &c->guard_mask, nblk * sizeof(uint32_t)))) return rc;
       if ((rc = dev_alloc(c, &c->refine_list, R * sizeof(int32_t)))) return rc;
-      if ((rc = dev_alloc(c, &c->guard_probe, R * sizeof(float)))) return rc;
+      if ((rc = dev_alloc(c, &c->guard_probe, R * 2 * sizeof(float)))) return rc;
     }
   }
   if ((rc = dev_alloc(c, &c->block_total, nblk * sizeof(int32_t)))) return rc;
   if ((rc = dev_alloc(c, &c->block_offset, nblk * sizeof(int32_t)))) return rc;
   if (!c->total.p) {
     if ((rc = dev_alloc(c, &c->total, 64))) return rc;      // [0] samples of the batch, [4] rays re-evaluated by the guarded selection,
-                                                            // [8] largest first-pass error seen (float bits), [9] rays where it exceeded the band
+                                                            // [8..12] its monitor (SelectOut::guard_seen): largest error seen (float bits), rays
+                                                            // beyond a bound, largest pair error seen, audit mismatches, audited rays
     HIP_TRY(c, hipMemset(c->total.p, 0, 64));
   }
   if ((rc = dev_alloc(c, &c->sample_key, S * sizeof(uint32_t)))) return rc;
@@ -518,7 +533,8 @@ int occupancy_grid(adanerf_ctx* c, K kernel, int threads, int* out) {
   return ADANERF_OK;
 }
 
-int calibrate_guard(adanerf_ctx* c, int n_poses, uint32_t seed, bool install, float* max_diff);
+int calibrate_guard(adanerf_ctx* c, int n_poses, uint32_t seed, bool install, float* max_diff, float* max_pair);
+int ensure_guard_band(adanerf_ctx* c);
 
 // a sampling net of another topology / layout on the split-precision run-time-shaped kernel (else: the fp32 one)
 bool generic_split_sampling(const adanerf_ctx* c) {
@@ -569,14 +585,17 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
   // Only where the selection is fused; otherwise this mode is the split-precision engine.
   const bool guarded = c->sampling_mode == ADANERF_SAMPLING_GUARDED && sel != nullptr;
   if (guarded) {
-    if (!(c->guard_eps > 0.f)) {      // first guarded frame of a context created without a band: measure one for this model
-      float d = 0.f;
-      int rc = calibrate_guard(c, 8, 1u, true, &d);
+    if (!(c->guard_eps > 0.f)) {      // first guarded frame of a context created without a band: the model's record, or measure one
+      int rc = ensure_guard_band(c);
       if (rc) return rc;
     }
     a.sel.guard_mask = reinterpret_cast<uint32_t*>(c->guard_mask.p);
     a.sel.guard_eps = guard_band_of(c->transform, c->guard_eps);
+    a.sel.guard_pair = guard_pair_of(c->transform, c->guard_eps, c->guard_eps_pair);
+    a.sel.audit_period = c->guard_audit_period;
+    a.sel.audit_phase = c->guard_audit_period > 0 ? static_cast<int32_t>(c->guard_frame & static_cast<uint32_t>(c->guard_audit_period - 1)) : 0;
     a.sel.guard_probe = reinterpret_cast<float*>(c->guard_probe.p);
+    a.sel.guard_rows = reinterpret_cast<float*>(c->oracle.p);      // free on this path: the selection is fused, nobody else writes the oracle buffer
     a.sel.guard_seen = reinterpret_cast<uint32_t*>(c->total.p) + 8;
   }
   if (c->sampling_mode == 1) {
@@ -605,13 +624,17 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
       const int n_words = (n_rays + 31) / 32;
       int32_t* n_list = reinterpret_cast<int32_t*>(c->total.p) + 4;
       hipLaunchKernelGGL(refine_list_kernel, dim3((n_words + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(c->guard_mask.p),
-                         n_words, reinterpret_cast<int32_t*>(c->refine_list.p), n_list);
+                         n_words, n_rays, a.sel.audit_period, a.sel.audit_phase, reinterpret_cast<int32_t*>(c->refine_list.p), n_list);
       SampleArgs r = a;
       r.net16 = c->net0_split.params;
       r.rays_out = nullptr;              // the first pass wrote the ray records
       r.sel.guard_mask = nullptr;
-      r.sel.guard_band = r.sel.guard_eps;      // the second pass only monitors against the band
+      // the second pass only monitors, in RAW units: the bound on single values, and -- where pass 1 used a measured one -- on differences
+      r.sel.guard_band = c->guard_eps;
+      r.sel.guard_band_pair = c->transform == kOracleRaw ? a.sel.guard_pair : 0.f;
       r.sel.guard_eps = 0.f;
+      r.sel.guard_pair = 0.f;
+      r.sel.audit_period = 0;
       r.sel.refine_list = reinterpret_cast<const int32_t*>(c->refine_list.p);
       r.ray_list = r.sel.refine_list;
       r.n_list = n_list;
@@ -698,9 +721,117 @@ int launch_compact(adanerf_ctx* c, const float* d_oracle, int n_rays, int n_max,
   return launch_expand(c, n_rays, n_max, kSelSegShift, d_off, d_cnt, d_key, d_w, d_total);
 }
 
-// Largest |plain-fp16 - split-precision| raw output of the sampling network over n_poses x 64 x 64 calibration rays
-// (include/adanerf_hip.h: adanerf_calibrate_guard).  Temporarily replaces the ray generator's image and camera.
-int calibrate_guard(adanerf_ctx* c, int n_poses, uint32_t seed, bool install, float* max_diff) {
+// ---- calibration record of the guarded selection (include/adanerf_hip.h: adanerf_guard_calibration_file) ----
+
+uint64_t fnv1a64_file(const std::string& path) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return 0;
+  uint64_t h = 0xcbf29ce484222325ull;
+  unsigned char buf[1 << 16];
+  size_t n;
+  while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0)
+    for (size_t i = 0; i < n; ++i) h = (h ^ buf[i]) * 0x100000001b3ull;
+  std::fclose(f);
+  return h ? h : 1;
+}
+
+std::string hex64(uint64_t v) {
+  char b[17];
+  std::snprintf(b, sizeof(b), "%016llx", static_cast<unsigned long long>(v));
+  return b;
+}
+
+std::string guard_record_dir(const adanerf_ctx* c) {
+  const char* env = std::getenv("ADANERF_GUARD_CACHE_DIR");
+  if (env && *env) return join_path(env, hex64(c->model0_hash));
+  return c->model_dir;
+}
+
+std::string guard_record_path(const adanerf_ctx* c) {
+  uint32_t tb;
+  const float thr = c->info.threshold;
+  std::memcpy(&tb, &thr, sizeof(tb));
+  char name[64];
+  std::snprintf(name, sizeof(name), "guard_band.n%d.t%08x.cal", c->info.num_samples, tb);
+  return join_path(guard_record_dir(c), name);
+}
+
+struct GuardRecord {
+  int poses = 0;
+  uint32_t seed = 0;
+  float max_diff = 0.f, max_pair = 0.f;
+};
+
+// what a record must agree with to be this context's
+std::string guard_record_key(const adanerf_ctx* c) {
+  char b[160];
+  std::snprintf(b, sizeof(b), "%s|enc %d-%d|transform %d|engine %d|n %d|thr %.9g", hex64(c->model0_hash).c_str(), c->fp0, c->fd0, c->transform,
+                kGuardEngineRev, c->info.num_samples, static_cast<double>(c->info.threshold));
+  return b;
+}
+
+bool read_guard_record(const adanerf_ctx* c, GuardRecord* r) {
+  FILE* f = std::fopen(guard_record_path(c).c_str(), "r");
+  if (!f) return false;
+  char line[512];
+  std::string key;
+  bool have[4] = {false, false, false, false};
+  while (std::fgets(line, sizeof(line), f)) {
+    std::string l(line);
+    const size_t eq = l.find('=');
+    if (l.empty() || l[0] == '#' || eq == std::string::npos) continue;
+    auto trim = [](std::string t) {
+      const char* ws = " \t\r\n";
+      const size_t a0 = t.find_first_not_of(ws), a1 = t.find_last_not_of(ws);
+      return a0 == std::string::npos ? std::string() : t.substr(a0, a1 - a0 + 1);
+    };
+    const std::string k = trim(l.substr(0, eq)), v = trim(l.substr(eq + 1));
+    if (k == "key") key = v;
+    else if (k == "poses") { r->poses = std::atoi(v.c_str()); have[0] = true; }
+    else if (k == "seed") { r->seed = static_cast<uint32_t>(std::strtoul(v.c_str(), nullptr, 10)); have[1] = true; }
+    else if (k == "max_diff") { r->max_diff = std::strtof(v.c_str(), nullptr); have[2] = true; }
+    else if (k == "max_pair_diff") { r->max_pair = std::strtof(v.c_str(), nullptr); have[3] = true; }
+  }
+  std::fclose(f);
+  return key == guard_record_key(c) && have[0] && have[1] && have[2] && have[3] && r->poses >= 1 && r->max_diff > 0.f &&
+         r->max_diff < INFINITY && r->max_pair >= 0.f && r->max_pair < INFINITY;
+}
+
+// best effort: a read-only model directory simply keeps being calibrated at start-up (or use ADANERF_GUARD_CACHE_DIR)
+void write_guard_record(const adanerf_ctx* c, const GuardRecord& r) {
+  const std::string dir = guard_record_dir(c), path = guard_record_path(c), tmp = path + ".tmp";
+  if (std::getenv("ADANERF_GUARD_CACHE_DIR")) {
+    (void)mkdir(std::getenv("ADANERF_GUARD_CACHE_DIR"), 0777);
+    (void)mkdir(dir.c_str(), 0777);
+  }
+  FILE* f = std::fopen(tmp.c_str(), "w");
+  if (!f) return;
+  std::fprintf(f,
+               "# libadanerf_hip: measured error bounds of the plain-fp16 sampling pass against the split-precision engine\n"
+               "# (ADANERF_SAMPLING_GUARDED).  Delete this file to have them measured again.\n"
+               "key = %s\nposes = %d\nseed = %u\nmax_diff = %.9g\nmax_pair_diff = %.9g\n",
+               guard_record_key(c).c_str(), r.poses, r.seed, static_cast<double>(r.max_diff), static_cast<double>(r.max_pair));
+  const bool ok = std::fclose(f) == 0;
+  if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+}
+
+void install_guard_band(adanerf_ctx* c, float max_diff, float max_pair, int poses, int source) {
+  c->guard_eps = std::max(ADANERF_GUARD_CALIB_MARGIN * max_diff, ADANERF_GUARD_EPS_MIN);
+  // a measured pair bound applies to untransformed outputs only (guard_pair_of); never below the floor, never above what the
+  // single-value bound implies
+  c->guard_eps_pair = (c->transform == kOracleRaw && max_pair > 0.f)
+                          ? std::min(std::max(ADANERF_GUARD_CALIB_MARGIN * max_pair, ADANERF_GUARD_EPS_MIN), 2.0f * c->guard_eps)
+                          : 2.0f * c->guard_eps;
+  c->info.guard_eps = c->guard_eps;
+  c->info.guard_eps_pair = c->guard_eps_pair;
+  c->info.guard_calib_source = source;
+  c->info.guard_calib_poses = poses;
+}
+
+// Largest |plain-fp16 - split-precision| raw output of the sampling network over n_poses x 64 x 64 calibration rays, and the largest
+// error of a (kept - candidate) difference under the single-value bound that gives (include/adanerf_hip.h: adanerf_calibrate_guard).
+// Two sweeps over the same seeded poses: the second statistic needs the first.  Temporarily replaces the ray generator's image and camera.
+int calibrate_guard(adanerf_ctx* c, int n_poses, uint32_t seed, bool install, float* max_diff, float* max_pair) {
   if (c->coarse_fine || c->generic0) return fail(c, ADANERF_EUNSUPPORTED, "guard calibration needs an 8 x 256 sampling network");
   if (n_poses < 1 || n_poses > 4096) return fail(c, ADANERF_EINVAL, "n_poses must be in 1..4096");
   constexpr int CW = 64, CH = 64, CR = CW * CH;
@@ -733,59 +864,95 @@ int calibrate_guard(adanerf_ctx* c, int n_poses, uint32_t seed, bool install, fl
   if ((rc = dev_alloc(c, &b_buf, static_cast<size_t>(CR) * kBins * sizeof(float)))) return done(rc);
   if ((rc = dev_alloc(c, &acc, 64))) return done(rc);
   if (hipMemsetAsync(acc.p, 0, 64, c->stream) != hipSuccess) return done(fail(c, ADANERF_EDEVICE, "hipMemsetAsync failed"));
-  uint64_t st = 0x9E3779B97F4A7C15ull ^ (static_cast<uint64_t>(seed) << 17);
-  auto rnd = [&]() {      // xorshift64*, uniform in [0, 1)
-    st ^= st >> 12;
-    st ^= st << 25;
-    st ^= st >> 27;
-    return static_cast<double>((st * 0x2545F4914F6CDD1Dull) >> 11) * (1.0 / 9007199254740992.0);
-  };
-  for (int k = 0; k < n_poses; ++k) {
-    for (int i = 0; i < 3; ++i) g.pos[i] = g.center[i] + static_cast<float>((rnd() - 0.5) * 0.9 * c->info.view_cell_size[i]);
-    // orientation: yaw about z, then pitch (the viewer's camera: z up, looking along -z of the camera frame)
-    const double yaw = 2.0 * M_PI * rnd(), pitch = (rnd() - 0.5) * (c->info.use_ndc ? 0.2 : 1.4);
-    const double cy = std::cos(yaw), sy = std::sin(yaw), cp = std::cos(pitch), sp = std::sin(pitch);
-    double fwd[3], right[3], up[3];
-    if (c->info.use_ndc) {      // forward-facing scenes look down -z
-      fwd[0] = sp * cy; fwd[1] = sp * sy; fwd[2] = -cp;
-      right[0] = 1; right[1] = 0; right[2] = 0;
-    } else {
-      fwd[0] = cp * cy; fwd[1] = cp * sy; fwd[2] = sp;
-      right[0] = sy; right[1] = -cy; right[2] = 0;
+  const bool want_pairs = c->transform == kOracleRaw && c->info.threshold > 0.f && c->info.num_samples <= kPairMaxN;
+  float d = 0.f, dp = 0.f;
+  bool nonfinite = false;
+  for (int sweep = 0; sweep < (want_pairs ? 2 : 1) && !nonfinite; ++sweep) {
+    const float two_eps = sweep == 0 ? 0.f : 2.0f * std::max(ADANERF_GUARD_CALIB_MARGIN * d, ADANERF_GUARD_EPS_MIN);
+    uint64_t st = 0x9E3779B97F4A7C15ull ^ (static_cast<uint64_t>(seed) << 17);
+    auto rnd = [&]() {      // xorshift64*, uniform in [0, 1)
+      st ^= st >> 12;
+      st ^= st << 25;
+      st ^= st >> 27;
+      return static_cast<double>((st * 0x2545F4914F6CDD1Dull) >> 11) * (1.0 / 9007199254740992.0);
+    };
+    for (int k = 0; k < n_poses; ++k) {
+      for (int i = 0; i < 3; ++i) g.pos[i] = g.center[i] + static_cast<float>((rnd() - 0.5) * 0.9 * c->info.view_cell_size[i]);
+      // orientation: yaw about z, then pitch (the viewer's camera: z up, looking along -z of the camera frame)
+      const double yaw = 2.0 * M_PI * rnd(), pitch = (rnd() - 0.5) * (c->info.use_ndc ? 0.2 : 1.4);
+      const double cy = std::cos(yaw), sy = std::sin(yaw), cp = std::cos(pitch), sp = std::sin(pitch);
+      double fwd[3], right[3], up[3];
+      if (c->info.use_ndc) {      // forward-facing scenes look down -z
+        fwd[0] = sp * cy; fwd[1] = sp * sy; fwd[2] = -cp;
+        right[0] = 1; right[1] = 0; right[2] = 0;
+      } else {
+        fwd[0] = cp * cy; fwd[1] = cp * sy; fwd[2] = sp;
+        right[0] = sy; right[1] = -cy; right[2] = 0;
+      }
+      // re-orthogonalise: right = normalize(right - (right . fwd) fwd), up = right x fwd
+      const double rf = right[0] * fwd[0] + right[1] * fwd[1] + right[2] * fwd[2];
+      double n = 0;
+      for (int i = 0; i < 3; ++i) { right[i] -= rf * fwd[i]; n += right[i] * right[i]; }
+      n = std::sqrt(n);
+      for (int i = 0; i < 3; ++i) right[i] /= n;
+      up[0] = right[1] * fwd[2] - right[2] * fwd[1];
+      up[1] = right[2] * fwd[0] - right[0] * fwd[2];
+      up[2] = right[0] * fwd[1] - right[1] * fwd[0];
+      for (int i = 0; i < 3; ++i) {      // columns of c2w: camera x = right, y = up, -z = forward
+        g.rot[3 * i + 0] = static_cast<float>(right[i]);
+        g.rot[3 * i + 1] = static_cast<float>(up[i]);
+        g.rot[3 * i + 2] = static_cast<float>(-fwd[i]);
+      }
+      c->rg = g;
+      c->sampling_mode = ADANERF_SAMPLING_SPLIT_FP16;
+      if ((rc = launch_sample_mlp(c, 0, CR, reinterpret_cast<float*>(a_buf.p), nullptr))) return done(rc);
+      c->sampling_mode = ADANERF_SAMPLING_FP16;
+      if ((rc = launch_sample_mlp(c, 0, CR, reinterpret_cast<float*>(b_buf.p), nullptr))) return done(rc);
+      hipLaunchKernelGGL(guard_stats_kernel, dim3((CR + 3) / 4), dim3(256), 0, c->stream, reinterpret_cast<const float*>(b_buf.p),
+                         reinterpret_cast<const float*>(a_buf.p), CR, c->info.num_samples, c->info.threshold, two_eps, reinterpret_cast<uint32_t*>(acc.p));
     }
-    // re-orthogonalise: right = normalize(right - (right . fwd) fwd), up = right x fwd
-    const double rf = right[0] * fwd[0] + right[1] * fwd[1] + right[2] * fwd[2];
-    double n = 0;
-    for (int i = 0; i < 3; ++i) { right[i] -= rf * fwd[i]; n += right[i] * right[i]; }
-    n = std::sqrt(n);
-    for (int i = 0; i < 3; ++i) right[i] /= n;
-    up[0] = right[1] * fwd[2] - right[2] * fwd[1];
-    up[1] = right[2] * fwd[0] - right[0] * fwd[2];
-    up[2] = right[0] * fwd[1] - right[1] * fwd[0];
-    for (int i = 0; i < 3; ++i) {      // columns of c2w: camera x = right, y = up, -z = forward
-      g.rot[3 * i + 0] = static_cast<float>(right[i]);
-      g.rot[3 * i + 1] = static_cast<float>(up[i]);
-      g.rot[3 * i + 2] = static_cast<float>(-fwd[i]);
-    }
-    c->rg = g;
-    c->sampling_mode = ADANERF_SAMPLING_SPLIT_FP16;
-    if ((rc = launch_sample_mlp(c, 0, CR, reinterpret_cast<float*>(a_buf.p), nullptr))) return done(rc);
-    c->sampling_mode = ADANERF_SAMPLING_FP16;
-    if ((rc = launch_sample_mlp(c, 0, CR, reinterpret_cast<float*>(b_buf.p), nullptr))) return done(rc);
-    hipLaunchKernelGGL(max_abs_diff_kernel, dim3(256), dim3(256), 0, c->stream, reinterpret_cast<const float*>(a_buf.p),
-                       reinterpret_cast<const float*>(b_buf.p), static_cast<size_t>(CR) * kBins, reinterpret_cast<uint32_t*>(acc.p));
+    uint32_t res[3] = {0, 0, 0};
+    if (hipMemcpyAsync(res, acc.p, sizeof(res), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+      return done(fail(c, ADANERF_EDEVICE, "guard calibration: read-back failed"));
+    std::memcpy(&d, &res[0], sizeof(d));
+    std::memcpy(&dp, &res[2], sizeof(dp));
+    nonfinite = res[1] != 0;
   }
-  uint32_t res[2] = {0, 0};
-  if (hipMemcpyAsync(res, acc.p, sizeof(res), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
-    return done(fail(c, ADANERF_EDEVICE, "guard calibration: read-back failed"));
-  float d;
-  std::memcpy(&d, &res[0], sizeof(d));
-  if (max_diff) *max_diff = res[1] ? INFINITY : d;
+  if (max_diff) *max_diff = nonfinite ? INFINITY : d;
+  if (max_pair) *max_pair = (nonfinite || !want_pairs) ? 0.f : dp;
   if (install) {
-    c->guard_eps = res[1] ? ADANERF_GUARD_EPS_DEFAULT : std::max(ADANERF_GUARD_CALIB_MARGIN * d, ADANERF_GUARD_EPS_MIN);
-    c->info.guard_eps = c->guard_eps;
+    if (nonfinite) {
+      c->guard_eps = ADANERF_GUARD_EPS_DEFAULT;
+      c->guard_eps_pair = 2.0f * c->guard_eps;
+      c->info.guard_eps = c->guard_eps;
+      c->info.guard_eps_pair = c->guard_eps_pair;
+      c->info.guard_calib_source = ADANERF_GUARD_FROM_CALIBRATION;
+      c->info.guard_calib_poses = n_poses;
+    } else {
+      install_guard_band(c, d, want_pairs ? dp : 0.f, n_poses, ADANERF_GUARD_FROM_CALIBRATION);
+      GuardRecord old;      // a record from more poses than this measurement stays
+      if (!(c->opt.flags & ADANERF_FLAG_NO_GUARD_CACHE) && !(read_guard_record(c, &old) && old.poses > n_poses)) {
+        GuardRecord r;
+        r.poses = n_poses;
+        r.seed = seed;
+        r.max_diff = d;
+        r.max_pair = want_pairs ? dp : 0.f;
+        write_guard_record(c, r);
+      }
+    }
   }
   return done(ADANERF_OK);
+}
+
+// first guarded frame of a context created without a band: the model's calibration record if it is current, else a measurement
+int ensure_guard_band(adanerf_ctx* c) {
+  GuardRecord r;
+  if (!(c->opt.flags & ADANERF_FLAG_NO_GUARD_CACHE) && read_guard_record(c, &r) && r.poses >= ADANERF_GUARD_CALIB_POSES) {
+    install_guard_band(c, r.max_diff, r.max_pair, r.poses, ADANERF_GUARD_FROM_RECORD);
+    return ADANERF_OK;
+  }
+  float d = 0.f, dp = 0.f;
+  return calibrate_guard(c, ADANERF_GUARD_CALIB_POSES, 1u, true, &d, &dp);
 }
 
 constexpr int kShadeWaves = 8;   // one 8-wave workgroup per CU (two independent 4-wave workgroups measured 4.2-5.7 ms vs 3.8)
@@ -831,7 +998,7 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
 #define ADN_GEN16(ET, FPv, FDv, Wv)                                                                                      \
   do {                                                                                                                   \
     if constexpr (tune::kGenericStaged)                                                                                  \
-      ADN_GEN16_GO((shade_mlp16_gen_staged_kernel<ET, FPv, FDv, Wv, gen_blocks<Wv>(), gen_occupancy<Wv>()>));            \
+      ADN_GEN16_GO((shade_mlp16_gen_staged_kernel<ET, FPv, FDv, Wv, gen_blocks<Wv>(), gen_occupancy<Wv, FPv>()>));            \
     else ADN_GEN16_GO((shade_mlp16_gen_kernel<ET, FPv, FDv, Wv>));                                                       \
   } while (0)
 #define ADN_GEN16_W(ET, FPv, FDv)                                  \
@@ -1023,8 +1190,15 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     if ((!c->generic0 || c->ray_samples == 0) && !pack_sampling_net(n0, sh, Elem::F16_SPLIT, &p0s, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
   }
   c->sampling_mode = opt->sampling_mode;
-  c->guard_eps = opt->guard_eps > 0.f ? opt->guard_eps : 0.f;      // 0: calibrated before the first guarded frame
+  c->model_dir = model_dir;
+  c->guard_eps = opt->guard_eps > 0.f ? opt->guard_eps : 0.f;      // 0: the model's calibration record, or calibrated before the first guarded frame
+  c->guard_eps_pair = (c->guard_eps > 0.f && opt->guard_eps_pair > 0.f) ? std::min(opt->guard_eps_pair, 2.0f * c->guard_eps) : 2.0f * c->guard_eps;
+  c->guard_audit_period = opt->guard_audit_period == 0 ? ADANERF_GUARD_AUDIT_PERIOD : std::max(opt->guard_audit_period, 0);
   c->info.guard_eps = c->guard_eps;
+  c->info.guard_eps_pair = c->guard_eps_pair;
+  c->info.guard_audit_period = c->sampling_mode == ADANERF_SAMPLING_GUARDED ? c->guard_audit_period : 0;
+  c->info.guard_calib_source = c->guard_eps > 0.f ? ADANERF_GUARD_FROM_OPTIONS : ADANERF_GUARD_FROM_NONE;
+  if (c->sampling_mode == ADANERF_SAMPLING_GUARDED) c->model0_hash = fnv1a64_file(join_path(model_dir, "model0.onnx"));
   {   // topology of the shading net first (fp32 packing accepts every supported topology)
     PackedNet probe;
     if (!pack_shading_net(c->net1_host, sh, Elem::F32, &probe, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
@@ -1242,39 +1416,78 @@ int adanerf_compact(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, int32
 }
 
 int adanerf_compact_guarded(adanerf_ctx* c, const float* d_approx, const float* d_exact, int32_t n_rays, int32_t n_max, float thr, float eps,
-                            int32_t* d_off, int32_t* d_cnt, uint32_t* d_key, float* d_w, int32_t* d_total, int32_t* d_refined) {
+                            float eps_pair, int32_t audit_period, int32_t audit_phase, int32_t* d_off, int32_t* d_cnt, uint32_t* d_key, float* d_w,
+                            int32_t* d_total, int32_t* d_refined, uint32_t* d_monitor) {
   if (!c) return ADANERF_EINVAL;
   BIND(c);
   if (!d_approx || !d_exact || !d_off || !d_cnt || !d_key || !d_w || !d_total || !d_refined) return fail(c, ADANERF_EINVAL, "NULL buffer");
   if (n_rays < 0 || n_max < 1 || n_max > kPairMaxN || !(thr > 0.f) || !(eps > 0.f)) return fail(c, ADANERF_EINVAL, "n_rays/n_max/thr/eps out of range");
+  if (audit_period > 32 || (audit_period > 0 && (audit_period & (audit_period - 1)) != 0)) return fail(c, ADANERF_EINVAL, "audit_period must be a power of two <= 32");
   if (static_cast<int64_t>(n_rays) >= (1ll << 25)) return fail(c, ADANERF_EINVAL, "n_rays must be < 2^25 per batch");
   if (n_rays == 0) return ADANERF_OK;
   int rc = ensure_compact_scratch(c, n_rays, n_max);
   if (rc) return rc;
   const int n_words = (n_rays + 31) / 32;
-  if (c->guard_mask.bytes < n_words * sizeof(uint32_t) || c->refine_list.bytes < static_cast<size_t>(n_rays) * sizeof(int32_t)) {
+  if (c->guard_mask.bytes < n_words * sizeof(uint32_t) || c->refine_list.bytes < static_cast<size_t>(n_rays) * sizeof(int32_t) ||
+      c->guard_probe.bytes < static_cast<size_t>(n_rays) * 2 * sizeof(float)) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if ((rc = dev_alloc(c, &c->guard_mask, n_words * sizeof(uint32_t)))) return rc;
     if ((rc = dev_alloc(c, &c->refine_list, static_cast<size_t>(n_rays) * sizeof(int32_t)))) return rc;
+    if ((rc = dev_alloc(c, &c->guard_probe, static_cast<size_t>(n_rays) * 2 * sizeof(float)))) return rc;
   }
+  const int period = audit_period > 0 ? audit_period : 0, phase = period ? (audit_phase & (period - 1)) : 0;
   SelectOut so = select_out(c, n_max, thr, d_cnt);
   so.guard_mask = reinterpret_cast<uint32_t*>(c->guard_mask.p);
   so.guard_eps = guard_band_of(c->transform, eps);
+  so.guard_pair = guard_pair_of(c->transform, eps, eps_pair);
+  so.audit_period = period;
+  so.audit_phase = phase;
+  so.guard_probe = reinterpret_cast<float*>(c->guard_probe.p);      // the cut values of the rays pass 2 will look at; their rows are d_approx itself
   const dim3 grid((n_rays + 127) / 128), block(256);
   hipLaunchKernelGGL(select_rows_kernel, grid, block, 0, c->stream, d_approx, n_rays, so, static_cast<const int32_t*>(nullptr));
   hipLaunchKernelGGL(refine_list_kernel, dim3((n_words + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(c->guard_mask.p), n_words,
-                     reinterpret_cast<int32_t*>(c->refine_list.p), d_refined);
+                     n_rays, period, phase, reinterpret_cast<int32_t*>(c->refine_list.p), d_refined);
   so.guard_mask = nullptr;
+  so.guard_band = eps;
+  so.guard_band_pair = c->transform == kOracleRaw ? so.guard_pair : 0.f;
   so.guard_eps = 0.f;
+  so.guard_pair = 0.f;
+  so.audit_period = 0;
   so.refine_list = reinterpret_cast<const int32_t*>(c->refine_list.p);
+  so.guard_rows = d_monitor ? const_cast<float*>(d_approx) : nullptr;      // pass 2 only reads them
+  so.guard_seen = d_monitor;
   hipLaunchKernelGGL(select_rows_kernel, grid, block, 0, c->stream, d_exact, n_rays, so, static_cast<const int32_t*>(d_refined));
   return launch_expand(c, n_rays, n_max, kPairSegShift, d_off, d_cnt, d_key, d_w, d_total);
 }
 
-int adanerf_calibrate_guard(adanerf_ctx* c, int32_t n_poses, uint32_t seed, int32_t set, float* max_diff) {
+int adanerf_calibrate_guard(adanerf_ctx* c, int32_t n_poses, uint32_t seed, int32_t set, float* max_diff, float* max_pair_diff) {
   if (!c) return ADANERF_EINVAL;
   BIND(c);
-  return calibrate_guard(c, n_poses, seed, set != 0, max_diff);
+  if (!c->model0_hash) c->model0_hash = fnv1a64_file(join_path(c->model_dir, "model0.onnx"));
+  return calibrate_guard(c, n_poses, seed, set != 0, max_diff, max_pair_diff);
+}
+
+int adanerf_guard_calibration_file(const adanerf_ctx* c, char* buf, size_t buf_bytes) {
+  if (!c) return ADANERF_EINVAL;
+  adanerf_ctx* m = const_cast<adanerf_ctx*>(c);
+  if (!m->model0_hash) m->model0_hash = fnv1a64_file(join_path(c->model_dir, "model0.onnx"));
+  const std::string p = guard_record_path(c);
+  if (buf && buf_bytes > 0) {
+    const size_t n = std::min(p.size(), buf_bytes - 1);
+    std::memcpy(buf, p.data(), n);
+    buf[n] = 0;
+  }
+  return static_cast<int>(p.size() + 1);
+}
+
+int adanerf_abi_version(void) { return ADANERF_ABI_VERSION; }
+
+int adanerf_struct_sizes(int32_t sizes_out[3]) {
+  if (!sizes_out) return ADANERF_EINVAL;
+  sizes_out[0] = static_cast<int32_t>(sizeof(adanerf_options));
+  sizes_out[1] = static_cast<int32_t>(sizeof(adanerf_info));
+  sizes_out[2] = static_cast<int32_t>(sizeof(adanerf_stats));
+  return ADANERF_OK;
 }
 
 int adanerf_shade_features(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key, int32_t n_samples, float* d_feat) {
@@ -1388,10 +1601,14 @@ int sum_stats(adanerf_ctx* c, adanerf_stats* stats) {
     stats->total_samples += c->pinned_totals[b][0];
     if (c->sampling_mode == ADANERF_SAMPLING_GUARDED) {
       stats->rays_refined += c->pinned_totals[b][4];
-      float seen;                                      // cumulative on the device: the latest batch holds the running values
+      float seen, pair;                                // cumulative on the device: the latest batch holds the running values
       std::memcpy(&seen, &c->pinned_totals[b][8], sizeof(seen));
+      std::memcpy(&pair, &c->pinned_totals[b][10], sizeof(pair));
       stats->guard_max_seen = std::max(stats->guard_max_seen, seen);
+      stats->guard_pair_seen = std::max(stats->guard_pair_seen, pair);
       stats->guard_violations = std::max(stats->guard_violations, c->pinned_totals[b][9]);
+      stats->guard_audit_mismatch = std::max(stats->guard_audit_mismatch, c->pinned_totals[b][11]);
+      stats->guard_audited = std::max(stats->guard_audited, c->pinned_totals[b][12]);
     }
   }
   int32_t ovf = 0;
@@ -1406,6 +1623,9 @@ int sum_stats(adanerf_ctx* c, adanerf_stats* stats) {
   stats->rays_refined += f.rays_refined;
   stats->guard_max_seen = std::max(stats->guard_max_seen, f.guard_max_seen);
   stats->guard_violations = std::max(stats->guard_violations, f.guard_violations);
+  stats->guard_pair_seen = std::max(stats->guard_pair_seen, f.guard_pair_seen);
+  stats->guard_audit_mismatch = std::max(stats->guard_audit_mismatch, f.guard_audit_mismatch);
+  stats->guard_audited = std::max(stats->guard_audited, f.guard_audited);
   stats->guard_widened = c->guard_widened;
   stats->ms_total += f.ms_total;
   stats->ms_sample_mlp += f.ms_sample_mlp;
@@ -1451,27 +1671,51 @@ int adanerf_render_oracle(adanerf_ctx* c, void* d_rgba8) {
 
 namespace {
 
-// The band of the guarded selection is an assumption (|fp16 output - split output| <= guard_eps) that the second pass samples on every
-// re-evaluated ray.  If a frame saw it violated, every later frame runs with a band of ADANERF_GUARD_CALIB_MARGIN x the largest
-// difference seen so far (adanerf_info.guard_eps follows, adanerf_stats.guard_widened counts).  Non-blocking: looks only at a copy
-// that has already arrived.
+// The band of the guarded selection rests on two measured assumptions (|fp16 output - split output| <= guard_eps on every raw
+// output; the error of a (kept - candidate) difference <= guard_eps_pair) that the second pass re-measures on the whole row of every
+// re-evaluated ray, and on an audit of the outcome (decided rays re-evaluated anyway).  All of it in RAW-output units -- the units
+// guard_eps is in (round 3 compared transformed values with a raw band).  If a frame saw a bound violated, every later frame runs
+// with ADANERF_GUARD_CALIB_MARGIN x the largest errors seen so far; an audit mismatch without a violated bound (the rule itself would
+// be wrong) falls back to the doubled single-value bound with no pair bound.  adanerf_info follows, adanerf_stats.guard_widened
+// counts.  Non-blocking: looks only at a copy that has already arrived.
 void poll_guard(adanerf_ctx* c) {
   if (!c->guard_ev_pending) return;
   const hipError_t q = hipEventQuery(c->guard_ev);
   (void)hipGetLastError();      // hipErrorNotReady is not a failure of this context
   if (q != hipSuccess) return;
   c->guard_ev_pending = false;
-  float seen;
+  float seen, pair;
   std::memcpy(&seen, &c->guard_host[0], sizeof(seen));
-  const int viol = c->guard_host[1];
+  std::memcpy(&pair, &c->guard_host[2], sizeof(pair));
+  const int viol = c->guard_host[1], mism = c->guard_host[3];
+  bool widened = false;
   if (viol > c->guard_viol_seen) {
     c->guard_viol_seen = viol;
-    const float wider = ADANERF_GUARD_CALIB_MARGIN * seen;
-    if (wider > c->guard_eps) {
-      c->guard_eps = wider;
-      c->info.guard_eps = wider;
-      ++c->guard_widened;
+    if (seen > c->guard_eps) {
+      // the bound on single values was exceeded: widen it, and drop the measured pair bound -- it was measured over the candidates
+      // the narrower band defined; 2 x the new bound is what holds by construction
+      c->guard_eps = ADANERF_GUARD_CALIB_MARGIN * seen;
+      c->guard_eps_pair = 2.0f * c->guard_eps;
+      widened = true;
+    } else if (pair > c->guard_eps_pair) {
+      c->guard_eps_pair = ADANERF_GUARD_CALIB_MARGIN * pair;
+      widened = true;
     }
+  }
+  if (mism > c->guard_mism_seen) {
+    c->guard_mism_seen = mism;
+    if (!widened) {
+      c->guard_eps *= 2.0f;
+      c->guard_eps_pair = 2.0f * c->guard_eps;
+      widened = true;
+    }
+  }
+  if (widened) {
+    c->guard_eps_pair = std::min(std::max(c->guard_eps_pair, ADANERF_GUARD_EPS_MIN), 2.0f * c->guard_eps);
+    c->info.guard_eps = c->guard_eps;
+    c->info.guard_eps_pair = c->guard_eps_pair;
+    c->info.guard_calib_source = ADANERF_GUARD_FROM_MONITOR;
+    ++c->guard_widened;
   }
 }
 
@@ -1590,17 +1834,18 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
     }
     if (ev) {
       HIP_TRY(c, hipEventRecord(ev[4], c->stream));
-      HIP_TRY(c, hipMemcpyAsync(c->pinned_totals[c->events_used / 5], total, 10 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(c->pinned_totals[c->events_used / 5], total, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
       c->events_used += 5;
     }
   }
+  if (c->sampling_mode == ADANERF_SAMPLING_GUARDED && c->guard_mask.p && n_batches > 0) ++c->guard_frame;      // the audit moves on
   if (c->sampling_mode == ADANERF_SAMPLING_GUARDED && c->guard_mask.p && n_batches > 0 && !c->guard_ev_pending) {
     if (!c->guard_host) {
-      HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->guard_host), 2 * sizeof(int32_t)));
-      c->guard_host[0] = c->guard_host[1] = 0;
+      HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->guard_host), 8 * sizeof(int32_t)));
+      std::memset(c->guard_host, 0, 8 * sizeof(int32_t));
       HIP_TRY(c, hipEventCreateWithFlags(&c->guard_ev, hipEventDisableTiming));
     }
-    HIP_TRY(c, hipMemcpyAsync(c->guard_host, total + 8, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->guard_host, total + 8, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipEventRecord(c->guard_ev, c->stream));
     c->guard_ev_pending = true;
   }
@@ -1623,6 +1868,7 @@ int adanerf_render(adanerf_ctx* c, void* d_rgba8, float* d_rgb, adanerf_stats* s
 
 int adanerf_set_aux_outputs(adanerf_ctx* c, float* d_depth_map, float* d_acc_map) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   c->aux_depth = d_depth_map;
   c->aux_acc = d_acc_map;
   return ADANERF_OK;
@@ -1630,6 +1876,7 @@ int adanerf_set_aux_outputs(adanerf_ctx* c, float* d_depth_map, float* d_acc_map
 
 int adanerf_set_disp_output(adanerf_ctx* c, float* d_disp_map) {
   if (!c) return ADANERF_EINVAL;
+  BIND(c);
   c->aux_disp = d_disp_map;
   return ADANERF_OK;
 }

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const float* __restric
   const int local = first + j;
   const bool valid = local < n_rays;
   const int lidx = valid ? local : n_rays - 1;
-  const float* row = oracle + static_cast<size_t>(n_list ? so.refine_list[lidx] : lidx) * kBins;
+  const float* row = oracle + static_cast<size_t>(n_list ? (so.refine_list[lidx] & kRefineRayMask) : lidx) * kBins;
   float x[64];
 #pragma unroll
   for (int m = 0; m < 4; ++m)
@@ -222,6 +222,52 @@ __global__ __launch_bounds__(256) void max_abs_diff_kernel(const float* __restri
   if ((threadIdx.x & 63) == 0) {
     if (m > 0.f) atomicMax(&out[0], __builtin_bit_cast(uint32_t, m));
     if (anybad) atomicAdd(&out[1], 1u);
+  }
+}
+
+// Calibration of the guarded selection's two bounds on [n_rays,128] raw outputs of the plain-fp16 engine (y) and the split engine (x);
+// the statistics pair_monitor measures on every frame, over whole rows.  One wave per ray (lane: bins lane and lane + 64).
+//   out[0]  max |y - x|                                     (float bits, atomicMax)
+//   out[1]  rays with a non-finite difference               (atomicAdd)
+//   out[2]  two_eps > 0 only: max over rays of (y_i - x_i) - (y_j - x_j), i kept by the selection from y (n_max largest that reach thr,
+//           or the arg-max), j a candidate that is not: max(v_n - two_eps, thr - two_eps / 2) <= y_j < cut value (arg-max fallback:
+//           v_1 - two_eps).  The sign that could make j overtake i; see pair_select.
+__global__ __launch_bounds__(256) void guard_stats_kernel(const float* __restrict__ y, const float* __restrict__ x, int n_rays, int n_max, float thr,
+                                                          float two_eps, uint32_t* __restrict__ out) {
+  const int lane = lane_id();
+  const int r = blockIdx.x * 4 + (static_cast<int>(threadIdx.x) >> 6);
+  if (r >= n_rays) return;   // wave-uniform
+  const float* yr = y + static_cast<size_t>(r) * kBins;
+  const float* xr = x + static_cast<size_t>(r) * kBins;
+  const float y0 = yr[lane], y1 = yr[64 + lane];
+  const float d0 = y0 - xr[lane], d1 = y1 - xr[64 + lane];
+  const bool f0 = fabsf(d0) < INFINITY, f1 = fabsf(d1) < INFINITY;
+  const float ma = wave_max_f32(fmaxf(f0 ? fabsf(d0) : 0.f, f1 ? fabsf(d1) : 0.f));
+  const uint64_t bad = __ballot(!f0 || !f1);
+  float mp = 0.f;
+  if (two_eps > 0.f && !bad) {
+    float a0 = y0, a1 = y1, c0 = 0.f, tn = 0.f;
+    for (int k = 0; k < n_max; ++k) {      // the n_max largest values of the row, one per round
+      const float m = wave_max_f32(fmaxf(a0, a1));
+      if (k == 0) c0 = m;
+      tn = m;
+      const uint64_t e0 = __ballot(a0 == m), e1 = __ballot(a1 == m);
+      if (e0) {
+        if (lane == __builtin_ctzll(e0)) a0 = -INFINITY;
+      } else if (lane == __builtin_ctzll(e1)) a1 = -INFINITY;
+    }
+    const bool none = c0 < thr;
+    const float t = none ? c0 : fmaxf(tn, thr);
+    const float cut = none ? c0 - two_eps : fmaxf(tn - two_eps, thr - 0.5f * two_eps);
+    const float dk = wave_max_f32(fmaxf(y0 >= t ? d0 : -INFINITY, y1 >= t ? d1 : -INFINITY));
+    const float dn = -wave_max_f32(fmaxf((y0 >= cut && y0 < t) ? -d0 : -INFINITY, (y1 >= cut && y1 < t) ? -d1 : -INFINITY));
+    const float pr = dk - dn;
+    mp = (pr > 0.f && pr < INFINITY) ? pr : 0.f;
+  }
+  if (lane == 0) {
+    if (ma > 0.f) atomicMax(&out[0], __builtin_bit_cast(uint32_t, ma));
+    if (bad) atomicAdd(&out[1], 1u);
+    if (mp > 0.f) atomicMax(&out[2], __builtin_bit_cast(uint32_t, mp));
   }
 }
 
@@ -311,28 +357,35 @@ __global__ __launch_bounds__(256) void expand_kernel(const int32_t* __restrict__
   }
 }
 
-// Guarded selection, between its two passes: the ascending list of the rays whose guard bit is set (one word per 32 rays,
-// written by pair_epilogue) and their number.  256 words (8 192 rays) per workgroup; like expand_kernel every workgroup sums what
-// lies in front of it instead of waiting for a scan (<= 80 KB of L2 reads per workgroup at 800 x 800).  Deterministic order.
-__global__ __launch_bounds__(256) void refine_list_kernel(const uint32_t* __restrict__ mask, int n_words, int32_t* __restrict__ list,
-                                                          int32_t* __restrict__ count) {
+// Guarded selection, between its two passes: the ascending list of the rays to re-evaluate and their number -- the rays whose guard
+// bit is set (one word per 32 rays, written by pair_epilogue) and the rays audited in this frame (audit_bits: a rotating 1 / period of all
+// rays; an audited ray that pass 1 had decided carries kRefineAuditBit in its entry).  256 words (8 192 rays) per workgroup; like
+// expand_kernel every workgroup sums what lies in front of it instead of waiting for a scan (<= 80 KB of L2 reads per workgroup at
+// 800 x 800).  Deterministic order.
+__global__ __launch_bounds__(256) void refine_list_kernel(const uint32_t* __restrict__ mask, int n_words, int n_rays, int period, int phase,
+                                                          int32_t* __restrict__ list, int32_t* __restrict__ count) {
   __shared__ int part[4], wtot[4];
   const int t = static_cast<int>(threadIdx.x);
   const int b0 = blockIdx.x * 256;
   int s = 0;
-  {   // b0 is a multiple of 256 words: 16-byte loads, four in flight per thread (the loop is latency-, not bandwidth-bound)
+  {   // b0 is a multiple of 256 words: 16-byte loads, four in flight per thread (the loop is latency-, not bandwidth-bound); none of
+      // these words is the batch's last one, so every audit bit in them is a ray
     const uint4* m4 = reinterpret_cast<const uint4*>(mask);
     const int n4 = b0 >> 2;
 #pragma unroll 4
     for (int i = t; i < n4; i += 256) {
       const uint4 v = m4[i];
-      s += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+      s += __popc(v.x | audit_bits(period, phase, 4 * i)) + __popc(v.y | audit_bits(period, phase, 4 * i + 1)) +
+           __popc(v.z | audit_bits(period, phase, 4 * i + 2)) + __popc(v.w | audit_bits(period, phase, 4 * i + 3));
     }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   const int wi = b0 + t;
-  const uint32_t m = wi < n_words ? mask[wi] : 0u;
+  const uint32_t und = wi < n_words ? mask[wi] : 0u;
+  const int left = n_rays - wi * 32;                                       // rays this word covers (the last word may be partial)
+  const uint32_t in_range = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? low_bits32(left) : 0u);
+  const uint32_t m = (und | audit_bits(period, phase, wi)) & in_range;
   const int c = __popc(m);
   int x = c;                                      // inclusive scan inside the wave
   for (int off = 1; off < 64; off <<= 1) {
@@ -344,7 +397,10 @@ __global__ __launch_bounds__(256) void refine_list_kernel(const uint32_t* __rest
   __syncthreads();
   int base = part[0] + part[1] + part[2] + part[3] + x - c;
   for (int w = 0; w < (t >> 6); ++w) base += wtot[w];
-  for (uint32_t r = m; r; r &= r - 1u) list[base++] = wi * 32 + __builtin_ctz(r);
+  for (uint32_t r = m; r; r &= r - 1u) {
+    const int bit = __builtin_ctz(r);
+    list[base++] = (wi * 32 + bit) | (((und >> bit) & 1u) ? 0 : kRefineAuditBit);
+  }
   if (blockIdx.x == gridDim.x - 1 && t == 255) *count = base;      // the last thread's end = the total
 }
 

@@ -210,9 +210,13 @@ template <int W>
 constexpr int gen_blocks() {
   return W == 64 ? 2 : W == 128 ? tune::kGenericBlocks128 : tune::kGenericBlocks256;
 }
-template <int W>
+// FP: the encoding layout of the instantiation.  Three workgroups per CU at width 128 are for the 10-4 layout only (168 registers);
+// the catch-all 16-band layout needs 184 and its LDS footprint (~58 KB per workgroup) admits two anyway -- asking for three there only
+// made the compiler spill towards a target it could not meet.
+template <int W, int FP = 10>
 constexpr int gen_occupancy() {
-  return W == 64 ? 2 : W == 128 ? (tune::kGenericOcc128 ? tune::kGenericOcc128 : tune::kGenericBlocks128 == 2 ? 1 : 2) : 1;
+  return W == 64 ? 2 : W == 128 ? (tune::kGenericOcc128 ? (FP <= 10 ? tune::kGenericOcc128 : (tune::kGenericOcc128 < 2 ? tune::kGenericOcc128 : 2))
+                                                        : tune::kGenericBlocks128 == 2 ? 1 : 2) : 1;
 }
 
 // A5 + A6 for any shading-net topology on the 16-bit engine, weights staged per tile.  Workgroup = 4 waves x NB x 32 samples.
@@ -399,7 +403,7 @@ __device__ __forceinline__ void layer_16x3_staged(TileStage& st, float (&br)[16]
 // One wave = 32 rays, 4 waves per workgroup; writes the raw outputs (selection by select_rows_kernel, as after the fp32 generic kernel).
 // STAGED: weight tiles through LDS, one copy per workgroup (tuning.hpp kGenericStaged); else every wave fetches its own from L2.
 template <int FP, int FD, int W, bool STAGED>
-__global__ __launch_bounds__(256, (STAGED && (W == 64 || (W == 128 && FP <= 10))) ? 2 : 1) void sample_mlp16x3_gen_kernel(SampleArgs a, GenericTopo t) {
+__global__ __launch_bounds__(256, (STAGED && W <= 128 && FP <= 10) ? 2 : 1) void sample_mlp16x3_gen_kernel(SampleArgs a, GenericTopo t) {
   constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP, MT = W / 32, KW = W / 16;
   constexpr int BUF = (Q0 / 8 > KW ? Q0 / 8 : KW) * 2048;
   __shared__ __attribute__((aligned(1024))) char stage_mem[(STAGED ? 2 * BUF : 0) + 4 * kPairLdsBytesPerWave];      // + staging block of the fused selection

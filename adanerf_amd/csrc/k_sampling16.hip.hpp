@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
     const int local = tile * TILE + wave * 32 + j;
     const bool valid = local < n_rays;
     const int lidx = valid ? local : n_rays - 1;
-    const int ray = a.first_ray + (a.ray_list ? a.ray_list[lidx] : lidx);
+    const int ray = a.first_ray + (a.ray_list ? (a.ray_list[lidx] & kRefineRayMask) : lidx);
     int col, row;
     ray_pixel(a.g, ray, &col, &row);
     float nds[3], p[3], u[3];
@@ -243,6 +243,11 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
 // 11-bit operands move a few outputs across the threshold / the N-th rank (raw error <= 3e-3), so the selected bins
 // differ from the fp32 PyTorch path on 0.3-1.5 % of rays: an opt-in speed mode, never the default.  Same engine as the shading
 // kernel (8 waves x 32 rays per workgroup, activations in registers, weights through the LDS ring).
+// Revision of the arithmetic of the two engines the guarded selection compares (this kernel: encoding, operand rounding, summation
+// order; sample_mlp16x3_kernel likewise): part of the key of the calibration record (adanerf_guard_calibration_file) -- bump it
+// with any change that moves the raw outputs, so that recorded error bounds of another engine are measured again.
+constexpr int kGuardEngineRev = 4;
+
 template <int FP, int FD>
 constexpr int sample16_frags() { return ((pe_slots(FD) + pe_slots(FP)) / 8) * 8 + 6 * 128 + 64; }
 

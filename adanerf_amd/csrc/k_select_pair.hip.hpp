@@ -19,16 +19,34 @@ struct SelectOut {
   int32_t transform;    // kOracle*: what the sampler applies to the raw network outputs first (losses[0])
   // Guard-banded two-precision selection (ADANERF_SAMPLING_GUARDED, see pair_select):
   uint32_t* guard_mask;        // pass 1 (plain-fp16 engine): [ceil(R / 32)] bit j of word s set <=> ray 32 s + j is undecided
-  float guard_eps;             //   guard_band_of(transform, bound on |fp16-engine output - split-engine output| per raw value)
-  const int32_t* refine_list;  // pass 2 (split engine on the undecided rays only): `local` indexes this list of ray ids; the
-                               //   ray's counts / selbin / selw are overwritten and seg_total corrected by the count difference
-  // Monitor of the assumption behind the band: pass 1 leaves the largest (transformed) value of every undecided ray in
-  // guard_probe[ray]; pass 2 compares it with its own and keeps the largest difference seen (guard_seen[0], float bits) and the
-  // number of rays where it exceeded the band (guard_seen[1]).  A sample of the error, for free, on every frame.
+  float guard_eps;             //   guard_band_of(transform, eps): bound on |fp16-engine output - split-engine output| per raw value
+  float guard_pair;            //   guard_pair_of(transform, eps, eps_pair): bound on the error of a DIFFERENCE of two candidate values
+  int32_t audit_period;        //   > 0 (a power of two <= 32): besides the undecided rays, ray j of 32-ray segment s is re-evaluated when
+  int32_t audit_phase;         //   ((j - phase - s) & (period - 1)) == 0 -- a rotating 1 / period of ALL rays, the decided ones included
+  const int32_t* refine_list;  // pass 2 (split engine on the listed rays only): `local` indexes this list of ray ids (bit 30 set: the
+                               //   ray was DECIDED by pass 1 and is audited: its row is compared, not overwritten); otherwise the ray's
+                               //   counts / selbin / selw are overwritten and seg_total corrected by the count difference
+  // Monitor of the assumptions behind the band, on every re-evaluated ray: pass 1 leaves the ray's RAW first-pass outputs in
+  // guard_rows[ray] and the value from which a bin is a candidate for the kept set in guard_probe[ray]; pass 2 compares the whole row with its own
+  // raw outputs and keeps (guard_seen, cumulative): [0] the largest |difference| (float bits), [1] rays where a bound was exceeded,
+  // [2] the largest error of a (kept, candidate-not-kept) difference (float bits), [3] audited rays whose pass-1 selection differs from the
+  // exact one, [4] audited rays.
   float* guard_probe;          // [R] or null
-  uint32_t* guard_seen;        // [2] or null
-  float guard_band;            // pass 2: the band pass 1 used (guard_eps is 0 there)
+  float* guard_rows;           // [R,128] or null (pass 1 writes, pass 2 reads)
+  uint32_t* guard_seen;        // [5] or null
+  float guard_band;            // pass 2: the RAW-unit bound on a value's error pass 1 ran with (guard_eps is 0 there)
+  float guard_band_pair;       // pass 2: the RAW-unit bound on a difference's error (0: the sampler transforms its values, no such bound in use)
 };
+
+constexpr int32_t kRefineAuditBit = 1 << 30;      // refine_list entry: the ray was decided by pass 1 (audit only)
+constexpr int32_t kRefineRayMask = kRefineAuditBit - 1;
+
+// the rays of segment `seg` (32 consecutive rays) that are audited at `phase`: bits j with ((j - phase - seg) & (period - 1)) == 0
+__host__ __device__ inline uint32_t audit_bits(int period, int phase, int seg) {
+  if (period <= 0) return 0u;
+  const uint32_t pattern = period >= 32 ? 1u : 0xFFFFFFFFu / ((1u << period) - 1u);      // bits 0, period, 2 period, ...
+  return pattern << ((phase + seg) & (period - 1));
+}
 
 // src/nerf_raymarch_common.py:624-630 / 686-690: BCEWithLogitsLoss -> sigmoid, CrossEntropyLoss[Weighted] -> softmax over the bins
 constexpr int kOracleRaw = 0, kOracleSigmoid = 1, kOracleSoftmax = 2;
@@ -36,6 +54,13 @@ constexpr int kOracleRaw = 0, kOracleSigmoid = 1, kOracleSoftmax = 2;
 // SelectOut::guard_eps for a bound eps on the raw outputs (host side; see pair_select)
 inline float guard_band_of(int transform, float eps) {
   return transform == kOracleSigmoid ? 0.25f * eps : (transform == kOracleSoftmax ? 1.01f * (__builtin_expf(2.0f * eps) - 1.0f) : eps);
+}
+// SelectOut::guard_pair: the bound on the error of a difference of two values.  Raw outputs: eps_pair as measured (never more than
+// 2 eps, which the bound on single values already implies).  A transformed sampler (sigmoid / softmax) scales the two errors of a pair
+// by different slopes, so only 2 x the transformed single-value bound holds there.
+inline float guard_pair_of(int transform, float eps, float eps_pair) {
+  if (transform != kOracleRaw || !(eps_pair > 0.f) || eps_pair > 2.0f * eps) return 2.0f * guard_band_of(transform, eps);
+  return eps_pair;
 }
 
 constexpr int kPairSegShift = 5;                 // a wave selects for 32 rays = one entry of seg_total
@@ -100,13 +125,20 @@ __device__ __forceinline__ int pair_below(uint32_t qlo, uint32_t qhi, int g) {  
 // as eps_raw, guard_band_of(), so that no loop-invariant VGPR is held across the MLP for it), a ray is decided iff
 //   (a) none of its n_max largest values lies within e of thr (membership of {x >= thr} is then the same for x and y; smaller
 //       values are either below thr - e or cut off by (b)),
-//   (b) exactly as many values reach u = max(v_n - 2 e, thr - e) as reach the cut value t (no value that could overtake the
-//       n_max-th one; for the arg-max fallback u = v_1 - 2 e: the runner-up is more than 2 e behind),
+//   (b) exactly as many values reach u = max(v_n - ep, thr - e) as reach the cut value t (no value that could overtake the
+//       n_max-th one; for the arg-max fallback u = v_1 - ep: the runner-up is more than ep behind).  ep bounds the error of a
+//       DIFFERENCE between a kept value and a not-kept candidate (a value from max(v_n - 2 e, thr - e) upwards; anything below that is
+//       out of reach by the bound on single values): x_j >= x_i needs (y_i - x_i) - (y_j - x_j) >= y_i - y_j > ep.  ep = 2 e
+//       always holds; for untransformed outputs the host may pass a smaller measured bound (guard_pair_of: errors of the outputs of one
+//       ray are correlated, the measured one-sided pair error is ~0.6 of 2 max|error|),
 //   (c) no tie at the cut and no non-finite value.
+// *cand_cut (when asked for) = max(v_n - 2 e, thr - e) (arg-max fallback: v_1 - 2 e), *kept_cut = t: what the monitor of pass 2 needs to
+// find the kept set and the candidates of this ray again.
 // Everything is derived from the merged sorted list c[] plus ONE counting pass over the lane's 64 values.
 template <int NB>
 __device__ __forceinline__ int pair_select(const float* x, int h, int n_max, float thr, uint32_t* sel_lo, uint32_t* sel_hi,
-                                           float eps_raw = 0.f, int transform = 0, bool* undecided = nullptr, float* top = nullptr) {
+                                           float eps_raw = 0.f, int transform = 0, bool* undecided = nullptr, float pair_raw = 0.f,
+                                           float* cand_cut = nullptr, float* kept_cut = nullptr) {
   static_assert(NB == 4 || NB == 8 || NB == 16, "bitonic merge");
   float s[NB];
 #pragma unroll
@@ -140,7 +172,6 @@ __device__ __forceinline__ int pair_select(const float* x, int h, int n_max, flo
   float tn = c[0];
 #pragma unroll
   for (int k = 1; k < NB; ++k) tn = (k == n_max - 1) ? c[k] : tn;
-  if (top) *top = c[0];
   const bool none = c[0] < thr;                       // nothing reaches the threshold: arg-max alone
   const float t = none ? c[0] : fmaxf(tn, thr);
   const int n_eff = none ? 1 : n_max;
@@ -155,7 +186,10 @@ __device__ __forceinline__ int pair_select(const float* x, int h, int n_max, flo
     bool und = tie;
 #pragma unroll
     for (int k = 0; k < NB; ++k) und |= (k < n_max) && (fabsf(c[k] - thr) <= e);
-    const float u = none ? c[0] - 2.0f * e : fmaxf(tn - 2.0f * e, thr - e);
+    const float ep = transform == kOracleSoftmax ? pair_raw * c[0] : pair_raw;      // guard_pair_of(): e < ep <= 2 e
+    const float u = none ? c[0] - ep : fmaxf(tn - ep, thr - e);
+    if (cand_cut) *cand_cut = none ? c[0] - 2.0f * e : fmaxf(tn - 2.0f * e, thr - e);
+    if (kept_cut) *kept_cut = t;
     int cu = 0;
 #pragma unroll
     for (int i = 0; i < 64; ++i) cu += (x[i] >= u) ? 1 : 0;
@@ -202,16 +236,8 @@ __device__ __forceinline__ int pair_select(const float* x, int h, int n_max, flo
   return total;
 }
 
-// wave64 max of non-negative floats (their bit patterns order like unsigned integers); every lane gets the result
-__device__ __forceinline__ float wave_max_nonneg(float v) {
-  uint32_t x = __builtin_bit_cast(uint32_t, v);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const uint32_t y = static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), off));
-    x = x > y ? x : y;
-  }
-  return __builtin_bit_cast(float, x);
-}
+// wave64 max of non-negative floats, every lane gets the result (in-row DPP steps + readlanes: stays in the VALU, k_common.hip.hpp)
+__device__ __forceinline__ float wave_max_nonneg(float v) { return wave_max_f32(v); }
 
 // hand-issued LDS accesses (hipcc would otherwise order them against the LDS-DMA weight ring with vmcnt(0): see k_mlp16.hip.hpp)
 __device__ __forceinline__ void pair_lds_write4(uint32_t byte_addr, float a, float b, float c, float d) {
@@ -227,11 +253,14 @@ __device__ __forceinline__ float pair_lds_read(uint32_t byte_addr) {
 // Writes the kept (bin, value) pairs of this lane in ascending-bin order of the RAY: slot = rank among the ray's kept bins.
 // The values are staged in a wave-private LDS block so that a lane can fetch x[i] for a run-time i (a register array cannot be
 // indexed dynamically); `stage` = LDS byte address of the wave's block + lane * 16.
-__device__ __forceinline__ void pair_emit(const float* x, uint32_t lo, uint32_t hi, int h, uint32_t stage, bool valid, size_t slot0,
-                                          uint8_t* __restrict__ selbin, float* __restrict__ selw) {
+// write == false (per lane; the audit of a decided ray in pass 2 of the guarded selection): nothing is stored -- the bins in place are
+// compared with this lane's instead; returns whether any differs.
+__device__ __forceinline__ bool pair_emit(const float* x, uint32_t lo, uint32_t hi, int h, uint32_t stage, bool valid, size_t slot0,
+                                          uint8_t* __restrict__ selbin, float* __restrict__ selw, bool write = true) {
   uint32_t qlo, qhi;
   pair_align(pair_xchg(lo), pair_xchg(hi), h, &qlo, &qhi);
   const int nlo = __popc(lo);
+  bool differs = false;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous pass's reads are done before the block is overwritten
@@ -246,10 +275,48 @@ __device__ __forceinline__ void pair_emit(const float* x, uint32_t lo, uint32_t 
       m &= m - 1u;
       const float v = pair_lds_read(stage + (i >> 2) * 1024 + (i & 3) * 4);
       const int rank = (pass ? nlo : 0) + __popc(own & low_bits32(i)) + pair_below(qlo, qhi, (32 * pass + i) >> 2);
-      selbin[slot0 + rank] = static_cast<uint8_t>(act_feature(32 * pass + i, h));
-      selw[slot0 + rank] = v;
+      const uint8_t bin = static_cast<uint8_t>(act_feature(32 * pass + i, h));
+      if (write) {
+        selbin[slot0 + rank] = bin;
+        selw[slot0 + rank] = v;
+      } else {
+        differs |= selbin[slot0 + rank] != bin;
+      }
     }
   }
+  return differs;
+}
+
+// Monitor of the guarded selection (pass 2): this lane's 64 exact raw outputs x against the ray's first-pass raw outputs (row = that
+// ray's [128] floats in HBM, the layout pass 1 / the oracle buffer use).  *m_abs = largest |y - x| of the ray, *m_pair = largest
+// (y_i - x_i) - (y_j - x_j) over kept bins i (y_i >= kept_cut) and candidates j (cand_cut <= y_j < kept_cut); both for the whole ray
+// (the two lanes that share it agree).  A non-finite difference counts as 0: such a ray is re-evaluated because of it.
+__device__ __forceinline__ void pair_monitor(const float* x, const float* __restrict__ row, int h, float cand_cut, float kept_cut, bool pairs,
+                                             float* m_abs, float* m_pair) {
+  float ma = 0.f, dk = -INFINITY, dn = INFINITY;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 y4 = *reinterpret_cast<const float4*>(row + 32 * m + 8 * g + 4 * h);
+      const float y[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = y[e] - x[16 * m + 4 * g + e];
+        const bool fin = fabsf(d) < INFINITY;      // false for NaN, too
+        ma = fin ? fmaxf(ma, fabsf(d)) : ma;
+        if (pairs) {
+          dk = (fin && y[e] >= kept_cut) ? fmaxf(dk, d) : dk;
+          dn = (fin && y[e] >= cand_cut && y[e] < kept_cut) ? fminf(dn, d) : dn;
+        }
+      }
+    }
+  ma = fmaxf(ma, pair_xchg(ma));
+  dk = fmaxf(dk, pair_xchg(dk));
+  dn = fminf(dn, pair_xchg(dn));
+  *m_abs = ma;
+  const float pr = dk - dn;      // -inf when the ray has no kept value or no candidate below the cut
+  *m_pair = (pairs && pr > 0.f && pr < INFINITY) ? pr : 0.f;
 }
 
 // The whole epilogue for one wave's 32 rays: select, emit, per-ray counts, segment total.
@@ -285,29 +352,51 @@ __device__ __forceinline__ void pair_epilogue(const float* x_raw, int lane, int 
   uint32_t lo, hi;
   int total;
   bool und = false;
-  float top = 0.f;
+  float cand_cut = 0.f, kept_cut = 0.f;
   const float eps = so.guard_eps;      // pass 1: the band; 0 otherwise (host) -- a plain kernel argument, no per-lane select
-  if (so.n_max <= 4) total = pair_select<4>(x, h, so.n_max, so.thr, &lo, &hi, eps, so.transform, &und, &top);
-  else if (so.n_max <= 8) total = pair_select<8>(x, h, so.n_max, so.thr, &lo, &hi, eps, so.transform, &und, &top);
-  else total = pair_select<16>(x, h, so.n_max, so.thr, &lo, &hi, eps, so.transform, &und, &top);
+  if (so.n_max <= 4) total = pair_select<4>(x, h, so.n_max, so.thr, &lo, &hi, eps, so.transform, &und, so.guard_pair, &cand_cut, &kept_cut);
+  else if (so.n_max <= 8) total = pair_select<8>(x, h, so.n_max, so.thr, &lo, &hi, eps, so.transform, &und, so.guard_pair, &cand_cut, &kept_cut);
+  else total = pair_select<16>(x, h, so.n_max, so.thr, &lo, &hi, eps, so.transform, &und, so.guard_pair, &cand_cut, &kept_cut);
   if (so.refine_list) {
-    // pass 2 of the guarded selection: this wave's rays are scattered over the batch; replace the ray's row and correct the
-    // total of its 32-ray segment by the difference (integer atomics: the result does not depend on their order)
-    const int target = valid ? so.refine_list[local] : 0;
-    if (so.guard_probe) {
-      const float band = so.transform == kOracleSoftmax ? so.guard_band * top : so.guard_band;
-      float d = (valid && h == 0) ? fabsf(top - so.guard_probe[target]) : 0.f;
-      if (!(d == d)) d = 0.f;                                   // a non-finite first-pass value is why the ray is here
-      const uint64_t over = __ballot(d > band);
-      d = wave_max_nonneg(d);
+    // pass 2 of the guarded selection: this wave's rays are scattered over the batch.  An undecided ray: replace its row and correct
+    // the total of its 32-ray segment by the difference (integer atomics: the result does not depend on their order).  A ray pass 1
+    // had decided (audit): compare the row in place with the exact selection, store nothing -- the frame does not depend on which
+    // rays were audited.
+    const int entry = valid ? so.refine_list[local] : 0;
+    const int target = entry & kRefineRayMask;
+    const bool audit = (entry & kRefineAuditBit) != 0;
+    if (so.guard_rows && so.guard_seen) {
+      // the assumptions behind the band, measured on the whole row in RAW units (x_raw: before the sampler's transform)
+      const bool pairs = so.guard_band_pair > 0.f && so.guard_probe != nullptr;
+      float cc = 0.f, kc = 0.f;
+      if (pairs) {
+        const float2 pr = *reinterpret_cast<const float2*>(so.guard_probe + 2 * static_cast<size_t>(target));
+        cc = pr.x;
+        kc = pr.y;
+      }
+      float ma, mp;
+      pair_monitor(x_raw, so.guard_rows + static_cast<size_t>(target) * kBins, h, cc, kc, pairs, &ma, &mp);
+      if (!(valid && h == 0)) ma = mp = 0.f;
+      const uint64_t over = __ballot(ma > so.guard_band || (pairs && mp > so.guard_band_pair));
+      ma = wave_max_nonneg(ma);
+      mp = wave_max_nonneg(mp);
       if (lane == 0) {
-        if (d > 0.f) atomicMax(&so.guard_seen[0], __builtin_bit_cast(uint32_t, d));
+        if (ma > 0.f) atomicMax(&so.guard_seen[0], __builtin_bit_cast(uint32_t, ma));
+        if (mp > 0.f) atomicMax(&so.guard_seen[2], __builtin_bit_cast(uint32_t, mp));
         if (over) atomicAdd(&so.guard_seen[1], static_cast<uint32_t>(__popcll(over)));
       }
     }
-    pair_emit(x, lo, hi, h, stage, valid, static_cast<size_t>(target) * so.n_max, so.selbin, so.selw);
-    if (valid && h == 0) {
-      const int old = so.counts[target];
+    const int old = valid ? so.counts[target] : 0;
+    bool differs = pair_emit(x, lo, hi, h, stage, valid, static_cast<size_t>(target) * so.n_max, so.selbin, so.selw, !audit);
+    differs = (differs | (pair_xchg(static_cast<uint32_t>(differs)) != 0u) | (total != old)) && audit && valid;
+    if (so.guard_seen) {
+      const uint64_t aud = __ballot(audit && valid && h == 0), bad = __ballot(differs && h == 0);
+      if (lane == 0) {
+        if (aud) atomicAdd(&so.guard_seen[4], static_cast<uint32_t>(__popcll(aud)));
+        if (bad) atomicAdd(&so.guard_seen[3], static_cast<uint32_t>(__popcll(bad)));
+      }
+    }
+    if (valid && h == 0 && !audit) {
       so.counts[target] = total;
       if (total != old) atomicAdd(&so.seg_total[target >> kPairSegShift], total - old);
     }
@@ -322,7 +411,19 @@ __device__ __forceinline__ void pair_epilogue(const float* x_raw, int lane, int 
     const bool u = (und | force_undecided) && valid;
     const uint64_t b = __ballot(u);      // lanes j and j + 32 agree; bits 0..31 = the rays
     if (lane == 0 && valid) so.guard_mask[local >> kPairSegShift] = static_cast<uint32_t>(b);
-    if (so.guard_probe && u && h == 0) so.guard_probe[local] = top;
+    // what pass 2 monitors: the raw first-pass row and the two cut values of every ray it will look at (undecided or audited)
+    const bool aud = so.audit_period > 0 && (((lane & 31) - so.audit_phase - (local >> kPairSegShift)) & (so.audit_period - 1)) == 0;
+    const bool keep = (u | aud) && valid;
+    if (so.guard_probe && keep && h == 0) *reinterpret_cast<float2*>(so.guard_probe + 2 * static_cast<size_t>(local)) = make_float2(cand_cut, kept_cut);
+    if (so.guard_rows && keep) {
+      float* row = so.guard_rows + static_cast<size_t>(local) * kBins;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(row + 32 * m + 8 * g + 4 * h) =
+              make_float4(x_raw[16 * m + 4 * g], x_raw[16 * m + 4 * g + 1], x_raw[16 * m + 4 * g + 2], x_raw[16 * m + 4 * g + 3]);
+    }
   }
   if (lane == 0 && valid) so.seg_total[local >> kPairSegShift] = t;   // lane 0 invalid: the whole wave is beyond n_rays
 }

@@ -179,8 +179,10 @@ bool NeuralRenderer::render() {
     guard_widened_seen = st.guard_widened;
     adanerf_info now;
     if (adanerf_get_info(ctx, &now) == ADANERF_OK)
-      std::cout << "guarded sampling: " << st.guard_violations << " re-evaluated rays differed by more than the band (largest " << st.guard_max_seen
-                << "); band widened to " << now.guard_eps << " for the following frames" << std::endl;
+      std::cout << "guarded sampling: " << st.guard_violations << " re-evaluated rays exceeded a measured bound (largest output error " << st.guard_max_seen
+                << ", largest pair error " << st.guard_pair_seen << "), audit: " << st.guard_audit_mismatch << " of " << st.guard_audited
+                << " decided rays selected differently; bounds widened to " << now.guard_eps << " / " << now.guard_eps_pair
+                << " for the following frames" << std::endl;
   }
   s_inference1 += st.ms_sample_mlp;
   s_inference2 += st.ms_shade_mlp;

@@ -23,7 +23,9 @@ _PREC = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "fp32": PREC_FP
 
 BUF_RAYS, BUF_ORACLE, BUF_RAY_OFFSETS, BUF_RAY_COUNTS, BUF_SAMPLE_KEY, BUF_SAMPLE_W, BUF_RAW, BUF_TOTAL, BUF_SAMPLE_Z, BUF_RAW_COARSE = range(10)
 SAMPLER_ADAPTIVE, SAMPLER_PDF, SAMPLER_COARSE_FINE = 0, 1, 2
-FLAG_KEEP_ORACLE, FLAG_WAVE_SELECT = 1, 2
+FLAG_KEEP_ORACLE, FLAG_WAVE_SELECT, FLAG_NO_GUARD_CACHE = 1, 2, 4
+ABI_VERSION = 4
+GUARD_FROM = {0: "none", 1: "options", 2: "record", 3: "calibration", 4: "monitor"}
 SAMPLING_MODES = {"split": 0, "fp16x3": 0, "fp32": 1, "fp16": 2, "guarded": 3}
 
 
@@ -35,7 +37,8 @@ class _Options(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("batch_rays", C.c_int32), ("device_id", C.c_int32),
                 ("precision", C.c_int32), ("num_samples", C.c_int32), ("threshold", C.c_float),
                 ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("strip_rows", C.c_int32),
-                ("sampling_mode", C.c_int32), ("flags", C.c_int32), ("guard_eps", C.c_float), ("reserved", C.c_int32 * 3)]
+                ("sampling_mode", C.c_int32), ("flags", C.c_int32), ("guard_eps", C.c_float), ("guard_eps_pair", C.c_float),
+                ("guard_audit_period", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class Info(C.Structure):
@@ -44,7 +47,9 @@ class Info(C.Structure):
                 ("num_samples", C.c_int32), ("threshold", C.c_float), ("dense", C.c_int32), ("use_ndc", C.c_int32),
                 ("precision", C.c_int32), ("compute_units", C.c_int32), ("fov", C.c_float), ("focal", C.c_float),
                 ("view_cell_center", C.c_float * 3), ("view_cell_radius", C.c_float), ("depth_range", C.c_float * 2),
-                ("max_depth", C.c_float), ("sampler_mode", C.c_int32), ("view_cell_size", C.c_float * 3), ("num_samples_coarse", C.c_int32), ("guard_eps", C.c_float)]
+                ("max_depth", C.c_float), ("sampler_mode", C.c_int32), ("view_cell_size", C.c_float * 3), ("num_samples_coarse", C.c_int32), ("guard_eps", C.c_float),
+                ("guard_eps_pair", C.c_float), ("guard_audit_period", C.c_int32), ("guard_calib_source", C.c_int32), ("guard_calib_poses", C.c_int32),
+                ("reserved", C.c_int32 * 8)]
 
 
 class Stats(C.Structure):
@@ -52,13 +57,14 @@ class Stats(C.Structure):
                 ("ms_sample_mlp", C.c_float), ("ms_compact", C.c_float), ("ms_shade_mlp", C.c_float),
                 ("ms_composite", C.c_float), ("shade_launches", C.c_int32), ("sample_launches", C.c_int32),
                 ("sampling_overflow", C.c_int32), ("rays_refined", C.c_int32), ("guard_max_seen", C.c_float),
-                ("guard_violations", C.c_int32), ("guard_widened", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("guard_violations", C.c_int32), ("guard_widened", C.c_int32), ("guard_pair_seen", C.c_float), ("guard_audited", C.c_int32),
+                ("guard_audit_mismatch", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
-EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_last_error", "adanerf_set_camera",
+EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_last_error", "adanerf_abi_version", "adanerf_struct_sizes", "adanerf_set_camera",
            "adanerf_render", "adanerf_set_aux_outputs", "adanerf_set_disp_output", "adanerf_assemble_strips", "adanerf_sync", "adanerf_set_stream", "adanerf_set_profiling",
            "adanerf_collect_stats", "adanerf_ray_features", "adanerf_sample_mlp",
-           "adanerf_compact", "adanerf_compact_guarded", "adanerf_calibrate_guard", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_shade_mlp_z", "adanerf_sample_pdf", "adanerf_sample_uniform", "adanerf_shade_mlp_coarse", "adanerf_sample_from_coarse",
+           "adanerf_compact", "adanerf_compact_guarded", "adanerf_calibrate_guard", "adanerf_guard_calibration_file", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_shade_mlp_z", "adanerf_sample_pdf", "adanerf_sample_uniform", "adanerf_shade_mlp_coarse", "adanerf_sample_from_coarse",
            "adanerf_composite", "adanerf_composite_classic", "adanerf_copy_result_sampling_network",
            "adanerf_render_oracle", "adanerf_gather_to", "adanerf_malloc",
            "adanerf_free", "adanerf_memcpy_h2d", "adanerf_memcpy_d2h", "adanerf_get_buffer"]
@@ -93,8 +99,11 @@ def load_library(path: Optional[str] = None):
     lib.adanerf_ray_features.argtypes = [vp, i32, i32, f32p, f32p]
     lib.adanerf_sample_mlp.argtypes = [vp, i32, i32, f32p, f32p]
     lib.adanerf_compact.argtypes = [vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, vp]
-    lib.adanerf_compact_guarded.argtypes = [vp, vp, vp, i32, i32, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp]
-    lib.adanerf_calibrate_guard.argtypes = [vp, i32, C.c_uint32, i32, C.POINTER(C.c_float)]
+    lib.adanerf_compact_guarded.argtypes = [vp, vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.adanerf_calibrate_guard.argtypes = [vp, i32, C.c_uint32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.adanerf_guard_calibration_file.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.adanerf_abi_version.argtypes = []
+    lib.adanerf_struct_sizes.argtypes = [C.POINTER(i32)]
     lib.adanerf_shade_features.argtypes = [vp, vp, vp, i32, vp]
     lib.adanerf_shade_mlp.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     lib.adanerf_composite.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
@@ -115,6 +124,12 @@ def load_library(path: Optional[str] = None):
     for name in EXPORTS:
         if name != "adanerf_last_error":
             getattr(lib, name).restype = C.c_int
+    # the handshake include/adanerf_hip.h asks of a binding: structs are written whole, so version and sizes must agree
+    sizes = (i32 * 3)()
+    lib.adanerf_struct_sizes(sizes)
+    if lib.adanerf_abi_version() != ABI_VERSION or list(sizes) != [C.sizeof(_Options), C.sizeof(Info), C.sizeof(Stats)]:
+        raise AdaNeRFError("%s: ABI %d with struct sizes %s, this host expects ABI %d with %s" %
+                           (p, lib.adanerf_abi_version(), list(sizes), ABI_VERSION, [C.sizeof(_Options), C.sizeof(Info), C.sizeof(Stats)]))
     if path is None:
         _lib = lib
     return lib
@@ -191,8 +206,11 @@ class NeuralRenderer:
 
     def __init__(self, settings: Settings, precision="bf16", device_id: int = 0, num_samples: int = 0,
                  threshold: float = -1.0, shard_rank: int = 0, shard_world: int = 1, strip_rows: int = 8,
-                 sampling: str = "split", lib_path: Optional[str] = None, keep_oracle: bool = False, wave_select: bool = False,
-                 guard_eps: float = 0.0):
+                 sampling: str = "guarded", lib_path: Optional[str] = None, keep_oracle: bool = False, wave_select: bool = False,
+                 guard_eps: float = 0.0, guard_eps_pair: float = 0.0, guard_audit_period: int = 0, guard_cache: bool = True):
+        """sampling: arithmetic of the sampling network -- "guarded" (default, as in the `adanerf` CLI and bench.py: plain fp16 for every
+        ray + the split-precision engine where the audited guard band cannot decide; the split engine's selections), "split", "fp32",
+        "fp16" (opt-in speed mode).  guard_*: include/adanerf_hip.h adanerf_options."""
         self.settings = settings
         self.lib = load_library(lib_path)
         self.handle = None
@@ -200,8 +218,10 @@ class NeuralRenderer:
                              device_id=device_id, precision=_PREC[precision] if isinstance(precision, str) else int(precision),
                              num_samples=num_samples, threshold=threshold, shard_rank=shard_rank,
                              shard_world=shard_world, strip_rows=strip_rows,
-                             sampling_mode=SAMPLING_MODES[sampling], guard_eps=guard_eps,
-                             flags=(FLAG_KEEP_ORACLE if keep_oracle else 0) | (FLAG_WAVE_SELECT if wave_select else 0))
+                             sampling_mode=SAMPLING_MODES[sampling], guard_eps=guard_eps, guard_eps_pair=guard_eps_pair,
+                             guard_audit_period=guard_audit_period,
+                             flags=(FLAG_KEEP_ORACLE if keep_oracle else 0) | (FLAG_WAVE_SELECT if wave_select else 0) |
+                                   (0 if guard_cache else FLAG_NO_GUARD_CACHE))
         self.info = Info()
         self.last_stats = Stats()
         self._own = []
@@ -340,24 +360,36 @@ class NeuralRenderer:
                                              _ptr(ray_counts), _ptr(sample_key), _ptr(sample_w), _ptr(total)))
 
     def compact_guarded(self, oracle_approx, oracle_exact, n_rays: int, n_max: int, thr: float, eps: float, ray_offsets, ray_counts,
-                        sample_key, sample_w, total, refined):
-        self._check(self.lib.adanerf_compact_guarded(self.handle, _ptr(oracle_approx), _ptr(oracle_exact), n_rays, n_max, thr, eps,
-                                                     _ptr(ray_offsets), _ptr(ray_counts), _ptr(sample_key), _ptr(sample_w), _ptr(total),
-                                                     _ptr(refined)))
+                        sample_key, sample_w, total, refined, eps_pair: float = 0.0, audit_period: int = 0, audit_phase: int = 0, monitor=None):
+        """monitor: optional device uint32[5] the caller zeroed (largest error bits, rows beyond a bound, largest pair error bits,
+        audit mismatches, audited rows)."""
+        self._check(self.lib.adanerf_compact_guarded(self.handle, _ptr(oracle_approx), _ptr(oracle_exact), n_rays, n_max, thr, eps, eps_pair,
+                                                     audit_period, audit_phase, _ptr(ray_offsets), _ptr(ray_counts), _ptr(sample_key),
+                                                     _ptr(sample_w), _ptr(total), _ptr(refined), _ptr(monitor)))
 
     def refresh_info(self) -> "Info":
         """Re-reads adanerf_info (guard_eps moves when the band is calibrated or widened after a violation)."""
         self._check(self.lib.adanerf_get_info(self.handle, C.byref(self.info)))
         return self.info
 
-    def calibrate_guard(self, n_poses: int = 8, seed: int = 1, install: bool = False) -> float:
-        """Largest |plain-fp16 - split-precision| raw output over n_poses x 4096 calibration rays; install=True makes
-        ADANERF_GUARD_CALIB_MARGIN x that the context's guard band."""
-        d = C.c_float(0)
-        self._check(self.lib.adanerf_calibrate_guard(self.handle, n_poses, seed, 1 if install else 0, C.byref(d)))
+    def calibrate_guard(self, n_poses: int = 8, seed: int = 1, install: bool = False, pair: bool = False):
+        """Largest |plain-fp16 - split-precision| raw output over n_poses x 4096 calibration rays (pair=True: also the largest
+        error of a (kept - candidate) difference, as a tuple); install=True makes ADANERF_GUARD_CALIB_MARGIN x those the context's
+        bounds and writes the model's calibration record."""
+        d, dp = C.c_float(0), C.c_float(0)
+        self._check(self.lib.adanerf_calibrate_guard(self.handle, n_poses, seed, 1 if install else 0, C.byref(d), C.byref(dp)))
         if install:
             self._check(self.lib.adanerf_get_info(self.handle, C.byref(self.info)))
-        return float(d.value)
+        return (float(d.value), float(dp.value)) if pair else float(d.value)
+
+    def guard_calibration_file(self) -> str:
+        """Path of the calibration record of this context's (model, N, threshold)."""
+        n = self.lib.adanerf_guard_calibration_file(self.handle, None, 0)
+        if n < 0:
+            self._check(n)
+        buf = C.create_string_buffer(n)
+        self.lib.adanerf_guard_calibration_file(self.handle, buf, n)
+        return buf.value.decode()
 
     def shade_features(self, rays, sample_key, n_samples: int, features_out):
         self._check(self.lib.adanerf_shade_features(self.handle, _ptr(rays), _ptr(sample_key), n_samples, _ptr(features_out)))

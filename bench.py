@@ -178,7 +178,9 @@ def main():
     ap.add_argument("--sampling", default="guarded", choices=["split", "fp32", "fp16", "guarded"],
                     help="sampling-MLP arithmetic: guarded (default: plain fp16 + split-fp16 on the rays inside the guard band -- the split "
                          "engine's selections), split-fp16 (fp32-accurate, every ray), exact fp32, or the opt-in plain fp16 speed mode")
-    ap.add_argument("--guard-eps", type=float, default=0.0, help="band of --sampling guarded (0: the library default)")
+    ap.add_argument("--guard-eps", type=float, default=0.0, help="band of --sampling guarded (0: the model's calibration record / measured at the first frame)")
+    ap.add_argument("--guard-audit-period", type=int, default=0, help="--sampling guarded: audit 1 / period of all rays per frame (0: library default 16, < 0: off)")
+    ap.add_argument("--no-exact-mode", action="store_true", help="skip the extra every-ray-split-precision measurement reported under exact_mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-speed-mode", action="store_true", help="skip the extra fp16-sampling measurement reported under speed_mode")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of wall time the CPU baseline may compute (all its cores busy)")
@@ -186,15 +188,16 @@ def main():
                     help="K > 0: step i renders pose i %% K of a K-pose orbit inside the view cell (yaw and position vary) instead of "
                          "the fixed camera; quality / cpu_baseline still refer to pose 0")
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2],
-                    help="N > 1 only: 2 (default there) renders alternate frames on two contexts / streams of the rank, so that the tail "
-                         "rounds, ring prologues and launch gaps of one frame's kernels overlap the next frame's (throughput; a frame's "
-                         "latency doubles); 1: one frame at a time, as on a single GPU")
+                    help="N > 1 only: 1 (default) renders one frame at a time, as on a single GPU and as an interactive viewer needs it; "
+                         "2 renders alternate frames on two contexts / streams of the rank, so that the tail rounds, ring prologues and "
+                         "launch gaps of one frame's kernels overlap the next frame's (more throughput; a frame's latency doubles)")
     ap.add_argument("--dump-image", default=None, help="rank 0 writes the last frame's RGBA8 image [h,w,4] as .npy (tests)")
     args = ap.parse_args()
 
     import torch
     import adanerf_amd
     from adanerf_amd import build as B
+    from adanerf_amd.renderer import GUARD_FROM as R_GUARD_FROM
     from adanerf_amd import modeldir as M
 
     rank = int(os.environ.get("RANK", "0"))
@@ -240,19 +243,19 @@ def main():
     from adanerf_amd import sharding
     strip_rows = sharding.balanced_strip_rows(h, world)
     r = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision, sampling=args.sampling,
-                                   guard_eps=args.guard_eps, device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=strip_rows)
+                                   guard_eps=args.guard_eps, guard_audit_period=args.guard_audit_period, device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=strip_rows)
     r.init()
     r.set_camera(pose, rot)
     # N > 1: a share of the frame is a few rounds of each kernel's persistent grid, and what does not shrink with N (the last,
     # partly filled round, the weight ring's prologue, dependent-launch gaps) is ~15 % of it at N = 8.  Two frames in
     # flight on two contexts / streams let the next frame's kernels take the CUs a kernel's tail leaves idle.
-    fif = args.frames_in_flight or int(os.environ.get("ADANERF_BENCH_FRAMES_IN_FLIGHT", "0")) or (2 if use_dist else 1)
+    fif = args.frames_in_flight or int(os.environ.get("ADANERF_BENCH_FRAMES_IN_FLIGHT", "0")) or 1
     if not use_dist:
         fif = 1
     rs = [r]
     if fif == 2:
         r_b = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision, sampling=args.sampling,
-                                         guard_eps=args.guard_eps, device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=strip_rows)
+                                         guard_eps=args.guard_eps, guard_audit_period=args.guard_audit_period, device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=strip_rows)
         r_b.init()
         r_b.set_camera(pose, rot)
         rs.append(r_b)
@@ -357,7 +360,9 @@ def main():
                     "sample_launches", "rays_refined"):
             setattr(st, fld, getattr(st, fld) + getattr(st2, fld))
         st.guard_max_seen = max(st.guard_max_seen, st2.guard_max_seen)
-        st.guard_violations += st2.guard_violations
+        st.guard_pair_seen = max(st.guard_pair_seen, st2.guard_pair_seen)
+        for fld in ("guard_violations", "guard_audited", "guard_audit_mismatch", "guard_widened"):
+            setattr(st, fld, getattr(st, fld) + getattr(st2, fld))
     r.lib.adanerf_get_info(r.handle, r.info)      # the guard band is calibrated at the first guarded frame
     exchange = None
     if dist:
@@ -405,8 +410,10 @@ def main():
         # committed rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh -> profiles/).  A summary is used
         # only if it was taken with the very sources this library is built from (source_hash), else traffic is null.
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_summary_%s.json" % args.workload)
-        if os.path.exists(pmc_path) and world == 1 and r.info.batch_rays >= r.info.rays_local:
+        import glob
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary_%s.json" % args.workload)))
+        pmc_path = found[-1] if found else ""                 # the latest round's summary of this workload
+        if found and world == 1 and r.info.batch_rays >= r.info.rays_local:
             try:
                 pmc = json.load(open(pmc_path))
                 meta = pmc.get("_meta", {})
@@ -512,6 +519,28 @@ def main():
                     speed["psnr_vs_oracle_db_all_rays"] = psnr(mine2, ref["rgb"])
                     if cnt2 is not None:
                         speed["rays_with_identical_sample_count"] = float((cnt2 == ref["count"]).mean())
+        # the same frame with the split-precision engine on EVERY ray: exact by construction, no band, no audit -- printed next to
+        # the headline so that the cost of that guarantee is on the line
+        exact = None
+        if world == 1 and args.sampling == "guarded" and not args.no_exact_mode and not generic_wl:
+            with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision,
+                                           sampling="split", device_id=local_rank) as r3:
+                r3.set_camera(pose, rot)
+                out3 = r3.empty((w * h, 4), np.uint8)
+                for _ in range(args.warmup):
+                    r3.render(out3, None)
+                r3.sync()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    r3.render(out3, None)
+                r3.sync()
+                dt3 = time.perf_counter() - t1
+                st3 = r3.render(out3, None, stats=True)
+                cnt3 = r3.buffer(3, np.int32, (w * h,)) if r3.info.batch_rays >= w * h else None
+                cnt1 = r.buffer(3, np.int32, (w * h,)) if (cnt3 is not None and not poses) else None
+                exact = {"sampling": "split-fp16 on every ray (ADANERF_SAMPLING_SPLIT_FP16)", "value": args.steps / dt3, "unit": "frames/s",
+                         "sample_mlp_ms": st3.ms_sample_mlp, "samples_per_frame": int(st3.total_samples),
+                         "rays_with_the_headline_modes_sample_count": float((cnt1 == cnt3).mean()) if cnt1 is not None else None}
         rec = {"metric": "FPS at %dx%d" % (w, h), "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": args.precision, "data": data,
@@ -525,12 +554,18 @@ def main():
                           "exchange": exchange,
                           "frames_in_flight": fif,
                           "rays_refined_per_frame": (st.rays_refined / frames) if args.sampling == "guarded" else None,
-                          "guard": ({"eps": float(r.info.guard_eps), "monitor_max_seen": float(st.guard_max_seen),
-                                     "monitor_violations": int(st.guard_violations), "band_widened": int(st.guard_widened)} if args.sampling == "guarded" else None),
+                          "guard": ({"eps": float(r.info.guard_eps), "eps_pair": float(r.info.guard_eps_pair),
+                                     "band_source": R_GUARD_FROM.get(int(r.info.guard_calib_source)), "calibration_poses": int(r.info.guard_calib_poses),
+                                     "monitor_max_seen": float(st.guard_max_seen), "monitor_pair_seen": float(st.guard_pair_seen),
+                                     "monitor_violations": int(st.guard_violations), "band_widened": int(st.guard_widened),
+                                     "audit_period": int(r.info.guard_audit_period), "rays_audited": int(st.guard_audited),
+                                     "audit_mismatches": int(st.guard_audit_mismatch),
+                                     "note": "monitor / audit counters are cumulative since the context was created (warm-up included)"}
+                                    if args.sampling == "guarded" else None),
                           "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame,
                           "camera": ("%d-pose orbit inside the view cell" % args.orbit) if poses else "fixed: view-cell centre, yaw 100 deg"},
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,
-               "sampling_mlp_algorithmic_tflops": smp_tflops, "sampling_roofline": sampling_roofline, "hbm_stages": hbm, "quality": quality, "speed_mode": speed}
+               "sampling_mlp_algorithmic_tflops": smp_tflops, "sampling_roofline": sampling_roofline, "hbm_stages": hbm, "quality": quality, "exact_mode": exact, "speed_mode": speed}
         if shard_samples:
             mean_s = sum(shard_samples) / len(shard_samples)
             rec["shards"] = {"samples_per_frame": shard_samples, "shade_ms_per_frame": shard_shade_ms,

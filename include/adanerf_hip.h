@@ -47,9 +47,15 @@
 extern "C" {
 #endif
 
-#define ADANERF_ABI_VERSION 3   /* 2: adanerf_info.view_cell_size, .num_samples_coarse appended
-                                   3: ADANERF_SAMPLING_GUARDED, adanerf_options.guard_eps, adanerf_stats.rays_refined
-                                      (both carved out of the reserved words: struct sizes unchanged) */
+#define ADANERF_ABI_VERSION 4   /* 2: adanerf_info.view_cell_size, .num_samples_coarse appended
+                                   3: ADANERF_SAMPLING_GUARDED, adanerf_options.guard_eps, adanerf_stats.rays_refined (carved out of
+                                      reserved words), adanerf_info.guard_eps APPENDED (adanerf_info grew by 4 bytes)
+                                   4: audited guard band: adanerf_options.guard_eps_pair / .guard_audit_period (carved out of the
+                                      reserved words: size unchanged); adanerf_info and adanerf_stats GROW (guard fields + reserved
+                                      words for later versions); adanerf_compact_guarded / adanerf_calibrate_guard take more
+                                      arguments.  adanerf_get_info / adanerf_render write the whole struct: a caller checks
+                                      adanerf_abi_version() == ADANERF_ABI_VERSION (and may compare adanerf_struct_sizes with its
+                                      own sizeof) once after loading the library -- there is no per-call size argument */
 
 enum {
   ADANERF_OK = 0,
@@ -70,13 +76,20 @@ enum {
                                       path on 0.3-1.5 % of rays (tools/probes/sampling_agreement.py); 3x faster. */
   ADANERF_SAMPLING_GUARDED = 3     /* two-precision selection with the results of ADANERF_SAMPLING_SPLIT_FP16: every ray goes
                                       through the plain-fp16 engine; a ray whose selection could change under a perturbation
-                                      of guard_eps of its raw outputs (a value within the band around the threshold, the
-                                      N-th / (N+1)-th largest closer than twice the band, a tie, a non-finite value) is
+                                      of guard_eps of its raw outputs (a value within the band around the threshold, a
+                                      not-kept value closer than guard_eps_pair to the N-th largest, a tie, a non-finite value) is
                                       re-evaluated by the split-precision engine, which overwrites its row.  Selections are
-                                      those of the split engine as long as |fp16 output - split output| <= guard_eps holds
-                                      (adanerf_stats.rays_refined counts the re-evaluated rays).  Applies where the selection
-                                      is fused into the sampling kernel (adaptive sampler, N <= 16, threshold > 0, 8 x 256
-                                      net); everywhere else this mode runs the split-precision engine alone. */
+                                      those of the split engine as long as |fp16 output - split output| <= guard_eps and the
+                                      error of a (kept - candidate) difference <= guard_eps_pair hold.  Both assumptions are
+                                      MEASURED on every re-evaluated ray (whole row: adanerf_stats.guard_max_seen /
+                                      .guard_pair_seen / .guard_violations) and the OUTCOME is audited: every frame a rotating
+                                      1 / guard_audit_period of ALL rays -- the ones the band declared decided included -- goes
+                                      through the split engine as well and its selection is compared with the one in place
+                                      (adanerf_stats.guard_audited / .guard_audit_mismatch); a violated bound or a mismatch widens
+                                      the band for the frames that follow.  adanerf_stats.rays_refined counts the re-evaluated
+                                      rays.  Applies where the selection is fused into the sampling kernel (adaptive sampler,
+                                      N <= 16, threshold > 0, 8 x 256 net); everywhere else this mode runs the split-precision
+                                      engine alone. */
 };
 /* Sampling nets of another topology / encoding layout (run-time-shaped kernels): ADANERF_SAMPLING_FP32 runs the exact fp32
  * kernel, every other mode the split-precision one (same arithmetic as ADANERF_SAMPLING_SPLIT_FP16; no plain-fp16 pass);
@@ -104,8 +117,10 @@ enum {
   ADANERF_FLAG_KEEP_ORACLE = 1, /* adanerf_render writes the raw oracle values [batch,128] to ADANERF_BUF_ORACLE and selects from
                                    there in a separate launch (debug / the reference's data flow); by default the selection runs
                                    in the sampling kernel's epilogue and that buffer is not written */
-  ADANERF_FLAG_WAVE_SELECT = 2  /* selection by the wave-per-ray kernel (the only one for numRaymarchSamples > 16) even where the
+  ADANERF_FLAG_WAVE_SELECT = 2, /* selection by the wave-per-ray kernel (the only one for numRaymarchSamples > 16) even where the
                                    lane-pair selection applies; implies the separate launch */
+  ADANERF_FLAG_NO_GUARD_CACHE = 4 /* ADANERF_SAMPLING_GUARDED: neither read nor write the calibration record next to the model
+                                   (adanerf_guard_calibration_file); the band is measured at the first guarded frame */
 };
 
 typedef struct adanerf_ctx adanerf_ctx;
@@ -123,9 +138,14 @@ typedef struct adanerf_options {
   int32_t strip_rows;       /* rows per strip for round-robin strip sharding; <=0 -> 8 */
   int32_t sampling_mode;    /* ADANERF_SAMPLING_* */
   int32_t flags;            /* ADANERF_FLAG_* (0 = defaults) */
-  float   guard_eps;        /* ADANERF_SAMPLING_GUARDED: the band, in units of the raw network outputs; <= 0 -> calibrated
-                               for the loaded model at the first frame (adanerf_calibrate_guard) */
-  int32_t reserved[3];
+  float   guard_eps;        /* ADANERF_SAMPLING_GUARDED: the band, in units of the raw network outputs; <= 0 -> the model's
+                               calibration record if there is a current one, else calibrated for the loaded model at the first
+                               guarded frame (adanerf_calibrate_guard, ADANERF_GUARD_CALIB_POSES poses) and recorded */
+  float   guard_eps_pair;   /* ... the bound on the error of a (kept - candidate) difference; <= 0 -> calibrated like guard_eps when
+                               that is, else 2 x guard_eps (what the bound on single values implies) */
+  int32_t guard_audit_period; /* ... audit 1 / period of all rays per frame: 0 -> ADANERF_GUARD_AUDIT_PERIOD, < 0 -> no audit,
+                               else a power of two <= 32 */
+  int32_t reserved[1];
 } adanerf_options;
 
 /* Band of the guarded selection when calibration is impossible (non-finite outputs): about 2x the largest difference between
@@ -135,6 +155,17 @@ typedef struct adanerf_options {
  * ADANERF_GUARD_EPS_MIN. */
 #define ADANERF_GUARD_CALIB_MARGIN 2.0f
 #define ADANERF_GUARD_EPS_MIN 1.0e-3f
+#define ADANERF_GUARD_CALIB_POSES 64     /* poses of the automatic calibration (x 4096 rays each) */
+#define ADANERF_GUARD_AUDIT_PERIOD 16    /* default audit rate: every ray is audited once in 16 frames */
+
+/* adanerf_info.guard_calib_source */
+enum {
+  ADANERF_GUARD_FROM_NONE = 0,        /* not calibrated yet */
+  ADANERF_GUARD_FROM_OPTIONS = 1,     /* adanerf_options.guard_eps */
+  ADANERF_GUARD_FROM_RECORD = 2,      /* the calibration record next to the model (adanerf_guard_calibration_file) */
+  ADANERF_GUARD_FROM_CALIBRATION = 3, /* measured by this context (and recorded, if the directory is writable) */
+  ADANERF_GUARD_FROM_MONITOR = 4      /* widened after a frame that violated a bound or failed the audit */
+};
 
 typedef struct adanerf_info {
   int32_t abi_version;
@@ -159,6 +190,11 @@ typedef struct adanerf_info {
   float   view_cell_size[3];/* dataset_info.txt view_cell_size (the viewer's camera speed: max(size / 2), camera.cpp:47) */
   int32_t num_samples_coarse; /* ADANERF_SAMPLER_COARSE_FINE: Nc (num_samples is then Nc + Nf); else 0 */
   float   guard_eps;          /* ADANERF_SAMPLING_GUARDED: the band in use (0 until it has been calibrated) */
+  float   guard_eps_pair;     /* ... the bound on (kept - candidate) differences in use */
+  int32_t guard_audit_period; /* ... 0: no audit */
+  int32_t guard_calib_source; /* ... ADANERF_GUARD_FROM_* */
+  int32_t guard_calib_poses;  /* ... poses behind a calibrated band (record or own calibration), else 0 */
+  int32_t reserved[8];
 } adanerf_info;
 
 /* per-frame statistics: the fields the reference logs every 100 frames
@@ -178,15 +214,20 @@ typedef struct adanerf_stats {
                                  fp16 range of the split-precision engine -> use ADANERF_SAMPLING_FP32 */
   int32_t rays_refined;       /* ADANERF_SAMPLING_GUARDED: rays re-evaluated by the split-precision engine, summed like
                                  total_samples */
-  float   guard_max_seen;     /* ... largest |fp16 - split| seen since create on the re-evaluated rays' top value (the
-                                 assumption behind the band, sampled on every frame) */
-  int32_t guard_violations;   /* ... re-evaluated rays (since create) where that difference exceeded the band: if this is
+  float   guard_max_seen;     /* ... largest |fp16 - split| raw output seen since create, over ALL 128 outputs of every
+                                 re-evaluated ray (undecided or audited): the assumption behind guard_eps, measured every frame */
+  int32_t guard_violations;   /* ... re-evaluated rays (since create) where a measured error exceeded its bound: if this is
                                  not 0 the band was too narrow for this model; the library widens it for the frames that
                                  follow (guard_widened), frames before that may hold rays selected by the fp16 engine */
-  int32_t guard_widened;      /* ... times (since create) the library widened the band after a frame reported violations: every
-                                 later frame runs with ADANERF_GUARD_CALIB_MARGIN x the largest difference seen
-                                 (adanerf_info.guard_eps is the band in force) */
-  int32_t reserved[1];
+  int32_t guard_widened;      /* ... times (since create) the library widened the band after a frame reported violations or an audit
+                                 mismatch: every later frame runs with ADANERF_GUARD_CALIB_MARGIN x the largest errors seen
+                                 (adanerf_info.guard_eps / .guard_eps_pair are the bounds in force) */
+  float   guard_pair_seen;    /* ... largest error of a (kept - candidate) difference seen since create (the assumption behind
+                                 guard_eps_pair; 0 where the sampler transforms its values) */
+  int32_t guard_audited;      /* ... rays (since create) that pass 1 had DECIDED and the audit re-evaluated anyway */
+  int32_t guard_audit_mismatch; /* ... of those, rays whose exact selection differs from the one pass 1 left in place: must be 0
+                                 while no bound is violated; not 0 -> the band is widened (guard_widened) */
+  int32_t reserved[5];
 } adanerf_stats;
 
 /* ---- lifecycle ---------------------------------------------------------------------------- */
@@ -198,6 +239,10 @@ int adanerf_destroy(adanerf_ctx* ctx);
 int adanerf_get_info(const adanerf_ctx* ctx, adanerf_info* info);
 /* message of the last failing call on ctx; ctx == NULL reads the thread's last create() failure */
 const char* adanerf_last_error(const adanerf_ctx* ctx);
+/* ADANERF_ABI_VERSION the library was built with, and sizeof(adanerf_options / adanerf_info / adanerf_stats) as it sees them:
+ * the handshake a binding does once after dlopen (structs are written whole, see ADANERF_ABI_VERSION). */
+int adanerf_abi_version(void);
+int adanerf_struct_sizes(int32_t sizes_out[3]);
 
 /* ---- per frame ---------------------------------------------------------------------------- */
 
@@ -277,21 +322,38 @@ int adanerf_compact(adanerf_ctx* ctx, const float* d_oracle, int32_t n_rays, int
                     float* d_sample_w, int32_t* d_total);
 
 /* The guarded two-precision selection (ADANERF_SAMPLING_GUARDED) on caller-provided values, for tests: selects from
- * d_oracle_approx [n_rays,128] with the guard band eps, then re-selects the undecided rays from d_oracle_exact [n_rays,128],
- * then compacts.  If |approx - exact| <= eps everywhere the outputs equal adanerf_compact(d_oracle_exact, ...) except that
- * d_sample_w holds the approximate values on the rays that were not re-selected.  d_refined [1] int32: how many were.
+ * d_oracle_approx [n_rays,128] with the guard band (eps, eps_pair <= 0 -> 2 eps), lists the undecided rays plus the rays audited at
+ * (audit_period, audit_phase) (audit_period <= 0: none), re-selects the undecided ones from d_oracle_exact [n_rays,128], compares
+ * the audited decided ones, then compacts.  If the two bounds hold on every row the outputs equal adanerf_compact(d_oracle_exact, ...)
+ * except that d_sample_w holds the approximate values on the rays that were not re-selected.  d_refined [1] int32: how many rays
+ * were looked at again.  d_monitor (may be NULL) [5] uint32, ADDED to / maximised into (the caller zeroes it): [0] float bits of
+ * the largest |approx - exact| over the re-evaluated rows, [1] rows that exceeded a bound, [2] float bits of the largest
+ * (kept - candidate) difference error, [3] audited rows whose approximate selection differs from the exact one, [4] audited rows.
  * n_max <= 16, thr > 0. */
 int adanerf_compact_guarded(adanerf_ctx* ctx, const float* d_oracle_approx, const float* d_oracle_exact, int32_t n_rays,
-                            int32_t n_max, float thr, float eps, int32_t* d_ray_offsets, int32_t* d_ray_counts,
-                            uint32_t* d_sample_key, float* d_sample_w, int32_t* d_total, int32_t* d_refined);
+                            int32_t n_max, float thr, float eps, float eps_pair, int32_t audit_period, int32_t audit_phase,
+                            int32_t* d_ray_offsets, int32_t* d_ray_counts, uint32_t* d_sample_key, float* d_sample_w,
+                            int32_t* d_total, int32_t* d_refined, uint32_t* d_monitor);
 
 /* Calibrates the band of ADANERF_SAMPLING_GUARDED for the loaded model: n_poses cameras drawn inside the view cell
  * (positions uniform in 90 % of it, any orientation; seeded), 64 x 64 rays covering the field of view each, through both the
- * plain-fp16 and the split-precision sampling network; *max_diff = the largest |difference| over all raw outputs.
- * set != 0 also installs max(ADANERF_GUARD_CALIB_MARGIN * max_diff, ADANERF_GUARD_EPS_MIN) as the context's band (what a
- * context created with guard_eps <= 0 does by itself before its first guarded frame, with 8 poses and seed 1).
+ * plain-fp16 and the split-precision sampling network; *max_diff = the largest |difference| over all raw outputs, *max_pair_diff
+ * (may be NULL) = the largest error of a (kept - candidate) difference under the context's N and threshold with the single-value
+ * bound that max_diff gives (0 where the sampler transforms its values).
+ * set != 0 also installs max(ADANERF_GUARD_CALIB_MARGIN * max_diff, ADANERF_GUARD_EPS_MIN) and ADANERF_GUARD_CALIB_MARGIN *
+ * max_pair_diff as the context's bounds -- what a context created with guard_eps <= 0 does by itself before its first guarded
+ * frame (ADANERF_GUARD_CALIB_POSES poses, seed 1) unless the model directory holds a current calibration record of at least that
+ * many poses -- and writes the record (see adanerf_guard_calibration_file; a record measured over more poses is left alone).
  * Synchronous.  8 x 256 sampling networks only. */
-int adanerf_calibrate_guard(adanerf_ctx* ctx, int32_t n_poses, uint32_t seed, int32_t set, float* max_diff);
+int adanerf_calibrate_guard(adanerf_ctx* ctx, int32_t n_poses, uint32_t seed, int32_t set, float* max_diff, float* max_pair_diff);
+
+/* Path of the calibration record of this context's (model, N, threshold): <model_dir>/guard_band.n<N>.t<threshold bits>.cal, or
+ * under $ADANERF_GUARD_CACHE_DIR/<model hash>/ when that variable is set (read-only model directories).  A text file (key = value):
+ * hash of model0.onnx, the encoding, the sampler transform, the revision of the fp16 engine, poses, seed, the measured maxima.  Read
+ * at the first guarded frame of a context created with guard_eps <= 0; a record of another model / engine revision is ignored
+ * and overwritten.  Delete it to force a new measurement.  buf may be NULL to query the length (return value: bytes needed
+ * including the terminator, or a negative ADANERF_E* code). */
+int adanerf_guard_calibration_file(const adanerf_ctx* ctx, char* buf, size_t buf_bytes);
 
 /* Explicit shading-net input features [n_samples, n_in1] fp32 = [PE(x^) | PE(dir)] (parity/debug;
  * the render path never materialises them). */

@@ -626,14 +626,16 @@ def select_adaptive(orc: np.ndarray, n_max: int, thr: float):
     return count, bins, wts.astype(F32)
 
 
-def guard_undecided(y: np.ndarray, n_max: int, thr: float, eps: float, transform: str = "none") -> np.ndarray:
+def guard_undecided(y: np.ndarray, n_max: int, thr: float, eps: float, transform: str = "none", eps_pair: float = 0.0) -> np.ndarray:
     """Guard band of the two-precision selection (no reference counterpart: the build's own ADANERF_SAMPLING_GUARDED,
     adanerf_amd/csrc/k_select_pair.hip.hpp pair_select; restated here so the CPU suite can check the rule itself).
     ``y`` [R,128]: the sampler's transformed values computed by the cheaper engine, whose RAW outputs are within ``eps``
-    of the exact engine's.  Returns a bool [R]: False only where select_adaptive(x) == select_adaptive(y) for EVERY x
-    with |x - y| <= e (e = eps carried through the transform).  Rule: undecided iff one of the n_max largest values lies
-    within e of thr, or more values reach u = max(v_n - 2e, thr - e) (arg-max fallback: v_1 - 2e) than reach the cut
-    value, or there is a tie at the cut / a non-finite value."""
+    of the exact engine's, and -- untransformed outputs only, ``eps_pair`` > 0 -- whose error on a DIFFERENCE between a kept
+    value and a not-kept candidate is at most ``eps_pair`` (<= 2 eps; 0 selects 2 eps, which the first bound implies).
+    Returns a bool [R]: False only where select_adaptive(x) == select_adaptive(y) for EVERY x that satisfies both bounds.
+    Rule (e, ep = the bounds carried through the transform): undecided iff one of the n_max largest values lies within e of thr, or
+    more values reach u = max(v_n - ep, thr - e) (arg-max fallback: v_1 - ep) than reach the cut value, or there is a tie at the
+    cut / a non-finite value."""
     y = y.astype(F32)
     srt = -np.sort(-y, axis=1)
     c0 = srt[:, 0]
@@ -641,6 +643,9 @@ def guard_undecided(y: np.ndarray, n_max: int, thr: float, eps: float, transform
         e = (F32(1.01) * F32(np.expm1(2.0 * eps)) * c0).astype(F32)
     else:
         e = np.full(len(y), F32(0.25 * eps if transform == "sigmoid" else eps), dtype=F32)
+    ep = F32(2) * e
+    if transform == "none" and 0.0 < eps_pair <= 2.0 * eps:
+        ep = np.full(len(y), F32(eps_pair), dtype=F32)
     top = srt[:, :n_max]
     tn = top[:, n_max - 1]
     none = c0 < F32(thr)
@@ -649,10 +654,39 @@ def guard_undecided(y: np.ndarray, n_max: int, thr: float, eps: float, transform
     total = (y >= t[:, None]).sum(axis=1)
     und = total > n_eff
     und |= (np.abs(top - F32(thr)) <= e[:, None]).any(axis=1)
-    u = np.where(none, c0 - F32(2) * e, np.maximum(tn - F32(2) * e, F32(thr) - e))
+    u = np.where(none, c0 - ep, np.maximum(tn - ep, F32(thr) - e))
     und |= (y >= u[:, None]).sum(axis=1) != total
     und |= ~np.isfinite(y).all(axis=1)
     return und
+
+
+def guard_pair_error(y: np.ndarray, x: np.ndarray, n_max: int, thr: float, eps: float) -> np.ndarray:
+    """The quantity ``eps_pair`` bounds, per row (pair_monitor / guard_stats_kernel measure it on the device): the largest
+    (y_i - x_i) - (y_j - x_j) over bins i kept by the selection from y and candidates j that are not -- values from
+    max(v_n - 2 eps, thr - eps) (arg-max fallback: v_1 - 2 eps) up to the cut value; 0 where a row has no such pair.  The sign
+    that lets j overtake i: x_j >= x_i needs this to reach y_i - y_j."""
+    y = y.astype(F32)
+    d = (y - x.astype(F32)).astype(F32)
+    srt = -np.sort(-y, axis=1)
+    c0, tn = srt[:, 0], srt[:, n_max - 1]
+    none = c0 < F32(thr)
+    t = np.where(none, c0, np.maximum(tn, F32(thr)))
+    cut = np.where(none, c0 - F32(2 * eps), np.maximum(tn - F32(2 * eps), F32(thr) - F32(eps)))
+    kept = y >= t[:, None]
+    cand = (y >= cut[:, None]) & ~kept
+    dk = np.where(kept, d, -np.inf).max(axis=1)
+    dn = np.where(cand, d, np.inf).min(axis=1)
+    pr = dk - dn
+    return np.where(np.isfinite(pr) & (pr > 0), pr, 0).astype(F32)
+
+
+def guard_audit_bits(period: int, phase: int, seg: int) -> int:
+    """Which of the 32 rays of segment ``seg`` the guarded selection audits at ``phase`` (k_select_pair.hip.hpp audit_bits): bit j set
+    iff ((j - phase - seg) & (period - 1)) == 0; period a power of two <= 32, 0 = no audit."""
+    if period <= 0:
+        return 0
+    pattern = 1 if period >= 32 else 0xFFFFFFFF // ((1 << period) - 1)
+    return (pattern << ((phase + seg) & (period - 1))) & 0xFFFFFFFF
 
 
 def compact(count: np.ndarray, bins: np.ndarray, wts: np.ndarray):

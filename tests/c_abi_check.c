@@ -27,6 +27,14 @@ int main(int argc, char** argv) {
     if (rc != ADANERF_OK || info.rays_local != 64 * 48 || info.abi_version != ADANERF_ABI_VERSION) return 3;
   }
   if (adanerf_destroy(NULL) != ADANERF_OK) return 4;
+  {
+    /* the handshake a binding does after loading the library: version and struct sizes as the LIBRARY sees them */
+    int32_t sizes[3] = {0, 0, 0};
+    if (adanerf_abi_version() != ADANERF_ABI_VERSION) return 5;
+    if (adanerf_struct_sizes(sizes) != ADANERF_OK || adanerf_struct_sizes(NULL) != ADANERF_EINVAL) return 6;
+    if (sizes[0] != (int32_t)sizeof(adanerf_options) || sizes[1] != (int32_t)sizeof(adanerf_info) || sizes[2] != (int32_t)sizeof(adanerf_stats))
+      return 7;
+  }
   printf("sizeof options=%u info=%u stats=%u\n", (unsigned)sizeof(adanerf_options), (unsigned)sizeof(adanerf_info),
          (unsigned)sizeof(adanerf_stats));
   return 0;

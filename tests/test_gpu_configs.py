@@ -75,6 +75,8 @@ def check_rows_against_oracle(sc, wts, w, h, pose, rot, rows, cnt, rgb, min_same
 # ---------------------------------------------------------------------------------------------
 
 def test_config4_thr01_eight_way_shard(classroom, tmp_path_factory):
+    """Runs in the host's default sampling mode -- the guarded two-precision selection bench.py measures -- and checks the full-size
+    rows against the oracle in it; the split engine's frame must select the same samples on every ray."""
     z, meta, sc, wts = classroom
     sc4 = dataclasses.replace(sc, threshold=0.1)
     d = _dir(tmp_path_factory, sc4, wts, "config4")
@@ -88,6 +90,11 @@ def test_config4_thr01_eight_way_shard(classroom, tmp_path_factory):
         rgb, full, st = r.render_numpy()
         cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,))
     assert cnt.min() >= 1 and cnt.max() <= 8 and st.total_samples == int(cnt.sum())
+    assert r._opt.sampling_mode == R.SAMPLING_MODES["guarded"] and st.rays_refined > 0 and st.guard_violations == 0 and st.guard_audit_mismatch == 0
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="split") as rs:
+        rs.set_camera(z["pose"], z["rot"])
+        rs.render(None, None, stats=True)
+        assert np.array_equal(rs.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,)), cnt)
     img, samples = render_sharded(d, w, h, z["pose"], z["rot"], world, strip, precision="bf16")
     assert np.array_equal(img, full)                       # assembled bytes == unsharded frame
     assert sum(samples) == st.total_samples
@@ -165,6 +172,8 @@ def test_config5_thresholds_01_03(ndc, thr):
         cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,))
         off = r.buffer(R.BUF_RAY_OFFSETS, np.int32, (w * h,))
         assert r.last_stats.sampling_overflow == 0
+        # the host's default mode: the guarded selection, band silent, audit clean
+        assert r._opt.sampling_mode == R.SAMPLING_MODES["guarded"] and st.rays_refined > 0 and st.guard_violations == 0 and st.guard_audit_mismatch == 0
     assert cnt.min() >= 1 and cnt.max() <= 8 and st.total_samples == int(cnt.sum())
     assert np.array_equal(off[1:].astype(np.int64), np.cumsum(cnt.astype(np.int64))[:-1])
     assert np.isfinite(rgb).all() and np.array_equal(rgba[:, :3], O.to_rgba8(rgb)[:, :3])
@@ -299,7 +308,7 @@ def test_aux_outputs_match_oracle(name, tmp_path_factory):
     if "bins" in ref:                                       # adaptive: compare rays whose selection agrees (SURVEY "Hard parts")
         cnt_ok = np.isclose(np.abs(rgb - ref["rgb"]).max(axis=1), 0, atol=3e-4)
         same = cnt_ok
-        assert same.mean() >= 0.99
+        check_identical(same, "aux_outputs_" + name, residual_budget(w * h))      # oracle evaluated on this box: at most max(1, 1e-4 n) rays
     if sc.sampler == "FromClassifiedDepth":
         # where a bin's probability mass is ~0 the inverse CDF is ill-conditioned and an occasional sample lands at the other
         # edge of an empty bin (see test_pdf_sampler_matches_reference): robust bounds, < 0.5 % of rays may deviate
@@ -412,7 +421,7 @@ def test_coarse_fine_stages_match_the_reference(name, tmp_path_factory):
     ok = (rel < 1e-5).all(axis=1)
     record("coarse_fine_stages", rays_with_all_depths_equal=float(ok.mean()), median_rel_depth_err=float(np.median(rel)),
            rgb_max_err=float(np.abs(got["rgb"][ok] - z["rgb"][ok]).max()))
-    assert ok.mean() > 0.9
+    assert ok.mean() > 0.97                       # measured 0.9766 (classroom) / 1.0 (NDC): rays with a fine sample in an empty bin (above)
     np.testing.assert_allclose(got["raw"][ok].reshape(-1, 4), z["shade_out"].reshape(-1, nc + nf, 4)[ok].reshape(-1, 4), rtol=1e-3, atol=2e-3)
     np.testing.assert_allclose(got["rgb"][ok], z["rgb"][ok], rtol=0, atol=3e-4)
 
@@ -590,7 +599,10 @@ def test_guarded_selection_at_full_size(classroom, ndc, workload, tmp_path_facto
             st_g, cnt_g, key_g = _selection_of(rg, w * h)
             rg.lib.adanerf_get_info(rg.handle, rg.info)
             record("guarded_full_size", workload=workload, pose=i, rays=w * h, refined=int(st_g.rays_refined), eps=float(rg.info.guard_eps),
-                   monitor_max_seen=float(st_g.guard_max_seen), violations=int(st_g.guard_violations), samples=int(st_g.total_samples))
+                   eps_pair=float(rg.info.guard_eps_pair), monitor_max_seen=float(st_g.guard_max_seen), monitor_pair_seen=float(st_g.guard_pair_seen),
+                   violations=int(st_g.guard_violations), audited=int(st_g.guard_audited), audit_mismatch=int(st_g.guard_audit_mismatch),
+                   samples=int(st_g.total_samples), band_source=R.GUARD_FROM[int(rg.info.guard_calib_source)])
             assert st_g.total_samples == st_s.total_samples and np.array_equal(cnt_g, cnt_s) and np.array_equal(key_g, key_s)
-            assert st_g.guard_violations == 0 and st_g.guard_max_seen <= rg.info.guard_eps
+            assert st_g.guard_violations == 0 and st_g.guard_max_seen <= rg.info.guard_eps and st_g.guard_pair_seen <= rg.info.guard_eps_pair
+            assert st_g.guard_audit_mismatch == 0 and st_g.guard_audited >= (i + 1) * 0.02 * w * h      # ~1/16 of the decided rays per frame, cumulative
             assert 0 < st_g.rays_refined < w * h

@@ -13,6 +13,8 @@ from adanerf_amd import renderer as R
 
 pytestmark = pytest.mark.gpu
 
+R_GUARD_FROM_NONE, R_GUARD_FROM_OPTIONS, R_GUARD_FROM_RECORD, R_GUARD_FROM_CALIBRATION, R_GUARD_FROM_MONITOR = range(5)
+
 
 @pytest.fixture(scope="module", autouse=True)
 def _built():
@@ -379,7 +381,9 @@ def test_composite_matches_reference(cases, name):
     np.testing.assert_allclose(out, z["rgb"], rtol=0, atol=2e-6)       # expf vs torch.sigmoid
     exp8 = O.to_rgba8(z["rgb"])
     assert (np.abs(out8.astype(np.int16) - exp8.astype(np.int16)) <= 1).all() and (out8[:, 3] == 255).all()
-    assert (out8 == exp8).mean() > 0.995
+    byte_eq = float((out8 == exp8).mean())       # truncation to 8 bits: a value within 2e-6 of a k / 255 boundary may land on the other side
+    record("composite_rgba8", case=name, bytes_equal=byte_eq)
+    assert byte_eq > 0.999
 
 
 def test_composite_accepts_any_sample_layout(cases):
@@ -525,15 +529,24 @@ def test_fused_selection_equals_separate_launches(cases, name, w, h, bs, samplin
 # A3 + A4, guarded two-precision selection (ADANERF_SAMPLING_GUARDED)
 # ---------------------------------------------------------------------------------------------
 
-def _gpu_compact_guarded(r, approx, exact, n_max, thr, eps):
+def _gpu_compact_guarded(r, approx, exact, n_max, thr, eps, eps_pair=0.0, audit_period=0, audit_phase=0, monitor=False):
     n = approx.shape[0]
     d_a, d_e = r.to_device(approx), r.to_device(exact)
     off, cnt = r.empty((n,), np.int32), r.empty((n,), np.int32)
     key, w = r.empty((n * n_max,), np.uint32), r.empty((n * n_max,), np.float32)
     tot, ref = r.empty((1,), np.int32), r.empty((1,), np.int32)
-    r.compact_guarded(d_a, d_e, n, n_max, thr, eps, off, cnt, key, w, tot, ref)
+    mon = r.to_device(np.zeros(5, np.uint32)) if monitor else None
+    r.compact_guarded(d_a, d_e, n, n_max, thr, eps, off, cnt, key, w, tot, ref, eps_pair=eps_pair, audit_period=audit_period,
+                      audit_phase=audit_phase, monitor=mon)
     t = int(tot.numpy()[0])
-    return off.numpy(), cnt.numpy(), key.numpy()[:t], w.numpy()[:t], t, int(ref.numpy()[0])
+    out = (off.numpy(), cnt.numpy(), key.numpy()[:t], w.numpy()[:t], t, int(ref.numpy()[0]))
+    if monitor:
+        m = mon.numpy()
+        out += (dict(max_diff=float(m[:1].view(np.float32)[0]), violations=int(m[1]), max_pair=float(m[2:3].view(np.float32)[0]),
+                     audit_mismatch=int(m[3]), audited=int(m[4])),)
+    for a in (d_a, d_e, off, cnt, key, w, tot, ref):
+        a.free()
+    return out
 
 
 @pytest.mark.parametrize("n_max,thr", [(8, 0.2), (4, 0.15), (16, 0.15), (1, 0.3), (7, 0.05)])
@@ -581,6 +594,95 @@ def test_compact_guarded_reproduces_the_exact_selection(cases, n_max, thr):
     record("compact_guarded", n_max=n_max, thr=thr, eps=eps, rays=R, refined=refined)
 
 
+def _peaky_rows(rng, R, thr):
+    x = (rng.standard_normal((R, 128)) * 0.05).astype(np.float32)
+    for i in range(R):
+        k = rng.integers(0, 20)
+        x[i, rng.integers(0, 128, k)] = rng.uniform(0, 1.2, k)
+        if i % 4 == 0:
+            x[i, rng.integers(0, 128, 3)] = thr + rng.uniform(-0.03, 0.03, 3)
+    return x
+
+
+@pytest.mark.parametrize("n_max,thr", [(8, 0.2), (4, 0.15), (16, 0.15)])
+def test_guard_monitor_and_pair_bound_on_constructed_rows(cases, n_max, thr):
+    """Stage-level check of the two measured assumptions and of the narrower rule they allow: `approx` = `exact` + a common
+    offset per row (fully correlated errors) + a small independent part, so single values are off by up to eps while differences
+    are off by at most eps_pair < 2 eps.  The monitor must report exactly the row maxima the oracle's restatement gives for the
+    re-evaluated rows (whole rows, raw units), no violation, fewer re-evaluated rays than under 2 eps -- and the selection of
+    `exact` bit for bit."""
+    rng = np.random.default_rng(n_max + 31)
+    R, eps, ep = 12007, 0.01, 0.006
+    exact = _peaky_rows(rng, R, thr)
+    common = rng.uniform(-(eps - ep / 2), eps - ep / 2, (R, 1)).astype(np.float32)
+    approx = (exact + np.float32(0.999) * (common + rng.uniform(-ep / 2, ep / 2, exact.shape))).astype(np.float32)
+    z, meta, sc, wts, dpath = cases["classroom_n8_thr02"]
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(dpath, 16, 16), precision="bf16") as r:
+        off, cnt, key, w, tot, refined, mon = _gpu_compact_guarded(r, approx, exact, n_max, thr, eps, eps_pair=ep, monitor=True)
+        *_, refined2, mon2 = _gpu_compact_guarded(r, approx, exact, n_max, thr, eps, monitor=True)
+    und = O.guard_undecided(approx, n_max, thr, eps, eps_pair=ep)
+    und2 = O.guard_undecided(approx, n_max, thr, eps)
+    assert refined == int(und.sum()) and refined2 == int(und2.sum()) and refined < refined2
+    e_cnt, e_bins, e_w = O.select_adaptive(exact, n_max, thr)
+    e_off, e_ray, e_bin, _ = O.compact(e_cnt, e_bins, e_w)
+    assert np.array_equal(cnt, e_cnt) and np.array_equal(key, (e_ray.astype(np.uint32) << 7) | e_bin.astype(np.uint32))
+    d = np.abs(approx - exact).max(axis=1)
+    pe = O.guard_pair_error(approx, exact, n_max, thr, eps)
+    assert mon["violations"] == 0 and mon["audited"] == 0 and mon["audit_mismatch"] == 0
+    assert mon["max_diff"] == float(d[und].max()) and mon2["max_diff"] == float(d[und2].max())
+    assert abs(mon["max_pair"] - float(pe[und].max())) < 1e-7 and mon["max_pair"] <= ep
+    assert abs(mon2["max_pair"] - float(pe[und2].max())) < 1e-7      # measured whether or not a narrower pair bound is in use
+    record("guard_monitor_rows", n_max=n_max, thr=thr, refined_pair_bound=refined, refined_two_eps=refined2, **mon)
+
+
+def test_guard_audit_finds_errors_that_only_decided_rays_carry(cases):
+    """The audit: rows whose `approx` is off by MORE than the band, but only on rays the band declares decided (an undecided ray
+    is re-evaluated and would show the error at once).  Every selection that comes out wrong is then on a decided ray.  With the
+    audit off nothing notices; with period 16 each phase looks at 1/16 of the decided rays, reports the bound violations and the
+    selection mismatches among them, and over the 16 phases of one rotation every wrong ray is counted exactly once.  Audited rows are
+    compared, never rewritten: the outputs are the same at every phase."""
+    rng = np.random.default_rng(5)
+    n_max, thr, eps, R = 8, 0.2, 0.004, 16384 + 19
+    exact = _peaky_rows(rng, R, thr)
+    big = np.zeros_like(exact)
+    rows = rng.choice(R, 3000, replace=False)
+    big[rows] = rng.uniform(-0.03, 0.03, (3000, 128))                # far beyond eps
+    approx = (exact + big).astype(np.float32)
+    und = O.guard_undecided(approx, n_max, thr, eps)
+    approx[und] = exact[und]                                         # the undecided rays carry no error at all ...
+    und = O.guard_undecided(approx, n_max, thr, eps)
+    bad_rows = (np.abs(approx - exact).max(axis=1) > eps) & ~und     # ... so every violated bound sits on a decided ray
+    c_a, b_a, _ = O.select_adaptive(approx, n_max, thr)
+    c_e, b_e, _ = O.select_adaptive(exact, n_max, thr)
+    wrong = ((c_a != c_e) | (b_a != b_e).any(axis=1)) & ~und
+    assert bad_rows.sum() > 500 and wrong.sum() > 100 and not (wrong & ~bad_rows).any()
+    z, meta, sc, wts, dpath = cases["classroom_n8_thr02"]
+    seg = np.arange(R) // 32
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(dpath, 16, 16), precision="bf16") as r:
+        base = _gpu_compact_guarded(r, approx, exact, n_max, thr, eps, monitor=True)
+        assert base[5] == int(und.sum()) and base[6]["violations"] == 0 and base[6]["audited"] == 0      # audit off: blind
+        found_viol = found_mism = audited = 0
+        first_detection = None
+        for phase in range(16):
+            out = _gpu_compact_guarded(r, approx, exact, n_max, thr, eps, audit_period=16, audit_phase=phase, monitor=True)
+            mon = out[6]
+            aud = ((np.arange(R) % 32 - phase - seg) & 15) == 0
+            assert out[5] == int((und | aud).sum())
+            assert mon["audited"] == int((aud & ~und).sum())
+            assert mon["violations"] == int((aud & bad_rows).sum()) and mon["audit_mismatch"] == int((aud & wrong).sum())
+            for a, b in zip(out[:5], base[:5]):                      # compare-only: nothing the frame is made of moves
+                assert np.array_equal(a, b)
+            found_viol += mon["violations"]
+            found_mism += mon["audit_mismatch"]
+            audited += mon["audited"]
+            if first_detection is None and mon["audit_mismatch"]:
+                first_detection = phase
+    assert found_viol == int(bad_rows.sum()) and found_mism == int(wrong.sum()) and audited == int((~und).sum())
+    assert first_detection is not None and first_detection < 16
+    record("guard_audit_rows", rays=R, decided=int((~und).sum()), rows_beyond_band=int(bad_rows.sum()), wrong_selections=int(wrong.sum()),
+           first_phase_with_a_mismatch=first_detection)
+
+
 @pytest.mark.parametrize("name,w,h,bs", [("classroom_n8_thr02", 200, 160, -1), ("classroom_n8_thr02", 97, 61, 1000),
                                          ("classroom_n16_thr015", 160, 120, -1), ("barbershop_n4_thr015", 131, 77, 4096),
                                          ("ndc_synthetic_n8", 192, 108, -1), ("synthetic_fixed8", 64, 64, 37)])
@@ -605,12 +707,14 @@ def test_guarded_sampling_reproduces_the_split_engine(cases, name, w, h, bs):
             assert st.sampling_overflow == 0
             r.lib.adanerf_get_info(r.handle, r.info)
             return dict(rgb=rgb, rgba=rgba, total=int(st.total_samples), cnt=cnt, off=off, tot=tot, key=key, sw=sw, refined=int(st.rays_refined),
-                        eps=float(r.info.guard_eps), seen=float(st.guard_max_seen), viol=int(st.guard_violations))
+                        eps=float(r.info.guard_eps), seen=float(st.guard_max_seen), viol=int(st.guard_violations),
+                        eps_pair=float(r.info.guard_eps_pair), pair_seen=float(st.guard_pair_seen), audited=int(st.guard_audited),
+                        mismatch=int(st.guard_audit_mismatch), source=int(r.info.guard_calib_source))
 
     split = run(sampling="split")
-    guard = run(sampling="guarded")                 # band calibrated for the model at the first frame
+    guard = run()                                   # the host's default mode; band from the model's calibration record / measured at the first frame
     wide = run(sampling="guarded", guard_eps=1.0)
-    meta_keys = ("refined", "eps", "seen", "viol")
+    meta_keys = ("refined", "eps", "seen", "viol", "eps_pair", "pair_seen", "audited", "mismatch", "source")
     for k in ("total", "cnt", "off", "tot", "key"):
         assert np.array_equal(split[k], guard[k]), k
     for k in split:
@@ -622,29 +726,37 @@ def test_guarded_sampling_reproduces_the_split_engine(cases, name, w, h, bs):
     # re-evaluated rays and what the kept values of the other rays show must lie inside it
     assert 1e-3 <= guard["eps"] <= 2e-2, guard["eps"]
     assert guard["viol"] == 0 and 0.0 < guard["seen"] <= guard["eps"]
+    assert guard["source"] in (R_GUARD_FROM_RECORD, R_GUARD_FROM_CALIBRATION) and guard["eps"] < guard["eps_pair"] <= 2 * guard["eps"]
+    assert guard["pair_seen"] <= guard["eps_pair"]
+    # the audit: the last batch looked at ~1/16 of its decided rays again and found every selection in place exact
+    assert guard["audited"] > 0 and guard["mismatch"] == 0 and wide["audited"] == 0
     sw_diff = float(np.abs(guard["sw"] - split["sw"]).max())
     assert sw_diff <= guard["eps"]
     p = O.psnr(guard["rgb"], split["rgb"])
     record("guarded_vs_split", case=name, w=w, h=h, refined_frac=guard["refined"] / (w * h), psnr_db=p, max_sw_diff=sw_diff,
-           eps=guard["eps"], monitor_max_seen=guard["seen"])
+           eps=guard["eps"], monitor_max_seen=guard["seen"], eps_pair=guard["eps_pair"], monitor_pair_seen=guard["pair_seen"],
+           audited=guard["audited"], band_source=R.GUARD_FROM[guard["source"]])
     assert p > 60.0
 
 
 def test_guard_calibration(cases):
-    """adanerf_calibrate_guard: seeded, repeatable, and 2x its result becomes the band.  The calibration rays are not this
+    """adanerf_calibrate_guard: seeded, repeatable, and 2x its results become the bounds.  The calibration rays are not this
     frame's rays, so the frame's own largest engine difference (measured here through the stage API) is an independent
     check that the margin holds."""
     z, meta, sc, wts, d = cases["classroom_n8_thr02"]
     w, h = 200, 160
-    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded") as r:
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded", guard_cache=False) as r:
         r.set_camera(z["pose"], z["rot"])
-        assert r.info.guard_eps == 0.0                      # not calibrated yet
-        a = r.calibrate_guard(8, 1)
-        b = r.calibrate_guard(8, 1)
+        assert r.info.guard_eps == 0.0 and r.info.guard_calib_source == R_GUARD_FROM_NONE       # not calibrated yet
+        a, ap = r.calibrate_guard(8, 1, pair=True)
+        b, bp = r.calibrate_guard(8, 1, pair=True)
         c = r.calibrate_guard(4, 7)
-        assert a == b and 1e-4 < a < 1e-2 and 1e-4 < c < 1e-2
+        assert a == b and ap == bp and 1e-4 < a < 1e-2 and 1e-4 < c < 1e-2
+        assert 0.0 < ap < 2.0 * a            # errors of one ray's outputs are correlated: the measured pair error stays below 2 max|error|
         r.calibrate_guard(8, 1, install=True)
         assert abs(r.info.guard_eps - max(2.0 * a, 1e-3)) < 1e-9
+        assert abs(r.info.guard_eps_pair - min(max(2.0 * ap, 1e-3), 2 * r.info.guard_eps)) < 1e-9
+        assert r.info.guard_calib_source == R_GUARD_FROM_CALIBRATION and r.info.guard_calib_poses == 8
         rgb, rgba, st = r.render_numpy()                    # the camera set before the calibration is still in place
         eps = r.info.guard_eps
     diffs = {}
@@ -657,9 +769,97 @@ def test_guard_calibration(cases):
             if smp == "split":
                 rgb_s = r.render_numpy()[0]
     frame_max = float(np.abs(diffs["split"] - diffs["fp16"]).max())
-    record("guard_calibration", calibrated_max=a, eps=eps, frame_max_diff=frame_max)
-    assert frame_max <= eps
+    frame_pair = float(O.guard_pair_error(diffs["fp16"], diffs["split"], sc.num_samples, sc.threshold, eps).max())
+    record("guard_calibration", calibrated_max=a, calibrated_pair_max=ap, eps=eps, frame_max_diff=frame_max, frame_max_pair_error=frame_pair)
+    assert frame_max <= eps and frame_pair <= min(max(2.0 * ap, 1e-3), 2 * eps)
     assert O.psnr(rgb, rgb_s) > 60.0
+
+
+def test_guard_calibration_record(cases, tmp_path, monkeypatch):
+    """The calibration is persisted per (model, N, threshold) and read back: the first guarded context of a model measures the band
+    over ADANERF_GUARD_CALIB_POSES poses and writes the record, the next one starts from it (same bounds, no measurement); a record of
+    another model / engine revision / fewer poses is ignored and replaced; ADANERF_FLAG_NO_GUARD_CACHE neither reads nor writes;
+    ADANERF_GUARD_CACHE_DIR moves the records out of the model directory."""
+    import shutil
+    z, meta, sc, wts, d0 = cases["classroom_n8_thr02"]
+    d = str(tmp_path / "model")
+    shutil.copytree(d0, d)
+    for f in os.listdir(d):
+        if f.startswith("guard_band."):
+            os.remove(os.path.join(d, f))
+    w, h = 96, 64
+
+    def frame(**kw):
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", **kw) as r:
+            path = r.guard_calibration_file()
+            r.set_camera(z["pose"], z["rot"])
+            _, rgba, st = r.render_numpy()
+            i = r.refresh_info()
+            return dict(path=path, eps=float(i.guard_eps), pair=float(i.guard_eps_pair), source=int(i.guard_calib_source), poses=int(i.guard_calib_poses),
+                        rgba=rgba, viol=int(st.guard_violations))
+
+    a = frame(guard_cache=False)
+    assert a["source"] == R_GUARD_FROM_CALIBRATION and a["poses"] == 64 and not os.path.exists(a["path"])
+    b = frame()
+    assert b["source"] == R_GUARD_FROM_CALIBRATION and os.path.exists(b["path"]) and os.path.dirname(b["path"]) == d
+    assert os.path.basename(b["path"]) == "guard_band.n8.t%08x.cal" % np.float32(sc.threshold).view(np.uint32)
+    c = frame()
+    assert c["source"] == R_GUARD_FROM_RECORD and c["poses"] == 64
+    assert a["eps"] == b["eps"] == c["eps"] and a["pair"] == b["pair"] == c["pair"] and 1e-3 <= c["eps"] <= 2e-2
+    assert np.array_equal(a["rgba"], c["rgba"]) and a["viol"] == b["viol"] == c["viol"] == 0
+    text = open(b["path"]).read()
+    assert "max_diff" in text and "max_pair_diff" in text and "poses = 64" in text
+    # another threshold is another record; a tampered key (another model), too few poses or a truncated file are not trusted
+    e = frame(threshold=0.1)
+    assert e["path"] != b["path"] and e["source"] == R_GUARD_FROM_CALIBRATION and e["eps"] == b["eps"]
+    for bad in (text.replace("key = ", "key = 0"), text.replace("poses = 64", "poses = 8"), text[: len(text) // 2], ""):
+        open(b["path"], "w").write(bad)
+        f = frame()
+        assert f["source"] == R_GUARD_FROM_CALIBRATION and f["eps"] == b["eps"]
+        assert open(b["path"]).read() == text                 # ... and replaced by a current one
+    os.remove(b["path"])
+    cache = str(tmp_path / "cache")
+    monkeypatch.setenv("ADANERF_GUARD_CACHE_DIR", cache)
+    g = frame()
+    assert g["path"].startswith(cache + os.sep) and os.path.exists(g["path"]) and not os.path.exists(b["path"])
+    assert frame()["source"] == R_GUARD_FROM_RECORD
+    record("guard_calibration_record", eps=b["eps"], eps_pair=b["pair"], file=os.path.basename(b["path"]))
+
+
+def test_guarded_frames_are_audited(cases):
+    """Frame level: over 16 frames of one pose the audit re-evaluates every decided ray exactly once (rotating 1/16), finds no
+    mismatch under the calibrated band, leaves every frame's bytes identical (audited rows are compared, not rewritten) -- and a
+    context whose band is far too narrow (1e-4: most rays 'decided', a per-mille of them wrongly) sees bound violations AND
+    selection mismatches on audited decided rays in its very first frame and widens the band."""
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    w, h = 320, 200
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16") as r:
+        r.set_camera(z["pose"], z["rot"])
+        assert r.info.guard_audit_period == 16
+        frames, sts = [], []
+        for _ in range(16):
+            _, rgba, st = r.render_numpy()
+            frames.append(rgba.copy())
+            sts.append((int(st.rays_refined), int(st.guard_audited), int(st.guard_audit_mismatch), int(st.guard_violations)))
+        und = sts[0][0] - sts[0][1]                               # rays_refined = undecided + audited decided rays of the frame
+    assert all(np.array_equal(f, frames[0]) for f in frames)
+    audited = [sts[0][1]] + [b[1] - a[1] for a, b in zip(sts, sts[1:])]      # guard_audited is cumulative
+    assert all(x[0] - (x[1] - y[1]) == und for x, y in zip(sts[1:], sts)) and sum(audited) == w * h - und
+    assert max(audited) - min(audited) <= 0.05 * (w * h - und) / 16 + 64
+    assert sts[-1][2] == 0 and sts[-1][3] == 0
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", guard_eps=1e-4) as r:
+        r.set_camera(z["pose"], z["rot"])
+        _, _, st = r.render_numpy()
+        narrow = (int(st.rays_refined), int(st.guard_audited), int(st.guard_audit_mismatch), int(st.guard_violations), int(st.guard_widened))
+        eps_after = float(r.refresh_info().guard_eps)
+        src = int(r.info.guard_calib_source)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", guard_eps=1e-4, guard_audit_period=-1) as r:
+        r.set_camera(z["pose"], z["rot"])
+        _, _, st = r.render_numpy()
+        assert r.info.guard_audit_period == 0 and st.guard_audited == 0 and st.guard_audit_mismatch == 0
+    record("guarded_frames_audited", undecided=und, audited_per_frame=audited, narrow_band=dict(zip(("refined", "audited", "mismatch", "violations", "widened"), narrow)),
+           band_after=eps_after)
+    assert narrow[1] > 0.8 * w * h / 16 and narrow[2] > 0 and narrow[3] > 0 and narrow[4] == 1 and eps_after > 1e-3 and src == R_GUARD_FROM_MONITOR
 
 
 def test_guard_band_widens_itself_after_a_violation(cases):
@@ -675,11 +875,12 @@ def test_guard_band_widens_itself_after_a_violation(cases):
         key_s = r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (int(cnt_s.sum()),)).copy()
     with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded", guard_eps=1e-3) as r:
         r.set_camera(z["pose"], z["rot"])
-        assert abs(r.info.guard_eps - 1e-3) < 1e-9
+        assert abs(r.info.guard_eps - 1e-3) < 1e-9 and r.info.guard_calib_source == R_GUARD_FROM_OPTIONS
         rgb, rgba, st0 = r.render_numpy()                   # synchronous: the monitor's copy of this frame is looked at right away
         assert st0.guard_violations > 0 and st0.guard_widened == 1
         eps = r.refresh_info().guard_eps
-        assert abs(eps - 2.0 * st0.guard_max_seen) < 1e-7 and eps > 2e-3
+        assert abs(eps - 2.0 * st0.guard_max_seen) < 1e-7 and eps > 2e-3 and r.info.guard_calib_source == R_GUARD_FROM_MONITOR
+        assert abs(r.info.guard_eps_pair - 2.0 * eps) < 1e-7      # a pair bound measured under the narrower band is dropped with it
         rgb, rgba, st1 = r.render_numpy()                   # rendered with the wider band
         cnt_g = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,)).copy()
         key_g = r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (int(cnt_g.sum()),)).copy()
@@ -1156,18 +1357,29 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     lines = [ln for ln in b.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, b.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0 and rec["config"]["frames_in_flight"] == 1
+    assert r1_guard_ok(rec)
     r1 = json.loads([ln for ln in a.stdout.splitlines() if ln.startswith("{")][0])
     assert abs(rec["config"]["samples_per_frame"] - r1["config"]["samples_per_frame"]) < 0.5
+    assert r1_guard_ok(r1) and r1["exact_mode"]["rays_with_the_headline_modes_sample_count"] == 1.0
+    assert r1["exact_mode"]["samples_per_frame"] == r1["config"]["samples_per_frame"]
     img1, img2 = np.load(one), np.load(two)
     assert img1.shape == img2.shape == (800, 800, 4)
     assert np.array_equal(img1, img2)
 
 
+def r1_guard_ok(rec):
+    """the bench line's record of the guarded selection: band from a 64-pose calibration, monitor silent, audit ran and is clean"""
+    g = rec["config"]["guard"]
+    return g["band_source"] in ("record", "calibration") and g["calibration_poses"] == 64 and g["monitor_violations"] == 0 and \
+        g["audit_mismatches"] == 0 and g["rays_audited"] > 0 and g["audit_period"] == 16 and 0 < g["monitor_max_seen"] <= g["eps"] < g["eps_pair"] <= 2 * g["eps"]
+
+
 @pytest.mark.gpu
 def test_bench_eight_ranks_share_one_gpu(tmp_path):
-    """The driver's N = 8 launch line on this box's one GPU (gloo exchange): 5-row strips, two frames in flight per rank
-    (sixteen contexts on the device), eight gathers per frame set; the assembled frame equals the single-rank frame."""
+    """The driver's N = 8 launch line on this box's one GPU (gloo exchange) with the optional two frames in flight per rank
+    (sixteen contexts on the device -- the default is one frame at a time, which test_bench_two_ranks_share_one_gpu runs): 5-row strips,
+    eight gathers per frame set; the assembled frame equals the single-rank frame."""
     import json
     import subprocess
     import sys
@@ -1179,7 +1391,7 @@ def test_bench_eight_ranks_share_one_gpu(tmp_path):
     env = dict(os.environ, ADANERF_BENCH_DIST_BACKEND="gloo", ADANERF_BENCH_ONE_DEVICE="1")
     b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                         "--master-port", "29771", "bench.py", "--gpus", "8", "--dump-image", eight, "--steps", "5", "--warmup", "2",
-                        "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--frames-in-flight", "2"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert b.returncode == 0, b.stderr[-2000:]
     lines = [ln for ln in b.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, b.stdout

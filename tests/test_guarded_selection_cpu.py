@@ -102,3 +102,75 @@ def test_transformed_values_band(transform):
         c, b, _ = O.select_adaptive(x, n_max, thr)
         same = (c == c0) & (b == b0).all(axis=1)
         assert same[~und].all()
+
+
+@pytest.mark.parametrize("n_max,thr", [(8, 0.2), (4, 0.15), (16, 0.15), (1, 0.3)])
+def test_pair_bound_rule(n_max, thr):
+    """Untransformed outputs with a measured bound on (kept - candidate) difference errors (eps_pair < 2 eps): more rays are decided
+    than under 2 eps, and a decided ray keeps its selection under every perturbation that respects BOTH bounds -- here the worst
+    admissible one for a pair bound: a common offset of up to eps - eps_pair / 2 on the whole row (fully correlated errors) plus
+    up to eps_pair / 2 of anything on top, so single values move by <= eps and differences by <= eps_pair."""
+    rng = np.random.default_rng(77 + n_max)
+    R = 4000
+    y = (rng.standard_normal((R, 128)) * 0.05).astype(F32)
+    for r in range(R):
+        k = rng.integers(0, 20)
+        y[r, rng.integers(0, 128, k)] = rng.uniform(0, 1.2, k)
+        if r % 5 == 0:
+            y[r, rng.integers(0, 128, 3)] = thr + rng.uniform(-0.03, 0.03, 3)
+    eps, ep = 0.01, 0.008
+    und2 = O.guard_undecided(y, n_max, thr, eps)
+    und = O.guard_undecided(y, n_max, thr, eps, eps_pair=ep)
+    assert (und <= und2).all() and und.sum() < und2.sum()      # never more conservative than 2 eps, and it buys something
+    assert (O.guard_undecided(y, n_max, thr, eps, eps_pair=2 * eps) == und2).all()
+    assert (O.guard_undecided(y, n_max, thr, eps, eps_pair=5 * eps) == und2).all()     # a bound above 2 eps is not a bound
+    c0, b0, _ = O.select_adaptive(y, n_max, thr)
+    e = np.full(R, F32(ep / 2))
+    for common in (-1.0, 0.0, 1.0):
+        for x in _adversarial(y, e, F32(thr), n_max, rng):
+            x = (x + F32(common * (eps - ep / 2) * 0.999)).astype(F32)
+            assert np.abs(x - y).max() <= eps
+            assert O.guard_pair_error(y, x, n_max, thr, eps).max() <= ep * 1.0001
+            c, b, _ = O.select_adaptive(x, n_max, thr)
+            same = (c == c0) & (b == b0).all(axis=1)
+            assert same[~und].all(), "a decided ray changed its selection under a perturbation inside both bounds"
+    # ... and the pair bound is what carries it: with independent errors of the full eps the narrower rule would be wrong somewhere
+    e = np.full(R, F32(eps))
+    broke = False
+    for x in _adversarial(y, e, F32(thr), n_max, rng):
+        c, b, _ = O.select_adaptive(x, n_max, thr)
+        broke |= bool((~((c == c0) & (b == b0).all(axis=1)))[~und].any())
+    assert broke or n_max == 1
+
+
+def test_pair_error_statistic():
+    """guard_pair_error on rows built by hand: only (kept, candidate-not-kept) pairs count, with the sign that closes the gap."""
+    n_max, thr, eps = 2, F32(0.2), F32(0.01)
+    y = np.full((4, 128), -1.0, dtype=F32)
+    x = y.copy()
+    y[:, 3], y[:, 9], y[:, 20] = 0.9, 0.5, 0.49          # kept: bins 3, 9; candidate: bin 20 (within 2 eps of the cut 0.5)
+    x[:] = y
+    x[0, 9] -= 0.004; x[0, 20] += 0.003                  # kept over-read by 4e-3, candidate under-read by 3e-3: pair error 7e-3
+    x[1, 9] += 0.004; x[1, 20] -= 0.003                  # the other sign opens the gap: 0
+    x[2, 3] -= 0.006                                     # the larger kept value counts too: 6e-3 against the candidate's 0
+    y[3, 20] = 0.47; x[3] = y[3]; x[3, 9] -= 0.009       # no candidate within 2 eps of the cut: 0
+    got = O.guard_pair_error(y, x, n_max, thr, eps)
+    assert np.allclose(got, [0.007, 0.0, 0.006, 0.0], atol=1e-6), got
+
+
+@pytest.mark.parametrize("period", [1, 2, 4, 8, 16, 32])
+def test_audit_rotation_covers_every_ray_once_per_period(period):
+    """Over `period` consecutive frames every ray of every segment is audited exactly once; at a fixed phase 32 / period rays of a
+    segment are, and neighbouring segments audit different lanes (no fixed image column)."""
+    for seg in (0, 1, 5, 31, 32, 1000):
+        seen = 0
+        for phase in range(period):
+            b = O.guard_audit_bits(period, phase, seg)
+            assert bin(b).count("1") == 32 // period and (seen & b) == 0
+            for j in range(32):
+                assert ((b >> j) & 1) == (1 if ((j - phase - seg) & (period - 1)) == 0 else 0)
+            seen |= b
+        assert seen == 0xFFFFFFFF
+    if period > 1:
+        assert O.guard_audit_bits(period, 0, 0) != O.guard_audit_bits(period, 0, 1)
+    assert O.guard_audit_bits(0, 3, 7) == 0

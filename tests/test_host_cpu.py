@@ -37,6 +37,42 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(R.EXPORTS) <= set(names)
 
 
+def test_dependency_list_is_the_include_closure():
+    """adanerf_amd/build.py: what `_stale()` watches and `source_hash()` stamps profiles with is every file the library's
+    translation units reach through #include "..." -- derived here a second way (the preprocessor's own dependency output would
+    need hipcc's headers; a plain scan of the text is enough for quoted includes).  Round 3 shipped with k_generic16.hip.hpp
+    missing from a hand-kept list."""
+    from adanerf_amd import build as B
+    csrc = B.CSRC
+    seen, todo = set(), list(B.LIB_SOURCES)
+    while todo:
+        rel = os.path.normpath(todo.pop())
+        if rel in seen:
+            continue
+        seen.add(rel)
+        for line in open(os.path.join(csrc, rel), errors="replace"):
+            m = re.match(r'\s*#\s*include\s+"([^"]+)"', line)
+            if m:
+                todo.append(os.path.join(os.path.dirname(rel), m.group(1)))
+    assert sorted(seen) == list(B.LIB_DEPS)
+    assert "k_generic16.hip.hpp" in B.LIB_DEPS and os.path.normpath("../../include/adanerf_hip.h") in B.LIB_DEPS
+    every_header = {f for f in os.listdir(csrc) if f.endswith((".hpp", ".h"))}
+    assert every_header <= set(B.LIB_DEPS), "headers in csrc/ that no translation unit includes: %s" % sorted(every_header - set(B.LIB_DEPS))
+    # the stamp moves with any hashed file and ignores the experiment-only header
+    h0 = B.source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", h0)
+
+
+def test_abi_handshake(lib):
+    """adanerf_abi_version / adanerf_struct_sizes against the ctypes mirrors (load_library refuses a library that disagrees)."""
+    sizes = (C.c_int32 * 3)()
+    assert lib.adanerf_abi_version() == R.ABI_VERSION
+    assert lib.adanerf_struct_sizes(sizes) == 0
+    assert list(sizes) == [C.sizeof(R._Options), C.sizeof(R.Info), C.sizeof(R.Stats)]
+    src = open(os.path.join(ROOT, "include", "adanerf_hip.h")).read()
+    assert int(re.search(r"#define ADANERF_ABI_VERSION (\d+)", src).group(1)) == R.ABI_VERSION
+
+
 def _opts(**kw):
     o = R._Options(width=64, height=48, batch_rays=0, device_id=0, precision=0, num_samples=0, threshold=-1.0,
                    shard_rank=0, shard_world=1, strip_rows=8)
