@@ -186,7 +186,7 @@ __device__ __forceinline__ int pair_select(const float* x, int h, int n_max, flo
     bool und = tie;
 #pragma unroll
     for (int k = 0; k < NB; ++k) und |= (k < n_max) && (fabsf(c[k] - thr) <= e);
-    const float ep = transform == kOracleSoftmax ? pair_raw * c[0] : pair_raw;      // guard_pair_of(): e < ep <= 2 e
+    const float ep = transform == kOracleSoftmax ? pair_raw * c[0] : pair_raw;      // guard_pair_of(): 0 < ep <= 2 e (may be below e)
     const float u = none ? c[0] - ep : fmaxf(tn - ep, thr - e);
     if (cand_cut) *cand_cut = none ? c[0] - 2.0f * e : fmaxf(tn - 2.0f * e, thr - e);
     if (kept_cut) *kept_cut = t;

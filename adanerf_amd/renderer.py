@@ -206,11 +206,15 @@ class NeuralRenderer:
 
     def __init__(self, settings: Settings, precision="bf16", device_id: int = 0, num_samples: int = 0,
                  threshold: float = -1.0, shard_rank: int = 0, shard_world: int = 1, strip_rows: int = 8,
-                 sampling: str = "guarded", lib_path: Optional[str] = None, keep_oracle: bool = False, wave_select: bool = False,
+                 sampling: Optional[str] = None, lib_path: Optional[str] = None, keep_oracle: bool = False, wave_select: bool = False,
                  guard_eps: float = 0.0, guard_eps_pair: float = 0.0, guard_audit_period: int = 0, guard_cache: bool = True):
-        """sampling: arithmetic of the sampling network -- "guarded" (default, as in the `adanerf` CLI and bench.py: plain fp16 for every
-        ray + the split-precision engine where the audited guard band cannot decide; the split engine's selections), "split", "fp32",
-        "fp16" (opt-in speed mode).  guard_*: include/adanerf_hip.h adanerf_options."""
+        """sampling: arithmetic of the sampling network -- "guarded" (plain fp16 for every ray + the split-precision engine where the
+        audited guard band cannot decide; the split engine's selections), "split", "fp32", "fp16" (opt-in speed mode).  Default (None),
+        as in the `adanerf` CLI and bench.py: "guarded" with a 16-bit shading network; "split" with precision="fp32" -- the
+        tight-tolerance parity mode, where the kept oracle values of the rays the guarded mode does not re-evaluate (the fp16 engine's,
+        within the band of the exact ones: ~4e-3) would be the largest error of the frame.  guard_*: include/adanerf_hip.h adanerf_options."""
+        if sampling is None:
+            sampling = "split" if (_PREC[precision] if isinstance(precision, str) else int(precision)) == PREC_FP32 else "guarded"
         self.settings = settings
         self.lib = load_library(lib_path)
         self.handle = None

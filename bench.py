@@ -175,9 +175,10 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--batch-rays", type=int, default=-1)
     ap.add_argument("--threshold", type=float, default=None, help="override the workload's adaptive sampling threshold")
-    ap.add_argument("--sampling", default="guarded", choices=["split", "fp32", "fp16", "guarded"],
-                    help="sampling-MLP arithmetic: guarded (default: plain fp16 + split-fp16 on the rays inside the guard band -- the split "
-                         "engine's selections), split-fp16 (fp32-accurate, every ray), exact fp32, or the opt-in plain fp16 speed mode")
+    ap.add_argument("--sampling", default=None, choices=["split", "fp32", "fp16", "guarded"],
+                    help="sampling-MLP arithmetic: guarded (default with a 16-bit shading MLP: plain fp16 + split-fp16 on the rays inside the "
+                         "audited guard band -- the split engine's selections), split-fp16 (fp32-accurate, every ray; default with --precision "
+                         "fp32), exact fp32, or the opt-in plain fp16 speed mode")
     ap.add_argument("--guard-eps", type=float, default=0.0, help="band of --sampling guarded (0: the model's calibration record / measured at the first frame)")
     ap.add_argument("--guard-audit-period", type=int, default=0, help="--sampling guarded: audit 1 / period of all rays per frame (0: library default 16, < 0: off)")
     ap.add_argument("--no-exact-mode", action="store_true", help="skip the extra every-ray-split-precision measurement reported under exact_mode")
@@ -193,6 +194,8 @@ def main():
                          "launch gaps of one frame's kernels overlap the next frame's (more throughput; a frame's latency doubles)")
     ap.add_argument("--dump-image", default=None, help="rank 0 writes the last frame's RGBA8 image [h,w,4] as .npy (tests)")
     args = ap.parse_args()
+    if args.sampling is None:
+        args.sampling = "split" if args.precision == "fp32" else "guarded"
 
     import torch
     import adanerf_amd

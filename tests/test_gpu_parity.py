@@ -726,7 +726,8 @@ def test_guarded_sampling_reproduces_the_split_engine(cases, name, w, h, bs):
     # re-evaluated rays and what the kept values of the other rays show must lie inside it
     assert 1e-3 <= guard["eps"] <= 2e-2, guard["eps"]
     assert guard["viol"] == 0 and 0.0 < guard["seen"] <= guard["eps"]
-    assert guard["source"] in (R_GUARD_FROM_RECORD, R_GUARD_FROM_CALIBRATION) and guard["eps"] < guard["eps_pair"] <= 2 * guard["eps"]
+    # (the pair bound may come out BELOW the single-value bound: errors of one ray's outputs are correlated -- barbershop: 0.0134 vs 0.0139)
+    assert guard["source"] in (R_GUARD_FROM_RECORD, R_GUARD_FROM_CALIBRATION) and 1e-3 <= guard["eps_pair"] <= 2 * guard["eps"]
     assert guard["pair_seen"] <= guard["eps_pair"]
     # the audit: the last batch looked at ~1/16 of its decided rays again and found every selection in place exact
     assert guard["audited"] > 0 and guard["mismatch"] == 0 and wide["audited"] == 0
@@ -1372,7 +1373,7 @@ def r1_guard_ok(rec):
     """the bench line's record of the guarded selection: band from a 64-pose calibration, monitor silent, audit ran and is clean"""
     g = rec["config"]["guard"]
     return g["band_source"] in ("record", "calibration") and g["calibration_poses"] == 64 and g["monitor_violations"] == 0 and \
-        g["audit_mismatches"] == 0 and g["rays_audited"] > 0 and g["audit_period"] == 16 and 0 < g["monitor_max_seen"] <= g["eps"] < g["eps_pair"] <= 2 * g["eps"]
+        g["audit_mismatches"] == 0 and g["rays_audited"] > 0 and g["audit_period"] == 16 and 0 < g["monitor_max_seen"] <= g["eps"] and 0 < g["eps_pair"] <= 2 * g["eps"]
 
 
 @pytest.mark.gpu
