@@ -132,14 +132,14 @@ def build_probes(force=False, verbose=False):
     so the GPU tests can exercise device functions that have no ABI entry of their own (sin_or_cos)."""
     pdir = os.path.join(os.path.dirname(HERE), "tools", "probes")
     outs = []
-    for name in ("sincos_probe",):
+    for name in ("sincos_probe", "mfma_peak"):      # mfma_peak: the table behind bench.py's roofline.sustained_peak (csrc/k_probe.hip.hpp)
         src = os.path.join(pdir, name + ".hip")
         out = os.path.join(BINDIR, name)
         if not os.path.exists(src):
             continue
         if force or _stale(out, [src] + [os.path.join(CSRC, d) for d in LIB_DEPS]):
             os.makedirs(BINDIR, exist_ok=True)
-            cmd = [_hipcc()] + HIPCC_FLAGS + [src, "-o", out]
+            cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", CSRC, src, "-o", out]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)

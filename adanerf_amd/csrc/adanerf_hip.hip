@@ -596,6 +596,9 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
     a.sel.audit_phase = c->guard_audit_period > 0 ? static_cast<int32_t>(c->guard_frame & static_cast<uint32_t>(c->guard_audit_period - 1)) : 0;
     a.sel.guard_probe = reinterpret_cast<float*>(c->guard_probe.p);
     a.sel.guard_rows = reinterpret_cast<float*>(c->oracle.p);      // free on this path: the selection is fused, nobody else writes the oracle buffer
+    if (const char* dbg = std::getenv("ADANERF_DEBUG_GUARD")) {      // measurement knob (profiles/r04_guard_monitor_cost.md): 1 = no whole-row monitor
+      if (std::atoi(dbg) & 1) a.sel.guard_rows = nullptr;
+    }
     a.sel.guard_seen = reinterpret_cast<uint32_t*>(c->total.p) + 8;
   }
   if (c->sampling_mode == 1) {
@@ -1949,6 +1952,19 @@ int adanerf_gather_to(adanerf_ctx* dst, void* d_dst, adanerf_ctx* src, const voi
   c = dst;
   BIND(dst);
   HIP_TRY(c, hipStreamWaitEvent(dst->stream, src->peer_event, 0));
+  return ADANERF_OK;
+}
+
+int adanerf_probe_mfma(adanerf_ctx* c, int32_t operands, int32_t f16, float target_ms, float* tflops, float* clock_mhz) {
+  if (!c) return ADANERF_EINVAL;
+  BIND(c);
+  if (operands < 0 || operands > 3 || !(target_ms > 0.f) || target_ms > 5000.f || !tflops || !clock_mhz)
+    return fail(c, ADANERF_EINVAL, "operands must be 0..3, target_ms in (0, 5000], outputs non-NULL");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  double tf = 0, mhz = 0;
+  HIP_TRY(c, probe_mfma_rate(operands, f16 != 0, target_ms, c->info.compute_units, c->stream, &tf, &mhz));
+  *tflops = static_cast<float>(tf);
+  *clock_mhz = static_cast<float>(mhz);
   return ADANERF_OK;
 }
 

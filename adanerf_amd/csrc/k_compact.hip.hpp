@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const float* __restric
   const int local = first + j;
   const bool valid = local < n_rays;
   const int lidx = valid ? local : n_rays - 1;
-  const float* row = oracle + static_cast<size_t>(n_list ? (so.refine_list[lidx] & kRefineRayMask) : lidx) * kBins;
+  const int entry = n_list ? so.refine_list[lidx] : 0;
+  const float* row = oracle + static_cast<size_t>(n_list ? (entry & kRefineRayMask) : lidx) * kBins;
   float x[64];
 #pragma unroll
   for (int m = 0; m < 4; ++m)
@@ -205,7 +206,9 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const float* __restric
     for (int i = 0; i < 64; ++i) z = __builtin_fmaf(x[i], 0.f, z);
     bad = (z != z) | (pair_xchg(static_cast<uint32_t>(z != z)) != 0u);
   }
-  pair_epilogue(x, lane, local, valid, stage, so, bad);
+  GuardAcc gacc;
+  pair_epilogue(x, lane, local, valid, stage, so, bad, entry, &gacc);
+  if (n_list) guard_flush(so, gacc, lane);
 }
 
 // max |a - b| over n floats -> *out (float bits of a non-negative value, atomicMax); a non-finite difference sets out[1]

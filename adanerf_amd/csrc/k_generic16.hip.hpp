@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, (STAGED && W <= 128 && FP <= 10) ? 2 : 1) void
     for (int i = 0; i < 64; ++i) z = __builtin_fmaf(out[i], 0.f, z);    // NaN iff some output is inf / NaN (fp16 range left)
     const bool bad_ray = (z != z) | (pair_xchg(static_cast<uint32_t>(z != z)) != 0u);
     if (bad_ray && valid && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
-    pair_epilogue(out, lane, local, valid, sel_stage, a.sel);
+    pair_epilogue<false>(out, lane, local, valid, sel_stage, a.sel);      // never pass 2 of the guarded selection
   }
   if (valid) {
     if (a.oracle_out) {

@@ -163,11 +163,13 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
   const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
   const uint32_t* bo = a.net16.b_off;
 
+  GuardAcc gacc;      // refinement pass: the wave's monitor / audit record over all its tiles
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int local = tile * TILE + wave * 32 + j;
     const bool valid = local < n_rays;
     const int lidx = valid ? local : n_rays - 1;
-    const int ray = a.first_ray + (a.ray_list ? (a.ray_list[lidx] & kRefineRayMask) : lidx);
+    const int entry = a.ray_list ? a.ray_list[lidx] : 0;      // refinement pass: ray id (+ kRefineAuditBit), kept for the epilogue
+    const int ray = a.first_ray + (a.ray_list ? (entry & kRefineRayMask) : lidx);
     int col, row;
     ray_pixel(a.g, ray, &col, &row);
     float nds[3], p[3], u[3];
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
       for (int i = 0; i < 64; ++i) z = __builtin_fmaf(out[i], 0.f, z);    // NaN iff some output is inf / NaN (fp16 range left)
       const bool bad_ray = (z != z) | (pair_xchg(static_cast<uint32_t>(z != z)) != 0u);
       if (bad_ray && valid && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
-      pair_epilogue(out, lane, local, valid, sel_stage, a.sel);
+      pair_epilogue(out, lane, local, valid, sel_stage, a.sel, false, entry, &gacc);
     }
     if (valid) {
       if (a.oracle_out) {
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
       }
     }
   }
+  if (a.fused_select && a.ray_list) guard_flush(a.sel, gacc, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
       const bool bad_ray = (z != z) | (pair_xchg(static_cast<uint32_t>(z != z)) != 0u);
       // guard mode: a non-finite ray goes to the refinement pass, which does the counting
       if (bad_ray && valid && h == 0 && a.overflow_flag && !a.sel.guard_mask) atomicAdd(a.overflow_flag, 1);
-      pair_epilogue(x, lane, local, valid, sel_stage, a.sel, bad_ray);
+      pair_epilogue<false>(x, lane, local, valid, sel_stage, a.sel, bad_ray);
     }
     if (valid && a.oracle_out) {
       float* o = a.oracle_out + static_cast<size_t>(local) * kBins;

@@ -287,28 +287,47 @@ __device__ __forceinline__ bool pair_emit(const float* x, uint32_t lo, uint32_t 
   return differs;
 }
 
-// Monitor of the guarded selection (pass 2): this lane's 64 exact raw outputs x against the ray's first-pass raw outputs (row = that
-// ray's [128] floats in HBM, the layout pass 1 / the oracle buffer use).  *m_abs = largest |y - x| of the ray, *m_pair = largest
-// (y_i - x_i) - (y_j - x_j) over kept bins i (y_i >= kept_cut) and candidates j (cand_cut <= y_j < kept_cut); both for the whole ray
-// (the two lanes that share it agree).  A non-finite difference counts as 0: such a ray is re-evaluated because of it.
-__device__ __forceinline__ void pair_monitor(const float* x, const float* __restrict__ row, int h, float cand_cut, float kept_cut, bool pairs,
-                                             float* m_abs, float* m_pair) {
+// Monitor of the guarded selection (pass 2): this lane's 64 exact raw outputs x against the ray's first-pass raw outputs -- that ray's
+// [128] floats in HBM, the layout pass 1 / the oracle buffer use: lane (j, h) owns the 16 float4 at floats 32 m + 8 g + 4 h.
+// The 16 loads and their wait are ONE asm statement: hipcc, left to itself, re-used one destination quad and exposed 16 memory
+// latencies per 32-ray tile of a one-wave-per-SIMD kernel (+18 % on the whole refinement pass, profiles/r04_guard_monitor_cost.md);
+// this exposes one.  (Issuing them before the selection and waiting after it -- two asm statements -- is not safe: between the two
+// the compiler believes the destinations already hold their values and, under this kernel's register pressure, moved some of them to
+// other registers before the data had landed: the monitor then compared garbage.)
+struct RowRegs {
+  f32x4 v[16];
+};
+__device__ __forceinline__ void row_load(const float* __restrict__ row, int h, RowRegs& r) {
+  const float* p = row + 4 * h;
+  asm volatile(
+      "global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:32\n\tglobal_load_dwordx4 %2, %16, off offset:64\n\t"
+      "global_load_dwordx4 %3, %16, off offset:96\n\tglobal_load_dwordx4 %4, %16, off offset:128\n\tglobal_load_dwordx4 %5, %16, off offset:160\n\t"
+      "global_load_dwordx4 %6, %16, off offset:192\n\tglobal_load_dwordx4 %7, %16, off offset:224\n\t"
+      "global_load_dwordx4 %8, %16, off offset:256\n\tglobal_load_dwordx4 %9, %16, off offset:288\n\tglobal_load_dwordx4 %10, %16, off offset:320\n\t"
+      "global_load_dwordx4 %11, %16, off offset:352\n\tglobal_load_dwordx4 %12, %16, off offset:384\n\tglobal_load_dwordx4 %13, %16, off offset:416\n\t"
+      "global_load_dwordx4 %14, %16, off offset:448\n\tglobal_load_dwordx4 %15, %16, off offset:480\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(r.v[8]),
+        "=&v"(r.v[9]), "=&v"(r.v[10]), "=&v"(r.v[11]), "=&v"(r.v[12]), "=&v"(r.v[13]), "=&v"(r.v[14]), "=&v"(r.v[15])
+      : "v"(p)
+      : "memory");
+}
+// *m_abs = largest |y - x| of the ray, *m_pair = largest (y_i - x_i) - (y_j - x_j) over kept bins i (y_i >= kept_cut) and candidates j
+// (cand_cut <= y_j < kept_cut); both for the whole ray (the two lanes that share it agree).  A non-finite difference counts as 0:
+// such a ray is re-evaluated because of it.
+__device__ __forceinline__ void pair_monitor(const float* x, const RowRegs& yr, float cand_cut, float kept_cut, bool pairs, float* m_abs, float* m_pair) {
   float ma = 0.f, dk = -INFINITY, dn = INFINITY;
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int q = 0; q < 16; ++q)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 y4 = *reinterpret_cast<const float4*>(row + 32 * m + 8 * g + 4 * h);
-      const float y[4] = {y4.x, y4.y, y4.z, y4.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float d = y[e] - x[16 * m + 4 * g + e];
-        const bool fin = fabsf(d) < INFINITY;      // false for NaN, too
-        ma = fin ? fmaxf(ma, fabsf(d)) : ma;
-        if (pairs) {
-          dk = (fin && y[e] >= kept_cut) ? fmaxf(dk, d) : dk;
-          dn = (fin && y[e] >= cand_cut && y[e] < kept_cut) ? fminf(dn, d) : dn;
-        }
+    for (int e = 0; e < 4; ++e) {
+      const float y = yr.v[q][e];
+      const float d = y - x[4 * q + e];          // q = 4 m + g: x index 16 m + 4 g + e
+      const bool fin = fabsf(d) < INFINITY;      // false for NaN, too
+      ma = fin ? fmaxf(ma, fabsf(d)) : ma;
+      if (pairs) {
+        dk = (fin && y >= kept_cut) ? fmaxf(dk, d) : dk;
+        dn = (fin && y >= cand_cut && y < kept_cut) ? fminf(dn, d) : dn;
       }
     }
   ma = fmaxf(ma, pair_xchg(ma));
@@ -319,14 +338,45 @@ __device__ __forceinline__ void pair_monitor(const float* x, const float* __rest
   *m_pair = (pairs && pr > 0.f && pr < INFINITY) ? pr : 0.f;
 }
 
+// What pass 2 of the guarded selection learns about its rays, accumulated per WAVE over all the tiles a persistent kernel walks and
+// written with five atomics at the end of the kernel (guard_flush).  Per tile they were ~4 same-address atomics per wave, counted
+// by vmcnt like every other memory operation -- the weight ring's next counted wait then sat behind them: +17 % on the whole
+// refinement pass (profiles/r04_guard_monitor_cost.md).  All fields are wave-uniform (they live in SGPRs).
+struct GuardAcc {
+  uint32_t max_bits = 0, pair_bits = 0;      // float bits of non-negative values: order like unsigned integers
+  uint32_t over = 0, audited = 0, mismatch = 0;
+};
+__device__ __forceinline__ void guard_flush(const SelectOut& so, const GuardAcc& g, int lane) {
+  if (!so.guard_seen || lane != 0) return;
+  if (g.max_bits) atomicMax(&so.guard_seen[0], g.max_bits);
+  if (g.over) atomicAdd(&so.guard_seen[1], g.over);
+  if (g.pair_bits) atomicMax(&so.guard_seen[2], g.pair_bits);
+  if (g.mismatch) atomicAdd(&so.guard_seen[3], g.mismatch);
+  if (g.audited) atomicAdd(&so.guard_seen[4], g.audited);
+}
+
 // The whole epilogue for one wave's 32 rays: select, emit, per-ray counts, segment total.
 //   x        64 values of ray j in lane (j, h) (layout above)
 //   local    ray index of lane j inside the batch, valid = local < n_rays (invalid lanes hold a duplicate ray)
 //   stage    see pair_emit
 //   force_undecided  guard mode: the caller already knows the ray needs the exact engine (non-finite raw outputs)
+//   entry    pass 2 of the guarded selection: the caller's copy of so.refine_list[local] (it needed the ray id anyway), else unused
+//   gacc     pass 2: the wave's running monitor / audit record, flushed by the caller (guard_flush) when it has no more tiles
+//   REFINE   the kernel can serve as pass 2 of the guarded selection (so.refine_list decides at run time); false in the plain-fp16
+//            first-pass kernel, whose 256-register budget has no room for the monitor's row (it spilled 185 registers with it)
+template <bool REFINE = true>
 __device__ __forceinline__ void pair_epilogue(const float* x_raw, int lane, int local, bool valid, uint32_t stage, const SelectOut& so,
-                                              bool force_undecided = false) {
+                                              bool force_undecided = false, int entry = 0, GuardAcc* gacc = nullptr) {
   const int h = lane >> 5;
+  // pass 2 of the guarded selection: what the monitor and the audit read from HBM is requested first and used after the selection
+  const bool monitored = REFINE && so.refine_list && so.guard_rows && so.guard_seen;      // wave-uniform
+  const int target = entry & kRefineRayMask;
+  float2 cuts = make_float2(0.f, 0.f);
+  int old_count = 0;
+  if (REFINE && so.refine_list) {
+    if (monitored && so.guard_band_pair > 0.f && so.guard_probe) cuts = *reinterpret_cast<const float2*>(so.guard_probe + 2 * static_cast<size_t>(target));
+    old_count = so.counts[target];
+  }
   float x[64];
   if (so.transform == kOracleSigmoid) {
 #pragma unroll
@@ -357,44 +407,36 @@ __device__ __forceinline__ void pair_epilogue(const float* x_raw, int lane, int 
   if (so.n_max <= 4) total = pair_select<4>(x, h, so.n_max, so.thr, &lo, &hi, eps, so.transform, &und, so.guard_pair, &cand_cut, &kept_cut);
   else if (so.n_max <= 8) total = pair_select<8>(x, h, so.n_max, so.thr, &lo, &hi, eps, so.transform, &und, so.guard_pair, &cand_cut, &kept_cut);
   else total = pair_select<16>(x, h, so.n_max, so.thr, &lo, &hi, eps, so.transform, &und, so.guard_pair, &cand_cut, &kept_cut);
-  if (so.refine_list) {
+  if (REFINE && so.refine_list) {
     // pass 2 of the guarded selection: this wave's rays are scattered over the batch.  An undecided ray: replace its row and correct
     // the total of its 32-ray segment by the difference (integer atomics: the result does not depend on their order).  A ray pass 1
     // had decided (audit): compare the row in place with the exact selection, store nothing -- the frame does not depend on which
     // rays were audited.
-    const int entry = valid ? so.refine_list[local] : 0;
-    const int target = entry & kRefineRayMask;
     const bool audit = (entry & kRefineAuditBit) != 0;
-    if (so.guard_rows && so.guard_seen) {
+    if (monitored) {
       // the assumptions behind the band, measured on the whole row in RAW units (x_raw: before the sampler's transform)
       const bool pairs = so.guard_band_pair > 0.f && so.guard_probe != nullptr;
-      float cc = 0.f, kc = 0.f;
-      if (pairs) {
-        const float2 pr = *reinterpret_cast<const float2*>(so.guard_probe + 2 * static_cast<size_t>(target));
-        cc = pr.x;
-        kc = pr.y;
-      }
       float ma, mp;
-      pair_monitor(x_raw, so.guard_rows + static_cast<size_t>(target) * kBins, h, cc, kc, pairs, &ma, &mp);
+      RowRegs yrow;
+      row_load(so.guard_rows + static_cast<size_t>(target) * kBins, h, yrow);
+      pair_monitor(x_raw, yrow, cuts.x, cuts.y, pairs, &ma, &mp);
       if (!(valid && h == 0)) ma = mp = 0.f;
       const uint64_t over = __ballot(ma > so.guard_band || (pairs && mp > so.guard_band_pair));
       ma = wave_max_nonneg(ma);
       mp = wave_max_nonneg(mp);
-      if (lane == 0) {
-        if (ma > 0.f) atomicMax(&so.guard_seen[0], __builtin_bit_cast(uint32_t, ma));
-        if (mp > 0.f) atomicMax(&so.guard_seen[2], __builtin_bit_cast(uint32_t, mp));
-        if (over) atomicAdd(&so.guard_seen[1], static_cast<uint32_t>(__popcll(over)));
-      }
+      const uint32_t mab = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__builtin_bit_cast(uint32_t, ma))));
+      const uint32_t mpb = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__builtin_bit_cast(uint32_t, mp))));
+      gacc->max_bits = gacc->max_bits > mab ? gacc->max_bits : mab;
+      gacc->pair_bits = gacc->pair_bits > mpb ? gacc->pair_bits : mpb;
+      gacc->over += static_cast<uint32_t>(__popcll(over));
     }
-    const int old = valid ? so.counts[target] : 0;
+    const int old = valid ? old_count : 0;
     bool differs = pair_emit(x, lo, hi, h, stage, valid, static_cast<size_t>(target) * so.n_max, so.selbin, so.selw, !audit);
     differs = (differs | (pair_xchg(static_cast<uint32_t>(differs)) != 0u) | (total != old)) && audit && valid;
     if (so.guard_seen) {
       const uint64_t aud = __ballot(audit && valid && h == 0), bad = __ballot(differs && h == 0);
-      if (lane == 0) {
-        if (aud) atomicAdd(&so.guard_seen[4], static_cast<uint32_t>(__popcll(aud)));
-        if (bad) atomicAdd(&so.guard_seen[3], static_cast<uint32_t>(__popcll(bad)));
-      }
+      gacc->audited += static_cast<uint32_t>(__popcll(aud));
+      gacc->mismatch += static_cast<uint32_t>(__popcll(bad));
     }
     if (valid && h == 0 && !audit) {
       so.counts[target] = total;

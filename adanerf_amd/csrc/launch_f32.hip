@@ -4,8 +4,36 @@
 #include "k_mlp16.hip.hpp"     // shade_mlp32_kernel (shares ShadeArgs / load_sample with the 16-bit shading kernel)
 #include "k_mlp_f32.hip.hpp"   // sample_mlp_kernel
 #include "k_generic_f32.hip.hpp"
+#include "k_probe.hip.hpp"
 
 namespace adanerf {
+
+hipError_t probe_mfma_rate(int operands, bool f16, double target_ms, int compute_units, hipStream_t stream, double* tflops, double* mhz) {
+  using namespace probe;
+  float* sink = nullptr;
+  uint64_t* clocks = nullptr;
+  hipError_t rc = hipMalloc(reinterpret_cast<void**>(&sink), 64);
+  if (rc != hipSuccess) return rc;
+  if ((rc = hipMalloc(reinterpret_cast<void**>(&clocks), 64)) != hipSuccess) {
+    (void)hipFree(sink);
+    return rc;
+  }
+#define ADN_PROBE(F16v, MODEv) rc = mfma_rate<2, F16v, MODEv>(compute_units, target_ms, stream, sink, clocks, tflops, mhz)
+#define ADN_PROBE_M(F16v)                          \
+  do {                                             \
+    if (operands == kZero) ADN_PROBE(F16v, kZero); \
+    else if (operands == kConstant) ADN_PROBE(F16v, kConstant); \
+    else if (operands == kRandom) ADN_PROBE(F16v, kRandom);     \
+    else ADN_PROBE(F16v, kRelu);                   \
+  } while (0)
+  if (f16) ADN_PROBE_M(true);
+  else ADN_PROBE_M(false);
+#undef ADN_PROBE_M
+#undef ADN_PROBE
+  (void)hipFree(sink);
+  (void)hipFree(clocks);
+  return rc;
+}
 
 hipError_t launch_sample_mlp_f32(const SampleArgs& a, bool full, unsigned grid, hipStream_t stream) {
   if (full) hipLaunchKernelGGL((sample_mlp_kernel<10, 4>), dim3(grid), dim3(256), 0, stream, a);

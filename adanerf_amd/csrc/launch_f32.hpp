@@ -24,4 +24,9 @@ enum { kEnc10_4 = 0, kEnc2_2 = 1, kEncMax = 2 };
 hipError_t launch_sample_mlp_gen(const SampleArgs& a, const GenericTopo& t, int enc, int width, unsigned grid, hipStream_t stream);
 hipError_t shade_mlp_gen_grid(int compute_units, int enc, int width, int* grid);
 hipError_t launch_shade_mlp_gen(const ShadeArgs& a, const GenericTopo& t, int enc, int width, int grid, hipStream_t stream);
+
+// Measurement hook (k_probe.hip.hpp; include/adanerf_hip.h adanerf_probe_mfma): register-only v_mfma_f32_32x32x16_{bf16,f16} loops on every
+// CU for ~target_ms, operands 0 zero / 1 constant / 2 random / 3 relu-like, two accumulator chains per wave and one wave per SIMD (the
+// shading kernel's form).  Synchronises the stream.
+hipError_t probe_mfma_rate(int operands, bool f16, double target_ms, int compute_units, hipStream_t stream, double* tflops, double* mhz);
 }  // namespace adanerf

@@ -66,7 +66,7 @@ EXPORTS = ["adanerf_create", "adanerf_destroy", "adanerf_get_info", "adanerf_las
            "adanerf_collect_stats", "adanerf_ray_features", "adanerf_sample_mlp",
            "adanerf_compact", "adanerf_compact_guarded", "adanerf_calibrate_guard", "adanerf_guard_calibration_file", "adanerf_shade_features", "adanerf_shade_mlp", "adanerf_shade_mlp_z", "adanerf_sample_pdf", "adanerf_sample_uniform", "adanerf_shade_mlp_coarse", "adanerf_sample_from_coarse",
            "adanerf_composite", "adanerf_composite_classic", "adanerf_copy_result_sampling_network",
-           "adanerf_render_oracle", "adanerf_gather_to", "adanerf_malloc",
+           "adanerf_render_oracle", "adanerf_gather_to", "adanerf_probe_mfma", "adanerf_malloc",
            "adanerf_free", "adanerf_memcpy_h2d", "adanerf_memcpy_d2h", "adanerf_get_buffer"]
 
 _lib = None
@@ -116,6 +116,7 @@ def load_library(path: Optional[str] = None):
     lib.adanerf_copy_result_sampling_network.argtypes = [vp, vp, i32, vp]
     lib.adanerf_render_oracle.argtypes = [vp, vp]
     lib.adanerf_gather_to.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    lib.adanerf_probe_mfma.argtypes = [vp, i32, i32, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.adanerf_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.adanerf_free.argtypes = [vp, vp]
     lib.adanerf_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -394,6 +395,14 @@ class NeuralRenderer:
         buf = C.create_string_buffer(n)
         self.lib.adanerf_guard_calibration_file(self.handle, buf, n)
         return buf.value.decode()
+
+    def probe_mfma(self, operands: str = "relu", f16: bool = False, target_ms: float = 100.0):
+        """(TFLOP/s, MHz) this device sustains on register-only 16-bit MFMA loops with "zero" / "constant" / "random" / "relu" operands
+        (include/adanerf_hip.h adanerf_probe_mfma)."""
+        tf, mhz = C.c_float(0), C.c_float(0)
+        self._check(self.lib.adanerf_probe_mfma(self.handle, {"zero": 0, "constant": 1, "random": 2, "relu": 3}[operands], 1 if f16 else 0,
+                                                target_ms, C.byref(tf), C.byref(mhz)))
+        return float(tf.value), float(mhz.value)
 
     def shade_features(self, rays, sample_key, n_samples: int, features_out):
         self._check(self.lib.adanerf_shade_features(self.handle, _ptr(rays), _ptr(sample_key), n_samples, _ptr(features_out)))

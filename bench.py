@@ -181,6 +181,7 @@ def main():
                          "fp32), exact fp32, or the opt-in plain fp16 speed mode")
     ap.add_argument("--guard-eps", type=float, default=0.0, help="band of --sampling guarded (0: the model's calibration record / measured at the first frame)")
     ap.add_argument("--guard-audit-period", type=int, default=0, help="--sampling guarded: audit 1 / period of all rays per frame (0: library default 16, < 0: off)")
+    ap.add_argument("--no-sustained-probe", action="store_true", help="skip the ~0.5 s MFMA-rate probe behind roofline.sustained_peak / frac_of_sustained")
     ap.add_argument("--no-exact-mode", action="store_true", help="skip the extra every-ray-split-precision measurement reported under exact_mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-speed-mode", action="store_true", help="skip the extra fp16-sampling measurement reported under speed_mode")
@@ -434,6 +435,18 @@ def main():
                     "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "avg_launch_ms": shade_ms, "samples_per_launch": st.total_samples / launches,
                     "flop_per_sample": flop_per_sample}
+        # What the silicon sustains on live operands, measured here and now on this box (adanerf_probe_mfma: register-only MFMA loops,
+        # the shading kernel's wave shape): the part runs to a power budget, so the same instruction stream clocks ~2.4 GHz on zeros and
+        # ~1.7 GHz on random operands (profiles/r04_mfma_peak_operands_clock.log).  `frac` stays against the nominal 2.5 PFLOP/s.
+        if args.precision != "fp32" and not args.no_sustained_probe:
+            sus = {}
+            for mode, ms_t in (("zero", 60.0), ("relu", 200.0), ("random", 200.0)):
+                tf, mhz = r.probe_mfma(mode, f16=(args.precision == "fp16"), target_ms=ms_t)
+                sus[mode] = {"tflops": tf, "clock_mhz": mhz}
+            roofline["sustained_peak"] = dict(sus, note="register-only v_mfma_f32_32x32x16 loops on every CU, same run, same box: operands all zero / "
+                                              "random weights x post-ReLU-like activations (half zeros, rest positive) / random x random changing every MFMA")
+            roofline["frac_of_sustained"] = achieved / sus["relu"]["tflops"] if sus["relu"]["tflops"] > 0 else None
+            roofline["frac_of_sustained_random_operands"] = achieved / sus["random"]["tflops"] if sus["random"]["tflops"] > 0 else None
         stage_ms = {"sample_mlp": st.ms_sample_mlp / frames, "compact": st.ms_compact / frames,
                     "shade_mlp": st.ms_shade_mlp / frames, "composite": st.ms_composite / frames}
         smp_launch = max(st.sample_launches, 1)

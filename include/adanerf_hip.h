@@ -419,6 +419,18 @@ int adanerf_composite(adanerf_ctx* ctx, const float* d_raw, const float* d_sampl
                       const int32_t* d_ray_offsets, const int32_t* d_ray_counts, int32_t n_rays,
                       float* d_rgb_out, void* d_rgba8_out);
 
+/* ---- measurement hook (bench.py's roofline) ---- */
+
+/* What dense 16-bit MFMA rate does the context's device sustain on live operands, and at which clock?  Runs register-only loops of
+ * v_mfma_f32_32x32x16_bf16 (f16 != 0: _f16) on every CU for about target_ms milliseconds -- two accumulator chains per wave, one wave
+ * per SIMD, the shading kernel's form -- and returns the achieved TFLOP/s and the effective shader clock (MHz, s_memtime against
+ * s_memrealtime).  operands: 0 all-zero bits, 1 constant small values, 2 random values that change with every MFMA, 3 as 2 with a
+ * post-ReLU-like B operand (half of its elements 0, the rest positive).  The part runs to a power budget: the same stream reaches
+ * ~2.4 GHz on zeros and ~1.7 GHz on random operands, so a kernel's fraction of the nominal 2.5 PFLOP/s and its fraction of what
+ * the silicon sustains on its kind of data differ (profiles/r04_mfma_peak_operands_clock.log).  Synchronous; nothing else should
+ * run on the device meanwhile. */
+int adanerf_probe_mfma(adanerf_ctx* ctx, int32_t operands, int32_t f16, float target_ms, float* tflops, float* clock_mhz);
+
 /* ---- device memory plumbing for callers without a HIP runtime of their own ---- */
 int adanerf_malloc(adanerf_ctx* ctx, size_t bytes, void** d_out);
 int adanerf_free(adanerf_ctx* ctx, void* d_ptr);
