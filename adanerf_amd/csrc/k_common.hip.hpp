@@ -252,6 +252,34 @@ __device__ __forceinline__ float wave_last_f32(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// The same forms for the integer exchanges of the selection / compaction kernels (segment totals, prefix sums of counts): since round 4
+// NO kernel of the library goes through ds_bpermute (__shfl*) any more -- tests/test_host_cpu.py greps for it.  profiles/r03_dense_shard_flake.md
+// is still without a root cause; staying in the VALU removes the only instruction the failing kernel had that its fixed form has not.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i32(int old, int v) {      // lanes without a source (or outside ROW_MASK) keep `old`
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+// sum over the wave, every lane gets it
+__device__ __forceinline__ int wave_sum_dpp_i32(int v) {
+  v += dpp_i32<0xB1>(0, v);        // quad_perm [1,0,3,2]
+  v += dpp_i32<0x4E>(0, v);        // quad_perm [2,3,0,1]
+  v += dpp_i32<0x141>(0, v);       // row_half_mirror
+  v += dpp_i32<0x140>(0, v);       // row_mirror
+  return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+// inclusive prefix sum over the wave (lane i: lanes 0..i); SEG = 32: two independent scans over lanes 0..31 and 32..63
+template <int SEG = 64>
+__device__ __forceinline__ int wave_incl_sum_dpp_i32(int v) {
+  static_assert(SEG == 32 || SEG == 64, "segment = half a wave or the wave");
+  v += dpp_i32<0x111>(0, v);       // row_shr:1
+  v += dpp_i32<0x112>(0, v);       // row_shr:2
+  v += dpp_i32<0x114>(0, v);       // row_shr:4
+  v += dpp_i32<0x118>(0, v);       // row_shr:8
+  v += dpp_i32<0x142, 0xA>(0, v);  // row_bcast:15 into rows 1 and 3
+  if (SEG == 64) v += dpp_i32<0x143, 0xC>(0, v);      // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 __device__ __forceinline__ float sigmoidf_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ int mbcnt64(uint64_t mask) {

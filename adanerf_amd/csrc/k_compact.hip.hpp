@@ -318,17 +318,11 @@ __global__ __launch_bounds__(256) void expand_kernel(const int32_t* __restrict__
                                                      const int32_t* __restrict__ block_total, int n_blocks, int n_rays, int n_max,
                                                      int seg_shift, int32_t* __restrict__ ray_offsets, uint32_t* __restrict__ sample_key,
                                                      float* __restrict__ sample_w, int32_t* __restrict__ total) {
-  const int seg_rays = 1 << seg_shift;                         // 32 or 64: one segment per wave or less
   const int segs = 256 >> seg_shift;                           // segments covered by this workgroup
   const int t = static_cast<int>(threadIdx.x);
   const int r = blockIdx.x * 256 + t;
   const int c = (r < n_rays) ? counts[r] : 0;
-  const int seg_lane = r & (seg_rays - 1);
-  int x = c;
-  for (int off = 1; off < seg_rays; off <<= 1) {
-    const int y = __shfl_up(x, off, seg_rays);
-    if (seg_lane >= off) x += y;
-  }
+  const int x = seg_shift == 5 ? wave_incl_sum_dpp_i32<32>(c) : wave_incl_sum_dpp_i32<64>(c);      // inclusive prefix inside the segment (DPP, no LDS crossbar)
   const int seg = r >> seg_shift;                              // segment of this ray
   int seg_base;
   if (INLINE_SCAN) {
@@ -336,8 +330,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const int32_t* __restrict__
     const int b0 = blockIdx.x * segs;                          // first segment of this workgroup
     int s = 0;
     for (int i = t; i < b0; i += 256) s += block_total[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    s = wave_sum_dpp_i32(s);
     if ((t & 63) == 0) part[t >> 6] = s;
     __syncthreads();
     seg_base = part[0] + part[1] + part[2] + part[3];
@@ -382,19 +375,14 @@ __global__ __launch_bounds__(256) void refine_list_kernel(const uint32_t* __rest
            __popc(v.z | audit_bits(period, phase, 4 * i + 2)) + __popc(v.w | audit_bits(period, phase, 4 * i + 3));
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  s = wave_sum_dpp_i32(s);
   const int wi = b0 + t;
   const uint32_t und = wi < n_words ? mask[wi] : 0u;
   const int left = n_rays - wi * 32;                                       // rays this word covers (the last word may be partial)
   const uint32_t in_range = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? low_bits32(left) : 0u);
   const uint32_t m = (und | audit_bits(period, phase, wi)) & in_range;
   const int c = __popc(m);
-  int x = c;                                      // inclusive scan inside the wave
-  for (int off = 1; off < 64; off <<= 1) {
-    const int y = __shfl_up(x, off, 64);
-    if ((t & 63) >= off) x += y;
-  }
+  const int x = wave_incl_sum_dpp_i32<64>(c);       // inclusive scan inside the wave
   if ((t & 63) == 63) wtot[t >> 6] = x;
   if ((t & 63) == 0) part[t >> 6] = s;
   __syncthreads();

@@ -447,8 +447,7 @@ __device__ __forceinline__ void pair_epilogue(const float* x_raw, int lane, int 
   pair_emit(x, lo, hi, h, stage, valid, static_cast<size_t>(local) * so.n_max, so.selbin, so.selw);
   int t = (valid && h == 0) ? total : 0;
   if (valid && h == 0) so.counts[local] = total;
-#pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) t += __shfl_xor(t, off);      // lanes 0..31 hold the rays
+  t = wave_sum_dpp_i32(t);      // lanes 0..31 hold the rays, lanes 32..63 contribute 0
   if (so.guard_mask) {
     const bool u = (und | force_undecided) && valid;
     const uint64_t b = __ballot(u);      // lanes j and j + 32 agree; bits 0..31 = the rays

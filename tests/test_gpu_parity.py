@@ -897,6 +897,58 @@ def test_guard_band_widens_itself_after_a_violation(cases):
     assert np.array_equal(cnt_g, cnt_s) and np.array_equal(key_g, key_s)
 
 
+def test_guarded_frames_next_to_other_contexts(cases):
+    """The configuration `bench.py --gpus N --frames-in-flight 2` and the `adanerf --gpus N --same-device` host run: several contexts of
+    one device rendering adaptive frames in the guarded two-precision mode with their launches interleaved (two strip shards of the frame
+    plus an unsharded context).  Every frame of a context must reproduce that context's first frame in its RAW buffers -- sample counts,
+    offsets, compacted keys, kept oracle values, the shading network's raw outputs -- and in its image, whatever the neighbours are
+    doing and whichever rays the rotating audit looks at (profiles/r03_dense_shard_flake.md: the failure that motivated this was only
+    visible next to other contexts).  Integer exchanges of the selection / compaction kernels are DPP since round 4."""
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    w, h = 256, 192
+    ctxs = [adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", shard_rank=k, shard_world=2, strip_rows=8) for k in range(2)]
+    ctxs.append(adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16"))
+    try:
+        outs = []
+        for r in ctxs:
+            r.init()
+            r.set_camera(z["pose"], z["rot"])
+            outs.append((r.empty((r.info.rays_local, 4), np.uint8), r.empty((r.info.rays_local, 3), np.float32)))
+
+        def snapshot(r, o):
+            n = r.info.rays_local
+            cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (n,))
+            tot = int(r.buffer(R.BUF_TOTAL, np.int32, (1,))[0])
+            return (cnt, r.buffer(R.BUF_RAY_OFFSETS, np.int32, (n,)), r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (tot,)),
+                    r.buffer(R.BUF_SAMPLE_W, np.float32, (tot,)), r.buffer(R.BUF_RAW, np.float32, (tot, 4)), o[0].numpy(), o[1].numpy())
+
+        first, bad, frames = None, [], 48                  # three rotations of the audit
+        for f in range(frames):
+            for r, o in zip(ctxs, outs):                   # launches of the three contexts interleave on the device
+                r.render(o[0], o[1])
+            snaps = []
+            for r, o in zip(ctxs, outs):
+                r.sync()
+                snaps.append(snapshot(r, o))
+            if first is None:
+                first = snaps
+                continue
+            for k, (a, b) in enumerate(zip(first, snaps)):
+                for name, x, y in zip(("counts", "offsets", "keys", "kept values", "raw outputs", "rgba8", "rgb"), a, b):
+                    if not np.array_equal(x, y):
+                        bad.append((f, k, name, int((x != y).sum()) if x.shape == y.shape else -1))
+        sts = [r.render(o[0], o[1], stats=True) for r, o in zip(ctxs, outs)]
+    finally:
+        for r in ctxs:
+            r.close()
+    record("guarded_frames_next_to_other_contexts", frames=frames, contexts=len(ctxs), differing=bad[:8],
+           audited=[int(s.guard_audited) for s in sts], mismatches=[int(s.guard_audit_mismatch) for s in sts])
+    assert not bad, bad[:8]
+    assert all(s.guard_audit_mismatch == 0 and s.guard_violations == 0 and s.guard_audited > 0 for s in sts)
+    # the two shards together select what the unsharded context selects
+    assert int(first[0][0].sum()) + int(first[1][0].sum()) == int(first[2][0].sum())
+
+
 def test_dense_frames_next_to_other_contexts(cases):
     """Regression for profiles/r03_dense_shard_flake.md: three strip shards of a dense frame rendered by three contexts on this GPU,
     launches interleaved, 40 frames each -- every frame of a context must be the context's first frame (the one-wave-per-ray
