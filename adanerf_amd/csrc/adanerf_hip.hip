@@ -190,7 +190,7 @@ struct ModelSetup {
   bool coarse_fine = false;
   int n_coarse = 0;
   std::vector<float> ztab_coarse;
-  bool normalize0 = false;
+  int normalize0 = 0;      // kNorm* of the coarse pass
 };
 
 // slot layout of an encoding pair: the specialised kernels exist for 10-4 (both networks) and 2-2 (sampling network); any other
@@ -273,16 +273,27 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   const bool ndc = cf.useNDC;
   const bool no_range = !coarse_fine && contains(cf.rayMarchSampler[1], "NoDepthRange");
   if (!pdf_mode && !coarse_fine && ndc != no_range) return bad(ADANERF_EUNSUPPORTED, "useNDC requires the NoDepthRange sampler and vice versa");
-  std::string norm = cf.rayMarchNormalization.size() >= 2 ? cf.rayMarchNormalization[1] : std::string("None");
-  if (norm != "InverseSqrtDistCentered" && norm != "None")
-    return bad(ADANERF_EUNSUPPORTED, "rayMarchNormalization[1] must be InverseSqrtDistCentered or None");
+  // every function nerf_get_normalization_function knows (src/nerf_raymarch_common.py:195-244); a config WITHOUT the key gets
+  // normalization_max_depth (src/features.py:319-324)
+  auto norm_code = [](const std::string& n) {
+    return n == "None" ? kNormNone : n == "InverseSqrtDistCentered" ? kNormInverseSqrtDistCentered : n == "Centered" ? kNormCentered
+         : n == "MaxDepth" ? kNormMaxDepth : n == "MaxDepthCentered" ? kNormMaxDepthCentered : n == "LogCentered" ? kNormLogCentered
+         : n == "InverseDistCentered" ? kNormInverseDistCentered : -1;
+  };
+  const size_t norm_idx = 1;
+  if (!cf.rayMarchNormalization.empty() && cf.rayMarchNormalization.size() <= norm_idx)
+    return bad(ADANERF_EIO, "rayMarchNormalization needs one entry per network");
+  const std::string norm = cf.rayMarchNormalization.empty() ? std::string("MaxDepth") : cf.rayMarchNormalization[norm_idx];
+  if (norm_code(norm) < 0)
+    return bad(ADANERF_EUNSUPPORTED, "rayMarchNormalization[1] = " + norm + ": None, Centered, MaxDepth, MaxDepthCentered, LogCentered, InverseDistCentered or InverseSqrtDistCentered");
+  if (!cf.rayMarchNormalizationCenter.empty() && cf.rayMarchNormalizationCenter.size() != 3)
+    return bad(ADANERF_EIO, "rayMarchNormalizationCenter must hold three values (or none)");
   if (cf.depthTransform != "log" && cf.depthTransform != "linear")
     return bad(ADANERF_EUNSUPPORTED, "depthTransform must be log or linear");
   if (coarse_fine) {
-    const std::string norm0 = cf.rayMarchNormalization.empty() ? std::string("None") : cf.rayMarchNormalization[0];
-    if (norm0 != "InverseSqrtDistCentered" && norm0 != "None")
-      return bad(ADANERF_EUNSUPPORTED, "rayMarchNormalization[0] must be InverseSqrtDistCentered or None");
-    ms->normalize0 = norm0 == "InverseSqrtDistCentered";
+    const std::string norm0 = cf.rayMarchNormalization.empty() ? std::string("MaxDepth") : cf.rayMarchNormalization[0];
+    if (norm_code(norm0) < 0) return bad(ADANERF_EUNSUPPORTED, "rayMarchNormalization[0] = " + norm0 + " is not a normalisation the reference knows");
+    ms->normalize0 = norm_code(norm0);
   }
   if (cf.accumulationMult == "alpha") ms->mult_mode = 1;
   else if (cf.accumulationMult == "weights") ms->mult_mode = 2;
@@ -386,9 +397,11 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   I.max_depth = cf.max_depth;
 
   ShadeParams& sp = ms->sp;
-  for (int i = 0; i < 3; ++i) sp.center[i] = cf.viewcellCenter[i];
+  for (int i = 0; i < 3; ++i) sp.center[i] = cf.rayMarchNormalizationCenter.size() == 3 ? cf.rayMarchNormalizationCenter[i] : cf.viewcellCenter[i];
+  sp.max_depth = cf.max_depth;
   sp.sqrt_max_depth = static_cast<float>(std::sqrt(static_cast<double>(cf.max_depth)));   // math.sqrt(max_depth)
-  sp.normalize = norm == "InverseSqrtDistCentered";
+  sp.log_max_depth_p1 = static_cast<float>(std::log(static_cast<double>(cf.max_depth) + 1.0));      // math.log(max_v + 1)
+  sp.normalize = norm_code(norm);
   sp.unit_dir = ndc;
   sp.ztab = nullptr;
 
@@ -1210,7 +1223,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     if (opt->precision == ADANERF_PREC_FP32) p1 = std::move(probe);
     else if (!pack_shading_net(c->net1_host, sh, elem_of(opt->precision), &p1, &err)) return bail(ADANERF_EIO, "model1.onnx: " + err);
   }
-  // the run-time-shaped fp32 kernels are instantiated for these widths (k_generic_f32.hip.hpp)
+  // the run-time-shaped kernels are instantiated for these widths (k_generic_f32.hip.hpp); the packer pads any width <= 256 up to one of them
   auto width_ok = [](int w) { return w == 64 || w == 128 || w == 256; };
   if (c->genericc && !width_ok(c->topoc.width)) return bail(ADANERF_EUNSUPPORTED, "model0.onnx: layer width " + std::to_string(c->topoc.width) + " (64, 128 or 256 supported)");
   if (c->generic0 && !width_ok(c->topo0.width)) return bail(ADANERF_EUNSUPPORTED, "model0.onnx: layer width " + std::to_string(c->topo0.width) + " (64, 128 or 256 supported)");
@@ -1244,7 +1257,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     c->spc.normalize = ms.normalize0;
     c->sp.unit_dir = 0;      // the fine pass encodes rays_d as RayMarchFromPoses handed it over: un-normalised under NDC (src/features.py:654-668)
     c->spc.ztab = reinterpret_cast<const float*>(c->ztab_coarse.p);
-    c->genc = GenericTopo{c->topoc.depth, c->topoc.skip, 0, 0, nullptr, 0.f};
+    c->genc = GenericTopo{c->topoc.depth, c->topoc.cat_mask, 0, 0, nullptr, 0.f};
   } else {
     if ((rc = upload_net(c, p0, &c->net0))) return bail(rc, c->err);
     if ((!c->generic0 || c->ray_samples == 0) && (rc = upload_net(c, p0s, &c->net0_split))) return bail(rc, c->err);
@@ -1254,8 +1267,8 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
     if (hipMemcpy(c->rsi_z.p, ms.rsi_z.data(), ms.rsi_z.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
       return bail(ADANERF_EDEVICE, "raySampleInput depth table upload failed");
   }
-  c->gen0 = GenericTopo{c->topo0.depth, -1, c->ray_samples, p0.rsi_w_off, reinterpret_cast<const float*>(c->rsi_z.p), c->cfg.depthRange[1]};
-  c->gen1 = GenericTopo{c->topo1.depth, c->topo1.skip, 0, 0, nullptr, 0.f};
+  c->gen0 = GenericTopo{c->topo0.depth, 0, c->ray_samples, p0.rsi_w_off, reinterpret_cast<const float*>(c->rsi_z.p), c->cfg.depthRange[1]};
+  c->gen1 = GenericTopo{c->topo1.depth, c->topo1.cat_mask, 0, 0, nullptr, 0.f};
   if ((rc = dev_alloc(c, &c->overflow, 64))) return bail(rc, c->err);
   if (hipMemset(c->overflow.p, 0, 64) != hipSuccess) return bail(ADANERF_EDEVICE, "hipMemset failed");
   if ((rc = upload_net(c, p1, &c->net1[opt->precision]))) return bail(rc, c->err);

@@ -88,6 +88,7 @@ void Config::store(std::string key, std::string value) {
   else if (key == "outFeatures") outFeatures = L;
   else if (key == "rayMarchSampler") rayMarchSampler = L;
   else if (key == "rayMarchNormalization") rayMarchNormalization = L;
+  else if (key == "rayMarchNormalizationCenter") rayMarchNormalizationCenter = to_floats(L);
   else if (key == "activation") activation = L;
   else if (key == "losses") losses = L;
   else if (key == "numRaymarchSamples") numRaymarchSamples = to_ints(L);

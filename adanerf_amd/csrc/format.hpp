@@ -26,6 +26,7 @@ struct Config {
   std::vector<std::string> rayMarchSampler, rayMarchNormalization, activation;
   std::vector<std::string> losses;   // training config key; only losses[0] matters (oracle output transform)
   std::vector<float> rayMarchSamplingStep, rayMarchSamplingNoise;
+  std::vector<float> rayMarchNormalizationCenter;   // training config key (src/features.py:317, 460-467): three floats replace view_cell_center in the normalisation
   std::vector<int> raySampleInput, multiDepthFeatures;
   std::string depthTransform = "linear";
   std::vector<float> zNear, zFar;

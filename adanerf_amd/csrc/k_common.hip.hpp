@@ -42,12 +42,17 @@ struct RayGenParams {
   float ndc_sw, ndc_sh;                // -1/(W/(2 focal)), -1/(H/(2 focal))
 };
 
+// rayMarchNormalization (src/nerf_raymarch_common.py:195-244)
+enum { kNormNone = 0, kNormInverseSqrtDistCentered = 1, kNormCentered = 2, kNormMaxDepth = 3, kNormMaxDepthCentered = 4, kNormLogCentered = 5,
+       kNormInverseDistCentered = 6 };
+
 struct ShadeParams {
-  float center[3];
-  float inv_sqrt_max_depth_unused;
+  float center[3];                     // view_cell_center, or rayMarchNormalizationCenter when the config sets three values
+  float max_depth;
   float sqrt_max_depth;
-  int32_t normalize;                   // 1: InverseSqrtDistCentered, 0: None
+  int32_t normalize;                   // kNorm*
   int32_t unit_dir;                    // 1: PE(dir/|dir|) (NDC), 0: PE(dir) as received
+  float log_max_depth_p1;              // math.log(max_depth + 1): kNormLogCentered
   const float* ztab;                   // [128] world depth per bin
 };
 
@@ -172,14 +177,45 @@ __device__ __forceinline__ void pe_eval(const float x[3], int h, float* out) {
 __device__ __forceinline__ void sample_position(const ShadeParams& sp, const float o[3], const float d[3], float z, float x[3]) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) x[i] = __fadd_rn(o[i], __fmul_rn(d[i], z));
-  if (sp.normalize) {
-    float l[3] = {x[0] - sp.center[0], x[1] - sp.center[1], x[2] - sp.center[2]};
-    float n2 = __fadd_rn(__fadd_rn(__fmul_rn(l[0], l[0]), __fmul_rn(l[1], l[1])), __fmul_rn(l[2], l[2]));
-    float local = sqrtf(sqrtf(n2));
-    float den = __fmul_rn(sp.sqrt_max_depth, local);
-    x[0] = l[0] / den;
-    x[1] = l[1] / den;
-    x[2] = l[2] / den;
+  if (sp.normalize == kNormNone) return;
+  if (sp.normalize == kNormMaxDepth) {      // x / max_depth: also what a config WITHOUT the key gets (src/features.py:319-324)
+    x[0] = x[0] / sp.max_depth;
+    x[1] = x[1] / sp.max_depth;
+    x[2] = x[2] / sp.max_depth;
+    return;
+  }
+  const float l[3] = {x[0] - sp.center[0], x[1] - sp.center[1], x[2] - sp.center[2]};
+  if (sp.normalize == kNormCentered) {
+    x[0] = l[0];
+    x[1] = l[1];
+    x[2] = l[2];
+  } else if (sp.normalize == kNormMaxDepthCentered) {
+    x[0] = l[0] / sp.max_depth;
+    x[1] = l[1] / sp.max_depth;
+    x[2] = l[2] / sp.max_depth;
+  } else {
+    const float n2 = __fadd_rn(__fadd_rn(__fmul_rn(l[0], l[0]), __fmul_rn(l[1], l[1])), __fmul_rn(l[2], l[2]));
+    if (sp.normalize == kNormInverseSqrtDistCentered) {
+      const float local = sqrtf(sqrtf(n2));
+      const float den = __fmul_rn(sp.sqrt_max_depth, local);
+      x[0] = l[0] / den;
+      x[1] = l[1] / den;
+      x[2] = l[2] / den;
+    } else if (sp.normalize == kNormInverseDistCentered) {      // localized * (1 - 1 / (1 + |localized|))
+      const float local = sqrtf(n2);
+      const float f = __fsub_rn(1.0f, 1.0f / __fadd_rn(1.0f, local));
+      x[0] = __fmul_rn(l[0], f);
+      x[1] = __fmul_rn(l[1], f);
+      x[2] = __fmul_rn(l[2], f);
+    } else {      // kNormLogCentered: localized * (log(local + 1) / log(max_depth + 1) / local), local <= 0 -> 0.001 (LogTransform.from_world
+                  // clamps in place, util/depth_transformations.py:21-27, so the divisor sees the clamped value too)
+      float local = sqrtf(n2);
+      local = local <= 0.f ? 0.001f : local;
+      const float f = (logf(__fadd_rn(local, 1.0f)) / sp.log_max_depth_p1) / local;
+      x[0] = __fmul_rn(l[0], f);
+      x[1] = __fmul_rn(l[1], f);
+      x[2] = __fmul_rn(l[2], f);
+    }
   }
 }
 

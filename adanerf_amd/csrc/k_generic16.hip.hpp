@@ -1,5 +1,5 @@
 // SURVEY 8f N4, second half: both networks in any exportable topology (sampling net of 2..8 layers, NeRF trunk of 1..8 layers, width
-// 64 / 128 / 256, one skip or none, src/models.py:18-82, 199-277) and any encoding layout on the 16-bit MFMA pipe.
+// 64 / 128 / 256, skips at any layers or none, src/models.py:18-82, 199-277) and any encoding layout on the 16-bit MFMA pipe.
 // The specialised 8 x 256 kernels stage one fragment stream through an LDS ring whose chunk positions are compile-time
 // constants of that topology.  Here the layer table is a run-time argument: a run-time loop over the hidden layers with the layer's
 // tiles and k-steps unrolled, and the weights staged per output tile through two LDS buffers shared by the workgroup (TileStage below;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void shade_mlp16_gen_kernel(ShadeArgs a, Ge
 #pragma unroll 1
     for (int l = 1; l < t.depth; ++l) {
       asm volatile("" : "+v"(w), "+v"(b));
-      if (l == t.skip + 1) layer_16_direct<ET, QP / 8, KW, MT, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, pts, hA, hB);      // cat([pts, h])
+      if ((t.cat_mask >> l) & 1) layer_16_direct<ET, QP / 8, KW, MT, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, pts, hA, hB);      // cat([pts, h])
       else layer_16_direct<ET, KW, 0, MT, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, hA, hA, hB);
 #pragma unroll
       for (int i = 0; i < W / 4; ++i) hA[i] = hB[i];
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
     uint32_t hA[NB * IA], hB[NB * IB];
     float dpe[NB][3];
     // k-steps (= KiB) of a tile of hidden layer l (1 <= l < depth), of the feature layer at l == depth
-    auto ks_of = [&](int l) { return (l < t.depth && l == t.skip + 1) ? QP / 8 + KW : KW; };
+    auto ks_of = [&](int l) { return (l < t.depth && ((t.cat_mask >> l) & 1)) ? QP / 8 + KW : KW; };
     {
       uint32_t pts[NB * IP];
 #pragma unroll
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
       const uint32_t nxt = a.net.w_off[l + 1];
       const float* nb_ = b + a.net.b_off[l + 1];
       const int nks = ks_of(l + 1);
-      if (l == t.skip + 1) {
+      if ((t.cat_mask >> l) & 1) {
         uint32_t pts[NB * IP];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)

@@ -1,5 +1,5 @@
 // the two networks in any topology the reference's model classes can export (BaseNet / NeRF,
-// src/models.py:18-82, 199-277: depth 2..8, width 64 / 128 / 256, one trunk skip at any layer or none) and the
+// src/models.py:18-82, 199-277: depth 2..8, width 64 / 128 / 256, trunk skips at any layers or none) and the
 // raySampleInput oracle input (src/features.py:876-888; viewer: updateSpherePosDirBatchedUnrolledEnc with additional
 // samples, adanerf_real_time_viewer/src/cuda/base_cuda_kernels.cu:99-145) -- on the exact-fp32 MFMA engine
 // (v_mfma_f32_32x32x2_f32, k_mlp_f32.hip.hpp) with a run-time loop over the hidden layers.  Every shipped config is
@@ -14,7 +14,7 @@ namespace adanerf {
 
 struct GenericTopo {
   int32_t depth;        // Linear layers of the trunk (sampling net: all layers)
-  int32_t skip;         // shading trunk: layer skip + 1 takes cat([pts, h]); -1 none
+  int32_t cat_mask;     // shading trunk: bit l set <=> layer l takes cat([pts, h]) (l - 1 in the reference's `skips`, src/models.py:226-228, 260-261); 0 none
   int32_t ray_samples;  // sampling net: raySampleInput
   uint32_t rsi_w_off;   // 16-byte offset of the raySampleInput fragments of layer 0, [a][s4][m][lane]
   const float* rsi_z;   // [ray_samples] world depth of every extra point
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void shade_mlp32_gen_kernel(ShadeArgs a, Gener
 #pragma unroll 1
     for (int l = 1; l < t.depth; ++l) {
       asm volatile("" : "+v"(w), "+v"(b));
-      if (l == t.skip + 1) layer_f32<QP, QW, MT, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, pts, hA, hB);      // cat([pts, h])
+      if ((t.cat_mask >> l) & 1) layer_f32<QP, QW, MT, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, pts, hA, hB);      // cat([pts, h])
       else layer_f32<QW, 0, MT, true>(w + a.net.w_off[l], b + a.net.b_off[l], lane, hA, hA, hB);
 #pragma unroll
       for (int i = 0; i < QW; ++i) hA[i] = hB[i];

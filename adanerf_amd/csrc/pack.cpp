@@ -111,13 +111,22 @@ void add_pe_slots(VLayer* L, int F, int col_base, int FL = 0) {
   }
 }
 
-void add_act_slots(VLayer* L, int n_features, int col_base) {
+// n_features: the (padded) width the kernels run; n_real: the network's own width -- features beyond it are padding (zero column)
+void add_act_slots(VLayer* L, int n_features, int col_base, int n_real = -1) {
+  if (n_real < 0) n_real = n_features;
   int n = n_features / 2;   // slots per lane-half
   for (int q = 0; q < n; ++q) {
-    L->col_h0.push_back(col_base + act_feature(q, 0));
-    L->col_h1.push_back(col_base + act_feature(q, 1));
+    const int f0 = act_feature(q, 0), f1 = act_feature(q, 1);
+    L->col_h0.push_back(f0 < n_real ? col_base + f0 : -1);
+    L->col_h1.push_back(f1 < n_real ? col_base + f1 : -1);
   }
 }
+
+// The kernels are instantiated for hidden widths 64 / 128 / 256.  A network of any other width W <= 256 (the reference's layerWidth is
+// free, src/models.py:18-82, 199-250) runs as the next of those with zero rows / zero bias appended to every hidden layer: a padded unit
+// is relu(0) = 0 (the feature layer has no activation: 0 as well) and feeds zero columns -- the results are those of the W-wide network
+// bit for bit in fp32, and to the engine's usual accuracy in 16 bits (the extra products are exact zeros).
+int pad_width(int w) { return w <= 64 ? 64 : (w <= 128 ? 128 : (w <= 256 ? 256 : 0)); }
 
 void emit(const VLayer& L, Elem elem, PackedNet* out) {
   const int G = (elem == Elem::F32) ? 4 : 8;          // slots per 16-byte fragment element group
@@ -209,9 +218,11 @@ bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, Pac
   NetTopology& T = out->topo;
   T.depth = count_layers(net0, "layers.");
   if (T.depth < 2 || T.depth > kMaxDepth) return fail(err, "sampling net: " + std::to_string(T.depth) + " layers (2.." + std::to_string(kMaxDepth) + " supported)");
-  T.width = find(net0, "layers.0.weight", err)->rows();     // exists: depth >= 2
+  const int Wr = find(net0, "layers.0.weight", err)->rows();     // exists: depth >= 2.  The network's own width ...
+  T.width = pad_width(Wr);                                       // ... and the width it runs at
+  T.real_width = Wr;
   T.ray_samples = sh.ray_samples;
-  if (T.width % 32 != 0 || T.width < 32 || T.width > 512) return fail(err, "sampling net: width " + std::to_string(T.width) + " (multiples of 32 up to 512 supported)");
+  if (Wr < 1 || T.width == 0) return fail(err, "sampling net: width " + std::to_string(Wr) + " (1 .. 256 supported)");
   // plain 16-bit fragments: the ring-streamed kernel of the 8 x 256 / 10-4 or 2-2 net only; the (hi, lo') split pairs pack for any
   // topology and layout without raySampleInput (k_generic16.hip.hpp); raySampleInput is fp32 only (K-major block, emit_ray_samples)
   const bool special = T.is_default(false) && !sh.lp0 && !sh.ld0;
@@ -222,20 +233,20 @@ bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, Pac
     const Tensor* W = find(net0, "layers." + std::to_string(i) + ".weight", err);
     const Tensor* B = find(net0, "layers." + std::to_string(i) + ".bias", err);
     if (!W || !B) return false;
-    const int n_out = (i == T.depth - 1) ? kBins : T.width;
-    const int k = (i == 0) ? n_in : T.width;      // BaseNet skip specs (src/models.py:44-66) are not used by any config: plain chain
+    const int n_out = (i == T.depth - 1) ? kBins : Wr;
+    const int k = (i == 0) ? n_in : Wr;           // BaseNet skip specs (src/models.py:44-66) are not used by any config: plain chain
     if (W->rows() != n_out) {
       if (err) *err = "layers." + std::to_string(i) + ".weight: expected " + std::to_string(n_out) + " rows";
       return false;
     }
     VLayer L;
-    init_layer(&L, n_out, k);
+    init_layer(&L, (i == T.depth - 1) ? kBins : T.width, k);      // hidden layers: rows padded to the width the kernels run
     if (!set_rows(&L, 0, W, B, k, err, "layers." + std::to_string(i))) return false;
     if (i == 0) {
       add_pe_slots(&L, sh.fd0, 0, sh.ld0);        // [dir PE | pos PE]  (src/features.py:868-874)
       add_pe_slots(&L, sh.fp0, n_dir, sh.lp0);
     } else {
-      add_act_slots(&L, T.width, 0);
+      add_act_slots(&L, T.width, 0, Wr);
     }
     emit(L, elem, out);
     if (i == 0 && sh.ray_samples > 0) emit_ray_samples(L, sh.ray_samples, sh.fp0, n_dir + n_pos, out, sh.lp0);
@@ -250,16 +261,18 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
   NetTopology& T = out->topo;
   T.depth = count_layers(net1, "pts_linears.");
   if (T.depth < 1 || T.depth > kMaxDepth) return fail(err, "shading net: " + std::to_string(T.depth) + " trunk layers (1.." + std::to_string(kMaxDepth) + " supported)");
-  T.width = find(net1, "pts_linears.0.weight", err)->rows();   // exists: depth >= 1
-  if (T.width % 64 != 0 || T.width < 64 || T.width > 512) return fail(err, "shading net: width " + std::to_string(T.width) + " (multiples of 64 up to 512 supported)");
-  const int Wd = T.width;
+  const int Wr = find(net1, "pts_linears.0.weight", err)->rows();   // exists: depth >= 1.  The network's own width W ...
+  T.width = pad_width(Wr);                                          // ... and the width it runs at (pad_width)
+  T.real_width = Wr;
+  if (Wr < 2 || T.width == 0) return fail(err, "shading net: width " + std::to_string(Wr) + " (2 .. 256 supported)");
+  const int Wd = T.width, Wh = Wr / 2;      // views_linears.0 has W // 2 rows (src/models.py:236)
   T.skip = -1;
   for (int i = 1; i < T.depth; ++i) {
     const Tensor* W = find(net1, "pts_linears." + std::to_string(i) + ".weight", err);
     if (!W) return false;
-    if (W->cols() == Wd + n_pos) {          // cat([input_pts, h]) in front of layer i  <=>  i - 1 in skips (src/models.py:226-228)
-      if (T.skip >= 0) return fail(err, "shading net: more than one skip connection");
-      T.skip = i - 1;
+    if (W->cols() == Wr + n_pos) {          // cat([input_pts, h]) in front of layer i  <=>  i - 1 in skips (src/models.py:226-228)
+      if (T.skip < 0) T.skip = i - 1;
+      T.cat_mask |= 1 << i;
     }
   }
   for (int i = 0; i < T.depth; ++i) {
@@ -267,9 +280,10 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
     const Tensor* W = find(net1, nm + ".weight", err);
     const Tensor* B = find(net1, nm + ".bias", err);
     if (!W || !B) return false;
-    const int k = (i == 0) ? n_pos : (i == T.skip + 1 ? n_pos + Wd : Wd);
-    if (W->rows() != Wd) {
-      if (err) *err = nm + ".weight: expected " + std::to_string(Wd) + " rows";
+    const bool cat = i > 0 && ((T.cat_mask >> i) & 1);
+    const int k = (i == 0) ? n_pos : (cat ? n_pos + Wr : Wr);
+    if (W->rows() != Wr) {
+      if (err) *err = nm + ".weight: expected " + std::to_string(Wr) + " rows";
       return false;
     }
     VLayer L;
@@ -277,11 +291,11 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
     if (!set_rows(&L, 0, W, B, k, err, nm)) return false;
     if (i == 0) {
       add_pe_slots(&L, sh.fp1, 0, sh.lp1);
-    } else if (i == T.skip + 1) {          // cat([input_pts, h])  (src/models.py:260-261)
+    } else if (cat) {                      // cat([input_pts, h])  (src/models.py:260-261)
       add_pe_slots(&L, sh.fp1, 0, sh.lp1);
-      add_act_slots(&L, Wd, n_pos);
+      add_act_slots(&L, Wd, n_pos, Wr);
     } else {
-      add_act_slots(&L, Wd, 0);
+      add_act_slots(&L, Wd, 0, Wr);
     }
     emit(L, elem, out);
   }
@@ -292,29 +306,29 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
     const Tensor* BA = find(net1, "alpha_linear.bias", err);
     if (!WF || !BF || !WA || !BA) return false;
     VLayer L;
-    init_layer(&L, Wd + 32, Wd);
-    if (!set_rows(&L, 0, WF, BF, Wd, err, "feature_linear")) return false;
-    if (WF->rows() != Wd || WA->rows() != 1) {
+    init_layer(&L, Wd + 32, Wr);
+    if (!set_rows(&L, 0, WF, BF, Wr, err, "feature_linear")) return false;
+    if (WF->rows() != Wr || WA->rows() != 1) {
       if (err) *err = "feature_linear/alpha_linear: unexpected row count";
       return false;
     }
-    if (!set_rows(&L, Wd, WA, BA, Wd, err, "alpha_linear")) return false;
-    add_act_slots(&L, Wd, 0);
+    if (!set_rows(&L, Wd, WA, BA, Wr, err, "alpha_linear")) return false;      // the alpha row sits behind the PADDED feature rows
+    add_act_slots(&L, Wd, 0, Wr);
     emit(L, elem, out);
   }
   {   // views_linears.0 on cat([feature, input_views])  (src/models.py:266-270)
     const Tensor* W = find(net1, "views_linears.0.weight", err);
     const Tensor* B = find(net1, "views_linears.0.bias", err);
     if (!W || !B) return false;
-    if (W->rows() != Wd / 2) {
-      if (err) *err = "views_linears.0.weight: expected " + std::to_string(Wd / 2) + " rows";
+    if (W->rows() != Wh) {
+      if (err) *err = "views_linears.0.weight: expected " + std::to_string(Wh) + " rows";
       return false;
     }
     VLayer L;
-    init_layer(&L, Wd / 2, Wd + n_dir);
-    if (!set_rows(&L, 0, W, B, Wd + n_dir, err, "views_linears.0")) return false;
-    add_act_slots(&L, Wd, 0);
-    add_pe_slots(&L, sh.fd1, Wd, sh.ld1);
+    init_layer(&L, Wd / 2, Wr + n_dir);
+    if (!set_rows(&L, 0, W, B, Wr + n_dir, err, "views_linears.0")) return false;
+    add_act_slots(&L, Wd, 0, Wr);
+    add_pe_slots(&L, sh.fd1, Wr, sh.ld1);
     emit(L, elem, out);
   }
   {   // rgb_linear W/2 -> 3 (tile 0 rows 0..2)
@@ -326,9 +340,9 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
       return false;
     }
     VLayer L;
-    init_layer(&L, 32, Wd / 2);
-    if (!set_rows(&L, 0, W, B, Wd / 2, err, "rgb_linear")) return false;
-    add_act_slots(&L, Wd / 2, 0);
+    init_layer(&L, 32, Wh);
+    if (!set_rows(&L, 0, W, B, Wh, err, "rgb_linear")) return false;
+    add_act_slots(&L, Wd / 2, 0, Wh);
     emit(L, elem, out);
   }
   return true;

@@ -17,10 +17,12 @@ constexpr float kSplitScale = 2048.0f;
 // src/models.py:18-82, 199-250; the viewer takes it from the ONNX graph as well, not from config.ini).
 struct NetTopology {
   int depth = 8;           // Linear layers of the trunk (sampling net: all of them)
-  int width = 256;         // hidden width W
-  int skip = -1;           // NeRF trunk: layer skip + 1 takes cat([input_pts, h]); -1 = none
+  int width = 256;         // hidden width the kernels run: 64 / 128 / 256 (the network's own width padded with zero units, pack.cpp pad_width)
+  int real_width = 256;    // the network's own hidden width W
+  int skip = -1;           // NeRF trunk: the first entry of the reference's `skips` (layer skip + 1 takes cat([input_pts, h])); -1 = none
+  int cat_mask = 0;        // ... all of them: bit l set <=> layer l takes cat([input_pts, h]) (one bit per skip: the NeRF class accepts a list)
   int ray_samples = 0;     // sampling net: raySampleInput points in layer 0's input
-  bool is_default(bool shading) const { return depth == 8 && width == 256 && ray_samples == 0 && skip == (shading ? 4 : -1); }
+  bool is_default(bool shading) const { return depth == 8 && width == 256 && ray_samples == 0 && cat_mask == (shading ? (1 << 5) : 0); }
 };
 constexpr int kMaxDepth = 8;    // w_off / b_off tables hold depth + 3 entries (kMaxLayers = 12)
 
@@ -52,13 +54,13 @@ struct NetShape {
 
 
 // layers.{0..D-1}.{weight,bias}: [dir PE | pos PE | raySampleInput points] -> W x (D-1) -> 128  (src/models.py:18-82,183-195).
-// Every shipped config is 8 x 256 without extra points; other depths / widths (W % 32 == 0, W <= 512, D in 2..8) and the
-// raySampleInput input pack for Elem::F32 only (the generic fp32-MFMA kernels): the 16-bit engines are specialised.
+// Every shipped config is 8 x 256 without extra points; other depths (2..8) / widths (any W <= 256, run zero-padded to 64 / 128 / 256) pack
+// for Elem::F32 and as split pairs; the raySampleInput input for Elem::F32 only (the generic fp32-MFMA kernels).
 bool pack_sampling_net(const TensorMap& net0, const NetShape& shape, Elem elem, PackedNet* out, std::string* err);
 
 // pts_linears.{0..D-1}, feature_linear(+alpha_linear as row W), views_linears.0, rgb_linear
-// (src/models.py:199-277).  Layer order in the blob: 0..D-1, feature+alpha, views, rgb.  Any topology (W % 64 == 0, W <= 512,
-// D in 1..8, one skip or none) and encoding layout packs for every element type (16-bit: k_generic16.hip.hpp).
+// (src/models.py:199-277).  Layer order in the blob: 0..D-1, feature+alpha, views, rgb.  Any topology (any W <= 256, run zero-padded to
+// 64 / 128 / 256; D in 1..8, skips anywhere) and encoding layout packs for every element type (16-bit: k_generic16.hip.hpp).
 bool pack_shading_net(const TensorMap& net1, const NetShape& shape, Elem elem, PackedNet* out, std::string* err);
 
 uint16_t f32_to_bf16(float f);

@@ -75,7 +75,8 @@ class Scene:
     use_ndc: bool = False
     depth_transform: str = "log"            # "log" | "linear"
     pos_enc: Tuple[Tuple[int, int], Tuple[int, int]] = ((10, 4), (10, 4))
-    normalization: str = "InverseSqrtDistCentered"   # rayMarchNormalization[1]
+    normalization: str = "InverseSqrtDistCentered"   # rayMarchNormalization[1]; "" = the config has no such key (-> MaxDepth, src/features.py:319-324)
+    normalization_center: Tuple[float, ...] = ()      # rayMarchNormalizationCenter: three values replace view_cell_center (src/features.py:460-467)
     accumulation_mult: str = "alpha"
     # "FromClassifiedDepthAdaptive" (AdaNeRF) or "FromClassifiedDepth" (DONeRF inverse-CDF sampling)
     sampler: str = "FromClassifiedDepthAdaptive"
@@ -118,7 +119,7 @@ def load_scene(model_dir: str, num_samples: Optional[int] = None,
         else:
             a, b = item.split("-")
             enc.append((int(a), int(b)))
-    norm = _parse_list(kv.get("rayMarchNormalization", "[None,None]"))
+    norm = _parse_list(kv.get("rayMarchNormalization", "[]"))
     sc = Scene(
         view_cell_center=tuple(fl("view_cell_center")),
         view_cell_size=tuple(fl("view_cell_size")),
@@ -132,7 +133,8 @@ def load_scene(model_dir: str, num_samples: Optional[int] = None,
         use_ndc=kv.get("useNDC", "False") == "True",
         depth_transform=kv.get("depthTransform", "linear"),
         pos_enc=(enc[0], enc[1]),
-        normalization=norm[-1] if norm else "None",
+        normalization=norm[-1] if norm else "",
+        normalization_center=tuple(float(x) for x in _parse_list(kv.get("rayMarchNormalizationCenter", "[]"))),
         accumulation_mult=kv.get("accumulationMult", ""),
     )
     smp = _parse_list(kv.get("rayMarchSampler", "[none,FromClassifiedDepthAdaptive]"))
@@ -311,7 +313,8 @@ def synthetic_weights(seed: int, n_in0: int = 90, n_in1_pos: int = 63, n_in1_dir
     n1: Dict[str, np.ndarray] = {}
     d1, w1 = layers[1], widths[1]
     for i in range(d1):
-        k = n_in1_pos if i == 0 else (w1 + n_in1_pos if i == skip1 + 1 else w1)
+        sk = tuple(skip1) if isinstance(skip1, (tuple, list)) else (skip1,)      # the NeRF class takes a list of skips (src/models.py:200, 226-228)
+        k = n_in1_pos if i == 0 else (w1 + n_in1_pos if (i - 1) in sk and i - 1 >= 0 else w1)
         w, b = lin(w1, k)
         n1["pts_linears.%d.weight" % i] = w
         n1["pts_linears.%d.bias" % i] = b
@@ -353,14 +356,18 @@ def write_model_dir(path: str, scene: Scene, weights: Weights) -> None:
             f.write("inFeatures = [RayMarchFromPoses, RayMarchFromCoarse]\n")
             f.write("outFeatures = [RGBARayMarch, RGBARayMarch]\n")
             f.write("rayMarchSampler = [LinearlySpacedZNearZFar, none]\n")
-            f.write("rayMarchNormalization = [%s, %s]\n" % (scene.normalization, scene.normalization))
+            if scene.normalization:
+                f.write("rayMarchNormalization = [%s, %s]\n" % (scene.normalization, scene.normalization))
             f.write("numRaymarchSamples = [%d, %d]\n" % (scene.num_samples_coarse, scene.num_samples))
         else:
             f.write("inFeatures = [SpherePosDir, RayMarchFromPoses]\n")
             f.write("outFeatures = [Raw, RGBARayMarch]\n")
             f.write("rayMarchSampler = [none, %s]\n" % sampler)
-            f.write("rayMarchNormalization = [InverseSqrtDistCentered, %s]\n" % scene.normalization)
+            if scene.normalization:
+                f.write("rayMarchNormalization = [InverseSqrtDistCentered, %s]\n" % scene.normalization)
             f.write("numRaymarchSamples = [%d, %d]\n" % (scene.num_samples, scene.num_samples))
+        if len(scene.normalization_center) == 3:
+            f.write("rayMarchNormalizationCenter = [%r, %r, %r]\n" % tuple(scene.normalization_center))
         f.write("rayMarchSamplingStep = [0.0078125, 0.0078125]\n")
         f.write("rayMarchSamplingNoise = [0.0, 0.0]\n")
         f.write("raySampleInput = [%d, 0]\n" % scene.ray_sample_input)
@@ -901,6 +908,35 @@ def ndc_rays(h: int, w: int, focal: float, near: float, rays_o: np.ndarray, rays
     return (np.stack([o0, o1, o2], -1).astype(F32), np.stack([d0, d1, d2], -1).astype(F32))
 
 
+def normalize_positions(x: np.ndarray, scene: Scene) -> np.ndarray:
+    """nerf_get_normalization_function(rayMarchNormalization[net])(x, centre, max_depth), src/nerf_raymarch_common.py:195-244; centre =
+    rayMarchNormalizationCenter when the config holds three values, else view_cell_center (src/features.py:460-467); a config
+    without the key (normalization == "") gets normalization_max_depth (src/features.py:319-324)."""
+    name = scene.normalization or "MaxDepth"
+    md = F32(scene.max_depth)
+    if name == "None":
+        return x
+    if name == "MaxDepth":
+        return (x / md).astype(F32)
+    c = np.array(scene.normalization_center if len(scene.normalization_center) == 3 else scene.view_cell_center, dtype=F32)
+    loc = (x - c).astype(F32)
+    if name == "Centered":
+        return loc
+    if name == "MaxDepthCentered":
+        return (loc / md).astype(F32)
+    n = np.sqrt(np.sum(loc * loc, -1, dtype=F32)).astype(F32)
+    if name == "InverseSqrtDistCentered":      # :226-230
+        local = np.sqrt(n).astype(F32)
+        return (loc / (F32(math.sqrt(scene.max_depth)) * local[:, None])).astype(F32)
+    if name == "InverseDistCentered":          # :219-223
+        return (loc * (F32(1.0) - F32(1.0) / (F32(1.0) + n))[:, None]).astype(F32)
+    if name == "LogCentered":                  # :211-216; LogTransform.from_world clamps its argument IN PLACE (util/depth_transformations.py:21-27)
+        n = np.where(n <= 0, F32(0.001), n).astype(F32)
+        lt = (np.log(n + F32(1.0), dtype=F32) / F32(math.log(scene.max_depth + 1.0))).astype(F32)
+        return (loc * (lt / n)[:, None]).astype(F32)
+    raise NotImplementedError(name)
+
+
 def shading_inputs(p: np.ndarray, nds: np.ndarray, sample_ray: np.ndarray, z: np.ndarray,
                    scene: Scene, w: int = 0, h: int = 0, unit_dir: bool = True) -> np.ndarray:
     """src/features.py:420-479: x = o + d*z; normalise; [PE_pos(x^) | PE_dir(dir)].
@@ -914,14 +950,7 @@ def shading_inputs(p: np.ndarray, nds: np.ndarray, sample_ray: np.ndarray, z: np
         # encodes it as it is (src/features.py:654-668): unit_dir = False
         dir_pe = (d / np.sqrt(np.sum(d * d, -1, keepdims=True, dtype=F32))).astype(F32) if unit_dir else d
     x = (o[sample_ray] + d[sample_ray] * z[:, None]).astype(F32)
-    if scene.normalization == "InverseSqrtDistCentered":
-        # src/nerf_raymarch_common.py:226-230
-        c = np.array(scene.view_cell_center, dtype=F32)
-        loc = (x - c).astype(F32)
-        local = np.sqrt(np.sqrt(np.sum(loc * loc, -1, dtype=F32))).astype(F32)
-        x = (loc / (F32(math.sqrt(scene.max_depth)) * local[:, None])).astype(F32)
-    elif scene.normalization != "None":
-        raise NotImplementedError(scene.normalization)
+    x = normalize_positions(x, scene)
     return np.concatenate([positional_encoding(x, fp),
                            positional_encoding(dir_pe[sample_ray], fd)], -1).astype(F32)
 

@@ -58,7 +58,7 @@ def make_config(scene: O.Scene, weights=None):
         d1, sk = O.shading_topology(weights.net1, 3 + 6 * scene.pos_enc[1][0])
         layers = [d0, d1]
         widths = [int(weights.net0["layers.0.weight"].shape[0]), int(weights.net1["pts_linears.0.weight"].shape[0])]
-        skips = ["", "auto" if (d1 == 8 and sk == [4]) else (str(sk[0]) if sk else "99")]
+        skips = ["", "auto" if (d1 == 8 and sk == [4]) else (str(sk[0]) if sk else "99")]      # (several skips: build_reference constructs the NeRF class itself)
     sampler = "FromClassifiedDepthAdaptiveNoDepthRange" if scene.use_ndc else "FromClassifiedDepthAdaptive"
     if scene.sampler == "FromClassifiedDepth":
         sampler = "FromClassifiedDepth"
@@ -71,8 +71,8 @@ def make_config(scene: O.Scene, weights=None):
         skips=skips, losses=[scene.losses0, "MSE"],
         numRaymarchSamples=[n, n], rayMarchSampler=["none", sampler],
         rayMarchSamplingStep=[1 / 128.0, 1 / 128.0], rayMarchSamplingNoise=[0.0, 0.0],
-        rayMarchNormalization=["InverseSqrtDistCentered", scene.normalization],
-        rayMarchNormalizationCenter=[], adaptiveSamplingThreshold=scene.threshold,
+        rayMarchNormalization=["InverseSqrtDistCentered", scene.normalization] if scene.normalization else [],
+        rayMarchNormalizationCenter=list(scene.normalization_center), adaptiveSamplingThreshold=scene.threshold,
         accumulationMult=scene.accumulation_mult if scene.sampler != "FromClassifiedDepth" else None, zNear=[scene.z_near, scene.z_near],
         zFar=[scene.z_far, scene.z_far], trainWithGTDepth=False, deterministicSampling=False,
         useNDC=scene.use_ndc, perturb=False, device="cpu", storeFullData=True,
@@ -105,6 +105,11 @@ def build_reference(R, scene: O.Scene, weights: O.Weights, w, h):
     n_in = [f.n_feat for f in f_in]
     m0 = R.models.ModelSelection.getModel(cfg, n_in[0], 128, "cpu", 0)
     m1 = R.models.ModelSelection.getModel(cfg, n_in[1], 4, "cpu", 1)
+    d1, sk = O.shading_topology(weights.net1, 3 + 6 * scene.pos_enc[1][0])
+    if len(sk) > 1:
+        # The NeRF class takes a LIST of skips (src/models.py:200, 226-228, 260-261); ModelSelection can only hand it one (it wraps
+        # config.skips[i] into a one-element list, src/models.py:370).  A network with several is built from the class directly.
+        m1 = R.models.NeRF(cfg.layers[1], cfg.layerWidth[1], n_in=n_in[1], n_out=4, skips=[str(x) for x in sk], use_viewdirs=True, net_idx=1, config=cfg)
     m0.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in weights.net0.items()})
     m1.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in weights.net1.items()})
     m0.eval()
@@ -215,6 +220,7 @@ def save_case(name, scene, meta, dirs, pose, rot, ref, n_max, weights_tag):
                   z_far=scene.z_far, use_ndc=scene.use_ndc, depth_transform=scene.depth_transform,
                   pos_enc=[list(scene.pos_enc[0]), list(scene.pos_enc[1])],
                   normalization=scene.normalization, accumulation_mult=scene.accumulation_mult,
+                  **({"normalization_center": list(scene.normalization_center)} if scene.normalization_center else {}),
                   sampler=scene.sampler, losses0=scene.losses0, ray_sample_input=scene.ray_sample_input, weights=weights_tag))
     n_f = min(64, ref["feat0"].shape[0], max(4, 65536 // ref["feat0"].shape[1]))
     m_f = min(64, ref["feat1"].shape[0])
@@ -564,7 +570,13 @@ def main():
     base = classroom_scene(8, 0.65)      # random-init outputs spread over [-0.8, 0.9]: ~6 of 128 clear 0.65
     for name, syn, rsi in [("syn_6x128_skip2", dict(seed=21, layers=[6, 6], widths=[128, 128], skip1=2, oracle_bias=0.1, oracle_scale=0.3), 0),
                            ("syn_d2w128_d3w256_skip1", dict(seed=22, layers=[2, 3], widths=[128, 256], skip1=1, oracle_bias=0.1, oracle_scale=0.3), 0),
-                           ("syn_rsi128_4x128", dict(seed=23, layers=[4, 8], widths=[128, 256], skip1=4, oracle_bias=0.1, oracle_scale=0.3), 128)]:
+                           ("syn_rsi128_4x128", dict(seed=23, layers=[4, 8], widths=[128, 256], skip1=4, oracle_bias=0.1, oracle_scale=0.3), 128),
+                           # widths the kernels have no instantiation for: run zero-padded to 128 / 256 and to 64 / 128 (pack.cpp pad_width);
+                           # 70 // 2 = 35 rows in views_linears.0
+                           ("syn_w96_w160_skip2", dict(seed=24, layers=[5, 6], widths=[96, 160], skip1=2, oracle_bias=0.1, oracle_scale=0.3), 0),
+                           ("syn_w40_w70_skip1", dict(seed=25, layers=[3, 4], widths=[40, 70], skip1=1, oracle_bias=0.1, oracle_scale=0.3), 0),
+                           # two skip connections in the NeRF trunk (layers 2 and 5 take cat([pts, h]))
+                           ("syn_7x128_skips_1_4", dict(seed=26, layers=[4, 7], widths=[128, 128], skip1=[1, 4], oracle_bias=0.1, oracle_scale=0.3), 0)]:
         sc = dataclasses.replace(base, ray_sample_input=rsi)
         wts = O.synthetic_weights(syn["seed"], n_in0=sc.n_in0, oracle_bias=syn["oracle_bias"], oracle_scale=syn["oracle_scale"],
                                   layers=tuple(syn["layers"]), widths=tuple(syn["widths"]), skip1=syn["skip1"])
@@ -586,6 +598,21 @@ def main():
         ref = run_reference(R, tc, dirs, pose, rot)
         save_case(name, sc, dict(w=400, h=400, crop=[12, 20, 24, 16, 16], yaw=100.0, pitch=0.0, syn=dict(syn, n_in0=sc.n_in0)),
                   dirs, pose, rot, ref, 8, "synthetic")
+
+    # --- cases V1..V8 (SURVEY 8f N4 residuals): every rayMarchNormalization the reference knows
+    #     (nerf_get_normalization_function, src/nerf_raymarch_common.py:233-244) on the shading network's sample positions, a custom
+    #     centre (rayMarchNormalizationCenter, src/features.py:460-467) and a config WITHOUT the key (-> MaxDepth, src/features.py:319-324);
+    #     shipped classroom weights (trained for InverseSqrtDistCentered: other normalisations give it other inputs, which is all that matters here)
+    for name, norm, centre in [("classroom_norm_none", "None", ()), ("classroom_norm_centered", "Centered", ()),
+                               ("classroom_norm_maxdepth", "MaxDepth", ()), ("classroom_norm_maxdepthcentered", "MaxDepthCentered", ()),
+                               ("classroom_norm_logcentered", "LogCentered", ()), ("classroom_norm_inversedistcentered", "InverseDistCentered", ()),
+                               ("classroom_norm_isd_custom_centre", "InverseSqrtDistCentered", (0.5, -2.9, 1.2)),
+                               ("classroom_norm_key_absent", "", ())]:
+        sc = dataclasses.replace(classroom_scene(8, 0.2), normalization=norm, normalization_center=centre)
+        dirs = subset_dirs(800, 800, sc.fov, 30, 44, 24, 16, 32)
+        tc = build_reference(R, sc, w_class, 800, 800)
+        ref = run_reference(R, tc, dirs, pose, rot)
+        save_case(name, sc, dict(w=800, h=800, crop=[30, 44, 24, 16, 32], yaw=100.0, pitch=0.0), dirs, pose, rot, ref, 8, "sample_pavillon_16")
 
     # --- cases O, P: small crops that carry the secondary compositing outputs (all cases written from now on do)
     sc = classroom_scene(8, 0.2)

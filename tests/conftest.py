@@ -25,7 +25,8 @@ def load_case(name):
                  num_samples=meta["num_samples"], threshold=meta["threshold"], z_near=meta["z_near"],
                  z_far=meta["z_far"], use_ndc=meta["use_ndc"], depth_transform=meta["depth_transform"],
                  pos_enc=(tuple(meta["pos_enc"][0]), tuple(meta["pos_enc"][1])),
-                 normalization=meta["normalization"], accumulation_mult=meta["accumulation_mult"],
+                 normalization=meta["normalization"], normalization_center=tuple(meta.get("normalization_center", ())),
+                 accumulation_mult=meta["accumulation_mult"],
                  sampler=meta.get("sampler", "FromClassifiedDepthAdaptive"),
                  losses0=meta.get("losses0", "NeRFWeightMultiplicationLoss"), ray_sample_input=meta.get("ray_sample_input", 0),
                  num_samples_coarse=meta.get("num_samples_coarse", 0))
@@ -46,7 +47,7 @@ def case_weights(meta):
         return O.synthetic_weights(s["seed"], n_in0=s.get("n_in0", 90), n_in1_pos=3 + 6 * meta["pos_enc"][1][0],
                                    n_in1_dir=3 + 6 * meta["pos_enc"][1][1], oracle_bias=s["oracle_bias"],
                                    oracle_scale=s["oracle_scale"], alpha_bias=s.get("alpha_bias", 0.0),
-                                   layers=tuple(s.get("layers", (8, 8))), widths=tuple(s.get("widths", (256, 256))), skip1=s.get("skip1", 4))
+                                   layers=tuple(s.get("layers", (8, 8))), widths=tuple(s.get("widths", (256, 256))), skip1=s.get("skip1", 4))      # skip1: an index or a list of them
     z = np.load(os.path.join(GOLD, "weights_%s.npz" % tag))
     n0 = {k[3:]: z[k] for k in z.files if k.startswith("n0/")}
     n1 = {k[3:]: z[k] for k in z.files if k.startswith("n1/")}
@@ -90,8 +91,11 @@ TRANSFORM_CASES = ["classroom_n8_bce_thr06", "classroom_n8_ce_thr0012"]
 PDF_CASES = ["classroom_pdf_n8", "ndc_pdf_n8", "classroom_pdf_ce_n8"]
 # fixtures that also carry the secondary compositing outputs (NeRFOutputDepth, accumulated opacity)
 # topologies other than 8 x 256 / skip 4, and the raySampleInput oracle input
-TOPOLOGY_CASES = ["syn_6x128_skip2", "syn_d2w128_d3w256_skip1", "syn_rsi128_4x128"]
+TOPOLOGY_CASES = ["syn_6x128_skip2", "syn_d2w128_d3w256_skip1", "syn_rsi128_4x128", "syn_w96_w160_skip2", "syn_w40_w70_skip1", "syn_7x128_skips_1_4"]
 # positional encodings other than 10-4 / 2-2 (any posEncArgs up to 16 bands)
 ENCODING_CASES = ["syn_enc_6-3_12-2", "syn_enc_16-1_1-16"]
+# SURVEY 8f N4 residuals: every rayMarchNormalization the reference knows, a custom centre, and a config without the key
+NORM_CASES = ["classroom_norm_none", "classroom_norm_centered", "classroom_norm_maxdepth", "classroom_norm_maxdepthcentered",
+              "classroom_norm_logcentered", "classroom_norm_inversedistcentered", "classroom_norm_isd_custom_centre", "classroom_norm_key_absent"]
 COARSE_FINE_CASES = ["classroom_coarse_fine_16_24", "ndc_coarse_fine_12_20"]      # vanilla NeRF, hierarchical sampling
 AUX_CASES = ["classroom_n8_aux", "ndc_n8_aux", "classroom_n8_mult_weights", "classroom_n8_bce_thr06", "ndc_pdf_n8", "classroom_pdf_ce_n8"]

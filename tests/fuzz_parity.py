@@ -146,7 +146,11 @@ def one_case(rng, idx):
         sc = dataclasses.replace(sc, ray_sample_input=rsi)
         layers = (int(rng.integers(2, 9)), int(rng.integers(2, 9))) if kind == "topo" or rng.random() < 0.5 else (8, 8)
         widths = (int(rng.choice([64, 128, 256])), int(rng.choice([64, 128, 256]))) if kind == "topo" or rng.random() < 0.5 else (256, 256)
+        if kind == "topo" and rng.random() < 0.4:      # any width <= 256: runs zero-padded to the next kernel width (pack.cpp pad_width)
+            widths = (int(rng.integers(4, 257)), int(rng.integers(4, 257)))
         skip1 = int(rng.integers(-1, layers[1] - 1)) if layers[1] > 2 else -1
+        if kind == "topo" and layers[1] > 3 and rng.random() < 0.3:      # several skips (the NeRF class takes a list)
+            skip1 = sorted(int(v) for v in rng.choice(layers[1] - 1, size=2, replace=False))
         if kind == "rsi" and layers == (8, 8) and widths == (256, 256):
             skip1 = 4
         wts = O.synthetic_weights(int(rng.integers(1 << 30)), n_in0=sc.n_in0, oracle_bias=float(rng.uniform(-0.3, 0.5)),

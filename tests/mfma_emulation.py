@@ -206,7 +206,8 @@ def run_shading_net_generic(net: PackedNet, x, dpe, depth, width, skip, fp=10, f
     pts, dirs = pe_eval(x, fp), pe_eval(dpe, fd)
     h = net.layer(0, pts, True)
     for l in range(1, depth):
-        h = net.layer(l, np.concatenate([pts, h], axis=1) if l == skip + 1 else h, True)
+        cat = (l - 1) in skip if isinstance(skip, (list, tuple)) else l == skip + 1      # one skip index or the list of them
+        h = net.layer(l, np.concatenate([pts, h], axis=1) if cat else h, True)
     f = net.layer(depth, h, False)                                # feature (+ alpha tile)
     alpha = f[0, width // 2]
     v = net.layer(depth + 1, np.concatenate([f[:, :width // 2], dirs], axis=1), True)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import adanerf_oracle as O
-from conftest import AUX_CASES, COARSE_FINE_CASES, ENCODING_CASES, MULT_CASES, ROOT, TOPOLOGY_CASES, case_weights, check_identical, load_case, record, residual_budget
+from conftest import AUX_CASES, COARSE_FINE_CASES, ENCODING_CASES, MULT_CASES, NORM_CASES, ROOT, TOPOLOGY_CASES, case_weights, check_identical, load_case, record, residual_budget
 
 import adanerf_amd
 from adanerf_amd import renderer as R
@@ -491,6 +491,50 @@ def test_context_lifecycle_returns_all_device_memory(tmp_path_factory):
     for _ in range(6):
         cycle()
     assert abs(free_bytes() - base) <= 8 << 20, (base, free_bytes())      # 90 contexts later: within 8 MiB
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY 8f N4 residuals: every rayMarchNormalization of the reference, a custom centre, a config without the key
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", NORM_CASES)
+def test_normalisations_match_the_reference(name, tmp_path_factory):
+    """nerf_get_normalization_function (src/nerf_raymarch_common.py:195-244) on the device, against reference-generated fixtures: the
+    encoded shading inputs of the fixture's samples (identity slots tight, top band loose: un-normalised positions reach |8| and the
+    2^9 band multiplies a 1-ulp difference by 4 000), the fp32 shading network on them, and the fixture's colours from an fp32 frame."""
+    from test_gpu_parity import golden_ray_records, golden_samples, run_rows
+    z, meta, sc = load_case(name)
+    wts = case_weights(meta)
+    d = _dir(tmp_path_factory, sc, wts, "norm_" + name)
+    count, off, key, sw, sray, sbin = golden_samples(z, sc)
+    m = z["shade_in"].shape[0]
+    S = min(len(key), 2570)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, meta["w"], meta["h"]), precision="fp32") as r:
+        r.set_camera(z["pose"], z["rot"])
+        d_rays, d_key = r.to_device(golden_ray_records(z, meta, sc)), r.to_device(key[:S])
+        out = r.empty((m, sc.n_in1), np.float32)
+        r.shade_features(d_rays, d_key, m, out)
+        f = out.numpy()
+        raw_d = r.empty((S, 4), np.float32)
+        r.shade_mlp(d_rays, d_key, r.to_device(np.array([S], np.int32)), S, raw_d)
+        raw = raw_d.numpy()
+    np.testing.assert_allclose(f[:, :3], z["shade_in"][:, :3], rtol=1e-6, atol=3e-6)        # the normalised position itself
+    np.testing.assert_allclose(f[:, :9], z["shade_in"][:, :9], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(f, z["shade_in"], rtol=0, atol=5e-3)
+    np.testing.assert_allclose(raw, z["shade_out"][:S], rtol=1e-3, atol=2e-2)             # raw outputs reach |30|; top-band conditioning as above
+    # a whole fp32 frame of the fixture's crop: rays rendered row by row through the C ABI
+    x0, y0, cw, ch, stride = meta["crop"]
+    cols = x0 + stride * np.arange(cw)
+    got = []
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, meta["w"], meta["h"]), precision="fp32") as r:
+        r.set_camera(z["pose"], z["rot"])
+        rgb_full, _, st = r.render_numpy()
+        cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (meta["w"] * meta["h"],))
+    idx = ((y0 + stride * np.arange(ch))[:, None] * meta["w"] + cols[None, :]).reshape(-1)
+    check_identical(cnt[idx] == z["sel_count"], "normalisation_counts", 0, case=name)
+    err = float(np.abs(rgb_full[idx] - z["rgb"]).max())
+    record("normalisation_frame", case=name, max_abs_rgb_err=err, shade_in_max_err=float(np.abs(f - z["shade_in"]).max()))
+    assert err < 2e-3, err
 
 
 # ---------------------------------------------------------------------------------------------

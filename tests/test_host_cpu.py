@@ -134,6 +134,29 @@ def test_parse_model_and_info(lib, tmp_path):
     assert info.num_samples == 4 and abs(info.threshold - 0.3) < 1e-7
 
 
+def test_normalisation_names_and_guard_options_are_validated(lib, tmp_path):
+    """Every rayMarchNormalization the reference knows parses (src/nerf_raymarch_common.py:233-244), a config without the key too; any other
+    name fails with EUNSUPPORTED and says which names exist; a malformed centre and bad guard options are EIO / EINVAL."""
+    import dataclasses
+    lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+    info = R.Info()
+    base = O.Scene((0.5, -1.0, 1.25), (0.7, 0.7, 0.2), (0.15, 8.25), 1.125, 8.75, 8, 0.2)
+    for i, norm in enumerate(["None", "Centered", "MaxDepth", "MaxDepthCentered", "LogCentered", "InverseDistCentered", "InverseSqrtDistCentered", ""]):
+        d, _, _ = _model_dir(tmp_path, dataclasses.replace(base, normalization=norm, normalization_center=(0.1, 0.2, 0.3) if i % 2 else ()), name="n%d" % i)
+        assert lib.adanerf_host_parse_model(d.encode(), C.byref(_opts()), C.byref(info)) == 0, norm
+    d, _, _ = _model_dir(tmp_path, dataclasses.replace(base, normalization="SqrtCentered"), name="bad")
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(_opts()), C.byref(info)) == -4
+    assert b"LogCentered" in lib.adanerf_last_error(None)
+    with open(os.path.join(d, "config.ini"), "a") as f:
+        f.write("rayMarchNormalization = [InverseSqrtDistCentered, None]\nrayMarchNormalizationCenter = [1.0, 2.0]\n")
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(_opts()), C.byref(info)) == -2
+    d, _, _ = _model_dir(tmp_path, base, name="ok")
+    for kw in (dict(guard_audit_period=3), dict(guard_audit_period=64), dict(guard_eps=2.0), dict(guard_eps_pair=3.0)):
+        assert lib.adanerf_host_parse_model(d.encode(), C.byref(_opts(**kw)), C.byref(info)) == -1, kw
+    for kw in (dict(guard_audit_period=-1), dict(guard_audit_period=32), dict(guard_eps=0.01, guard_eps_pair=0.015)):
+        assert lib.adanerf_host_parse_model(d.encode(), C.byref(_opts(**kw)), C.byref(info)) == 0, kw
+
+
 def test_strip_sharding_partitions_rows(lib, tmp_path):
     d, _, _ = _model_dir(tmp_path)
     lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
@@ -276,7 +299,9 @@ def test_generic_topologies_pack_and_reproduce_the_reference(lib, tmp_path, name
     u = (nds / np.sqrt(np.sum(nds * nds, -1, keepdims=True))).astype(np.float32)
     w, b, lay = pack_weights(lib, d, 0, 2)
     assert lay.shape[0] == syn["layers"][0] + (1 if sc.ray_sample_input else 0)
-    assert [int(v) for v in lay[:syn["layers"][0], 3]] == [syn["widths"][0] // 32] * (syn["layers"][0] - 1) + [4]
+    pad = lambda w_: 64 if w_ <= 64 else (128 if w_ <= 128 else 256)      # widths without a kernel instantiation run zero-padded (pack.cpp pad_width)
+    pw0, pw1 = pad(syn["widths"][0]), pad(syn["widths"][1])
+    assert [int(v) for v in lay[:syn["layers"][0], 3]] == [pw0 // 32] * (syn["layers"][0] - 1) + [4]
     rsi_z = O.ray_sample_depths(sc) if sc.ray_sample_input else None
     orc = run_sampling_net_generic(PackedNet(w, b, lay, 2), u, z["p"][:n], nds, fp, fd, rsi_z, sc.depth_range[1])
     np.testing.assert_allclose(orc, z["oracle_out"][:n], rtol=0, atol=1e-4)
@@ -287,13 +312,13 @@ def test_generic_topologies_pack_and_reproduce_the_reference(lib, tmp_path, name
     ref = O.shading_mlp(feat, wts.net1)
     w1, b1, lay1 = pack_weights(lib, d, 1, 2)
     depth, skips = O.shading_topology(wts.net1, 63)
-    out = run_shading_net_generic(PackedNet(w1, b1, lay1, 2), feat[:, 0:3], feat[:, 63:66], depth, syn["widths"][1], skips[0] if skips else -1)
+    out = run_shading_net_generic(PackedNet(w1, b1, lay1, 2), feat[:, 0:3], feat[:, 63:66], depth, pw1, skips)
     np.testing.assert_allclose(out, ref, rtol=0, atol=2e-4)
     # the shading net packs for the 16-bit engines in every topology (k_generic16.hip.hpp); replayed in bf16 / fp16 it stays
     # within the operand rounding of the oracle
     for prec, tol in ((0, 0.25), (1, 0.03)):
         wq, bq, layq = pack_weights(lib, d, 1, prec)
-        outq = run_shading_net_generic(PackedNet(wq, bq, layq, prec), feat[:, 0:3], feat[:, 63:66], depth, syn["widths"][1], skips[0] if skips else -1)
+        outq = run_shading_net_generic(PackedNet(wq, bq, layq, prec), feat[:, 0:3], feat[:, 63:66], depth, pw1, skips)
         assert np.abs(outq - ref).max() < tol and np.sqrt(np.mean((outq - ref) ** 2)) < tol / 6
     # the sampling net: plain 16-bit fragments only for 8 x 256 (ring-streamed kernel); the split-precision pairs for every
     # topology without raySampleInput (sample_mlp16x3_gen_kernel), reproducing the reference's outputs like the fp32 packing
