@@ -186,6 +186,7 @@ struct ModelSetup {
   int ray_samples = 0;
   std::vector<float> rsi_z;
   std::vector<float> ztab;
+  int bins = 128;                 // multiDepthFeatures: depth cells of the adaptive sampler (src/nerf_raymarch_common.py:675-677, 726-727)
   DepthMap dm{};
   bool coarse_fine = false;
   int n_coarse = 0;
@@ -317,6 +318,16 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
     n_max += ms->n_coarse;
   }
   if (thr < 0.f) return bad(ADANERF_EUNSUPPORTED, "adaptiveSamplingThreshold < 0 is unsupported on the adaptive path (as in the reference)");
+  // multiDepthFeatures = [D0, D1]: D0 outputs of the sampling network, D1 depth cells of the sampler (cell_size = 1 / D1); the
+  // reference needs them equal (it indexes cells by output position).  D < 128 runs on 128-wide rows padded with absent bins
+  // (pack.cpp); only the adaptive sampler with a threshold takes it -- dense mode and the inverse-CDF sampler walk all 128 bins.
+  ms->bins = cf.multiDepthFeatures.empty() ? kBins : cf.multiDepthFeatures.back();
+  if (!cf.multiDepthFeatures.empty() && cf.multiDepthFeatures.front() != cf.multiDepthFeatures.back() && !coarse_fine)
+    return bad(ADANERF_EUNSUPPORTED, "multiDepthFeatures entries differ: the sampler's cells are the sampling network's outputs");
+  if (ms->bins < 1 || ms->bins > kBins) return bad(ADANERF_EUNSUPPORTED, "multiDepthFeatures must be in 1..128");
+  if (ms->bins != kBins && (pdf_mode || coarse_fine || thr == 0.f))
+    return bad(ADANERF_EUNSUPPORTED, "multiDepthFeatures != 128 is supported with the adaptive sampler and a threshold > 0 only");
+  if (ms->bins != kBins && n_max > ms->bins) return bad(ADANERF_EINVAL, "numRaymarchSamples exceeds multiDepthFeatures");
   if (thr == 0.f && n_max != kBins) return bad(ADANERF_EUNSUPPORTED, "adaptiveSamplingThreshold == 0 (dense) requires numRaymarchSamples == 128");
   if (!coarse_fine && (n_max < 1 || n_max > kBins)) return bad(ADANERF_EINVAL, "numRaymarchSamples must be in 1..128");
   if (opt->precision < 0 || opt->precision > 2) return bad(ADANERF_EINVAL, "precision must be ADANERF_PREC_{BF16,FP16,FP32}");
@@ -430,7 +441,7 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
       float u = static_cast<float>(k) * (1.0f / kBins) + 0.5f / kBins;
       t = znear * (1.0f - u) + zfar * u;
     } else {
-      t = (static_cast<float>(k) + 0.5f) * (1.0f / kBins);   // (k + .5) * cell_size, :737-741
+      t = (static_cast<float>(k) + 0.5f) * (1.0f / static_cast<float>(ms->bins));   // (k + .5) * cell_size, cell_size = 1 / multiDepthFeatures, :726-741
     }
     float z;
     if (ndc) z = t;                                            // ...NoDepthRange: :796-851
@@ -639,8 +650,17 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
       // undecided rays -> ascending list (+ count at total[4]) -> split engine over the list, rows overwritten in place
       const int n_words = (n_rays + 31) / 32;
       int32_t* n_list = reinterpret_cast<int32_t*>(c->total.p) + 4;
+      if (!c->sample_grid) {
+        int rc = full ? occupancy_grid(c, sample_mlp16x3_kernel<10, 4>, 256, &c->sample_grid)
+                      : occupancy_grid(c, sample_mlp16x3_kernel<2, 2>, 256, &c->sample_grid);
+        if (rc) return rc;
+      }
+      const dim3 rgrid(std::min<unsigned>(grid.x, static_cast<unsigned>(c->sample_grid)));
+      // ADANERF_FLAG_GUARD_AUDIT_FILL: the audit only fills the last round of the refinement pass (rgrid tiles of 128 rays per round)
+      const int cap_round = (c->opt.flags & ADANERF_FLAG_GUARD_AUDIT_FILL) ? static_cast<int>(rgrid.x) * 128 : 0;
+      const int cycle = a.sel.audit_period > 0 ? static_cast<int>((c->guard_frame / static_cast<uint32_t>(a.sel.audit_period)) & 0x7fffffffu) : 0;
       hipLaunchKernelGGL(refine_list_kernel, dim3((n_words + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(c->guard_mask.p),
-                         n_words, n_rays, a.sel.audit_period, a.sel.audit_phase, reinterpret_cast<int32_t*>(c->refine_list.p), n_list);
+                         n_words, n_rays, a.sel.audit_period, a.sel.audit_phase, cap_round, cycle, reinterpret_cast<int32_t*>(c->refine_list.p), n_list);
       SampleArgs r = a;
       r.net16 = c->net0_split.params;
       r.rays_out = nullptr;              // the first pass wrote the ray records
@@ -654,12 +674,6 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
       r.sel.refine_list = reinterpret_cast<const int32_t*>(c->refine_list.p);
       r.ray_list = r.sel.refine_list;
       r.n_list = n_list;
-      if (!c->sample_grid) {
-        int rc = full ? occupancy_grid(c, sample_mlp16x3_kernel<10, 4>, 256, &c->sample_grid)
-                      : occupancy_grid(c, sample_mlp16x3_kernel<2, 2>, 256, &c->sample_grid);
-        if (rc) return rc;
-      }
-      const dim3 rgrid(std::min<unsigned>(grid.x, static_cast<unsigned>(c->sample_grid)));
       if (full) hipLaunchKernelGGL((sample_mlp16x3_kernel<10, 4>), rgrid, block, 0, c->stream, r);
       else hipLaunchKernelGGL((sample_mlp16x3_kernel<2, 2>), rgrid, block, 0, c->stream, r);
     }
@@ -1200,6 +1214,8 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
       return bail(ADANERF_EIO, "model0.onnx: " + err);
   } else {
     if (!pack_sampling_net(n0, sh, Elem::F32, &p0, &err)) return bail(ADANERF_EIO, "model0.onnx: " + err);
+    if (p0.topo.bins != ms.bins)
+      return bail(ADANERF_EIO, "model0.onnx has " + std::to_string(p0.topo.bins) + " outputs, config.ini says multiDepthFeatures = " + std::to_string(ms.bins));
     c->topo0 = p0.topo;
     c->generic0 = !p0.topo.is_default(false) || c->enc0 == kEncMax;
     // the split-precision packing: the ring-streamed kernel's for the 8 x 256 net, the run-time-shaped kernel's otherwise (not with raySampleInput)
@@ -1432,8 +1448,8 @@ int adanerf_compact(adanerf_ctx* c, const float* d_oracle, int32_t n_rays, int32
 }
 
 int adanerf_compact_guarded(adanerf_ctx* c, const float* d_approx, const float* d_exact, int32_t n_rays, int32_t n_max, float thr, float eps,
-                            float eps_pair, int32_t audit_period, int32_t audit_phase, int32_t* d_off, int32_t* d_cnt, uint32_t* d_key, float* d_w,
-                            int32_t* d_total, int32_t* d_refined, uint32_t* d_monitor) {
+                            float eps_pair, int32_t audit_period, int32_t audit_phase, int32_t audit_fill_cap, int32_t audit_cycle, int32_t* d_off,
+                            int32_t* d_cnt, uint32_t* d_key, float* d_w, int32_t* d_total, int32_t* d_refined, uint32_t* d_monitor) {
   if (!c) return ADANERF_EINVAL;
   BIND(c);
   if (!d_approx || !d_exact || !d_off || !d_cnt || !d_key || !d_w || !d_total || !d_refined) return fail(c, ADANERF_EINVAL, "NULL buffer");
@@ -1462,7 +1478,7 @@ int adanerf_compact_guarded(adanerf_ctx* c, const float* d_approx, const float* 
   const dim3 grid((n_rays + 127) / 128), block(256);
   hipLaunchKernelGGL(select_rows_kernel, grid, block, 0, c->stream, d_approx, n_rays, so, static_cast<const int32_t*>(nullptr));
   hipLaunchKernelGGL(refine_list_kernel, dim3((n_words + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(c->guard_mask.p), n_words,
-                     n_rays, period, phase, reinterpret_cast<int32_t*>(c->refine_list.p), d_refined);
+                     n_rays, period, phase, audit_fill_cap > 0 ? audit_fill_cap : 0, audit_cycle, reinterpret_cast<int32_t*>(c->refine_list.p), d_refined);
   so.guard_mask = nullptr;
   so.guard_band = eps;
   so.guard_band_pair = c->transform == kOracleRaw ? so.guard_pair : 0.f;

@@ -355,44 +355,99 @@ __global__ __launch_bounds__(256) void expand_kernel(const int32_t* __restrict__
 
 // Guarded selection, between its two passes: the ascending list of the rays to re-evaluate and their number -- the rays whose guard
 // bit is set (one word per 32 rays, written by pair_epilogue) and the rays audited in this frame (audit_bits: a rotating 1 / period of all
-// rays; an audited ray that pass 1 had decided carries kRefineAuditBit in its entry).  256 words (8 192 rays) per workgroup; like
-// expand_kernel every workgroup sums what lies in front of it instead of waiting for a scan (<= 80 KB of L2 reads per workgroup at
-// 800 x 800).  Deterministic order.
+// rays; an audited ray that pass 1 had decided carries kRefineAuditBit in its entry).  256 words (8 192 rays) per workgroup.  Every
+// workgroup reads the whole mask (<= 80 KB from L2 at 800 x 800) for the totals and its own prefix instead of waiting for a scan.
+// Deterministic order.
+//   cap_round > 0 ("fill" mode, ADANERF_FLAG_GUARD_AUDIT_FILL): the refinement pass runs in rounds of cap_round rays (its grid x 128); the
+//   undecided rays fix the number of rounds, and only as many audited-only rays are listed as the last round has room for -- the audit
+//   then never costs a round of its own (an 80 000-ray share of an 8-GPU frame: 31 000 undecided rays are one round, 34 000 with the
+//   audit were two).  Which ones: a window of the frame's audit candidates, in ray order, that moves on by its own length every time the
+//   same audit phase comes round again (`cycle`), so no ray is left out for good.
+struct RefinePlan {
+  int tot_und, tot_aud, budget, offset;
+};
+__device__ __forceinline__ int refine_accepted_before(const RefinePlan& p, int pa) {      // accepted audit candidates with rank < pa
+  if (p.budget >= p.tot_aud) return pa;
+  const int wrap = p.offset + p.budget - p.tot_aud;      // > 0: the window wraps round to the first `wrap` candidates
+  if (wrap <= 0) return min(max(pa - p.offset, 0), p.budget);
+  return min(pa, wrap) + max(pa - p.offset, 0);
+}
+__device__ __forceinline__ bool refine_accepts(const RefinePlan& p, int pa) {
+  if (p.budget >= p.tot_aud) return true;
+  int d = pa - p.offset;
+  if (d < 0) d += p.tot_aud;
+  return d < p.budget;
+}
 __global__ __launch_bounds__(256) void refine_list_kernel(const uint32_t* __restrict__ mask, int n_words, int n_rays, int period, int phase,
-                                                          int32_t* __restrict__ list, int32_t* __restrict__ count) {
-  __shared__ int part[4], wtot[4];
+                                                          int cap_round, int cycle, int32_t* __restrict__ list, int32_t* __restrict__ count) {
+  __shared__ int red[4][4], wtot[2][4];
   const int t = static_cast<int>(threadIdx.x);
   const int b0 = blockIdx.x * 256;
-  int s = 0;
-  {   // b0 is a multiple of 256 words: 16-byte loads, four in flight per thread (the loop is latency-, not bandwidth-bound); none of
-      // these words is the batch's last one, so every audit bit in them is a ray
-    const uint4* m4 = reinterpret_cast<const uint4*>(mask);
-    const int n4 = b0 >> 2;
-#pragma unroll 4
-    for (int i = t; i < n4; i += 256) {
-      const uint4 v = m4[i];
-      s += __popc(v.x | audit_bits(period, phase, 4 * i)) + __popc(v.y | audit_bits(period, phase, 4 * i + 1)) +
-           __popc(v.z | audit_bits(period, phase, 4 * i + 2)) + __popc(v.w | audit_bits(period, phase, 4 * i + 3));
+  auto word = [&](int i, uint32_t* und, uint32_t* aud) {      // bits of word i: undecided rays, audited-only rays
+    const int left = n_rays - i * 32;                           // rays this word covers (the last word may be partial)
+    const uint32_t in_range = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? low_bits32(left) : 0u);
+    const uint32_t u = mask[i] & in_range;
+    *und = u;
+    *aud = audit_bits(period, phase, i) & ~u & in_range;
+  };
+  int s[4] = {0, 0, 0, 0};      // undecided / audited-only in front of this workgroup, and in the whole batch
+  for (int i = t; i < n_words; i += 256) {
+    uint32_t u, a;
+    word(i, &u, &a);
+    const int cu = __popc(u), ca = __popc(a);
+    if (i < b0) {
+      s[0] += cu;
+      s[1] += ca;
+    }
+    s[2] += cu;
+    s[3] += ca;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s[k] = wave_sum_dpp_i32(s[k]);
+  const int wi = b0 + t;
+  uint32_t und = 0u, aud = 0u;
+  if (wi < n_words) word(wi, &und, &aud);
+  const int cu = __popc(und), ca = __popc(aud);
+  const int xu = wave_incl_sum_dpp_i32<64>(cu), xa = wave_incl_sum_dpp_i32<64>(ca);       // inclusive scans inside the wave
+  if ((t & 63) == 63) {
+    wtot[0][t >> 6] = xu;
+    wtot[1][t >> 6] = xa;
+  }
+  if ((t & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[k][t >> 6] = s[k];
+  }
+  __syncthreads();
+  int tot[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) tot[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+  RefinePlan p;
+  p.tot_und = tot[2];
+  p.tot_aud = tot[3];
+  p.budget = p.tot_aud;
+  p.offset = 0;
+  if (cap_round > 0) {
+    const int rounds = max(1, (p.tot_und + cap_round - 1) / cap_round);
+    p.budget = min(p.tot_aud, max(0, rounds * cap_round - p.tot_und));
+    if (p.budget > 0 && p.budget < p.tot_aud) p.offset = static_cast<int>((static_cast<long long>(cycle) * p.budget) % p.tot_aud);
+  }
+  int pu = tot[0] + xu - cu, pa = tot[1] + xa - ca;      // ranks of this word's first undecided / audited-only ray
+  for (int w = 0; w < (t >> 6); ++w) {
+    pu += wtot[0][w];
+    pa += wtot[1][w];
+  }
+  for (uint32_t r = und | aud; r; r &= r - 1u) {
+    const int bit = __builtin_ctz(r);
+    const int ray = wi * 32 + bit;
+    if ((und >> bit) & 1u) {
+      list[pu + refine_accepted_before(p, pa)] = ray;
+      ++pu;
+    } else {
+      if (refine_accepts(p, pa)) list[pu + refine_accepted_before(p, pa)] = ray | kRefineAuditBit;
+      ++pa;
     }
   }
-  s = wave_sum_dpp_i32(s);
-  const int wi = b0 + t;
-  const uint32_t und = wi < n_words ? mask[wi] : 0u;
-  const int left = n_rays - wi * 32;                                       // rays this word covers (the last word may be partial)
-  const uint32_t in_range = left >= 32 ? 0xFFFFFFFFu : (left > 0 ? low_bits32(left) : 0u);
-  const uint32_t m = (und | audit_bits(period, phase, wi)) & in_range;
-  const int c = __popc(m);
-  const int x = wave_incl_sum_dpp_i32<64>(c);       // inclusive scan inside the wave
-  if ((t & 63) == 63) wtot[t >> 6] = x;
-  if ((t & 63) == 0) part[t >> 6] = s;
-  __syncthreads();
-  int base = part[0] + part[1] + part[2] + part[3] + x - c;
-  for (int w = 0; w < (t >> 6); ++w) base += wtot[w];
-  for (uint32_t r = m; r; r &= r - 1u) {
-    const int bit = __builtin_ctz(r);
-    list[base++] = (wi * 32 + bit) | (((und >> bit) & 1u) ? 0 : kRefineAuditBit);
-  }
-  if (blockIdx.x == gridDim.x - 1 && t == 255) *count = base;      // the last thread's end = the total
+  if (blockIdx.x == 0 && t == 0) *count = p.tot_und + p.budget;
 }
 
 // Debug view of the sampling network (viewer 'O' key: copyResultSamplingNetwork -> samplesToImage,

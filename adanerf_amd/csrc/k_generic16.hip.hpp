@@ -131,7 +131,8 @@ __device__ __forceinline__ void ts_start(TileStage& st, const void* gbase, char*
 // the tile issued last has landed and the other buffer is free: returns this lane's read address, starts the copy of the next tile
 template <int BUF_BYTES>
 __device__ __forceinline__ uint32_t ts_next(TileStage& st, uint32_t next_off, int next_frags) {
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  if (tune::kAblateGeneric & 1) asm volatile("s_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   const uint32_t rd = st.lds_base + st.buf * BUF_BYTES + st.lane_off;
   st.buf ^= 1u;
   ts_issue<BUF_BYTES>(st, next_off, next_frags, st.buf);
@@ -143,7 +144,23 @@ __device__ __forceinline__ uint32_t ts_next(TileStage& st, uint32_t next_off, in
 // itself the scheduler hoisted every LDS read of a tile to its head (92 registers for a 23-step tile) and spilled.
 constexpr int kStageAhead = 4;
 
+// Keeps the bias loads of a tile loop inside it (hipcc otherwise hoists every one of them out of the loop and spills) WITHOUT taking the
+// pointer's address space away: an opaque zero added to the kernel-argument pointer.  Round 3 laundered the pointer itself through an
+// asm statement; what came back was a generic pointer, the bias blocks became FLAT loads, and with flat loads in flight hipcc cannot
+// count LDS returns: it put `s_waitcnt vmcnt(0) lgkmcnt(0)` in front of every tile's first MFMA, which also drained the copy of the
+// NEXT tile's weights that had just been issued -- every tile of 4-16 MFMAs paid a global-memory round trip
+// (profiles/r04_generic_bias_loads.md).  As global loads they are counted on vmcnt alone and waited for a tile later.
+__device__ __forceinline__ int bias_launder() {
+  int z = 0;
+  asm volatile("" : "+s"(z));
+  return z;
+}
 __device__ __forceinline__ void bias_request(const float* __restrict__ bias_tile, int h, float (&br)[16]) {
+  if (tune::kAblateGeneric & 2) {      // timing ablation: no bias loads at all
+#pragma unroll
+    for (int r = 0; r < 16; ++r) br[r] = 0.f;
+    return;
+  }
   const float4* bp = reinterpret_cast<const float4*>(bias_tile + h * 16);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -235,7 +252,8 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
   const int j = lane & 31, h = lane >> 5;
   int total = a.total ? *a.total : a.max_samples;
   if (total > a.max_samples) total = a.max_samples;
-  const float* b = a.net.bias;
+  const float* const bias0 = a.net.bias;
+  const float* b = bias0;
   if (static_cast<int>(blockIdx.x) * TILE >= total) return;      // workgroup-uniform
   const uint32_t stash = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(stage_mem)) + 2 * BUF + wave * NB * STASH + lane * 16;
   TileStage st;
@@ -245,7 +263,7 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
   bias_request(b + a.net.b_off[0], h, br);
   const int lf = t.depth;
   for (int tile = blockIdx.x; tile * TILE < total; tile += gridDim.x) {
-    asm volatile("" : "+v"(b));                  // keep the bias loads inside the loops (see shade_mlp32_kernel)
+    b = bias0 + bias_launder();                  // keep the bias loads inside the loops (see shade_mlp32_kernel)
     // narrow networks spend as long in the encodings as in their MFMAs (60 sin / cos per sample against 243 MFMAs per block at
     // 6 x 128): the position encoding is evaluated once and parked in LDS for the skip layer, the direction encoding is evaluated
     // where it is consumed -- neither lives in registers across the layer stack
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
     }
 #pragma unroll 1
     for (int l = 1; l < t.depth; ++l) {
-      asm volatile("" : "+v"(b));
+      b = bias0 + bias_launder();
       const uint32_t nxt = a.net.w_off[l + 1];
       const float* nb_ = b + a.net.b_off[l + 1];
       const int nks = ks_of(l + 1);
@@ -422,7 +440,8 @@ __global__ __launch_bounds__(256, (STAGED && W <= 128 && FP <= 10) ? 2 : 1) void
   unit3(nds, u);
   uint32_t aH[W / 4], aL[W / 4], bH[W / 4], bL[W / 4];
   const u32x4* w = a.net16.w;
-  const float* b = a.net16.bias;
+  const float* const bias0 = a.net16.bias;
+  const float* b = bias0;
   float out[64];
   if constexpr (STAGED) {
     TileStage st;
@@ -442,7 +461,7 @@ __global__ __launch_bounds__(256, (STAGED && W <= 128 && FP <= 10) ? 2 : 1) void
     }
 #pragma unroll 1
     for (int l = 1; l + 1 < t.depth; ++l) {
-      asm volatile("" : "+v"(b));
+      b = bias0 + bias_launder();
       layer_16x3_staged<BUF, KW, MT, false>(st, br, a.net16.w_off[l], b + a.net16.b_off[l], lane, bH, bL, aH, aL, nullptr, a.net16.w_off[l + 1], 2 * KW,
                                             b + a.net16.b_off[l + 1]);
 #pragma unroll

@@ -218,6 +218,9 @@ bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, Pac
   NetTopology& T = out->topo;
   T.depth = count_layers(net0, "layers.");
   if (T.depth < 2 || T.depth > kMaxDepth) return fail(err, "sampling net: " + std::to_string(T.depth) + " layers (2.." + std::to_string(kMaxDepth) + " supported)");
+  const int n_bins = find(net0, "layers." + std::to_string(T.depth - 1) + ".weight", err)->rows();      // multiDepthFeatures[0]
+  T.bins = n_bins;
+  if (n_bins < 1 || n_bins > kBins) return fail(err, "sampling net: " + std::to_string(n_bins) + " outputs (multiDepthFeatures 1 .. 128 supported)");
   const int Wr = find(net0, "layers.0.weight", err)->rows();     // exists: depth >= 2.  The network's own width ...
   T.width = pad_width(Wr);                                       // ... and the width it runs at
   T.real_width = Wr;
@@ -233,7 +236,7 @@ bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, Pac
     const Tensor* W = find(net0, "layers." + std::to_string(i) + ".weight", err);
     const Tensor* B = find(net0, "layers." + std::to_string(i) + ".bias", err);
     if (!W || !B) return false;
-    const int n_out = (i == T.depth - 1) ? kBins : Wr;
+    const int n_out = (i == T.depth - 1) ? n_bins : Wr;
     const int k = (i == 0) ? n_in : Wr;           // BaseNet skip specs (src/models.py:44-66) are not used by any config: plain chain
     if (W->rows() != n_out) {
       if (err) *err = "layers." + std::to_string(i) + ".weight: expected " + std::to_string(n_out) + " rows";
@@ -242,6 +245,10 @@ bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, Pac
     VLayer L;
     init_layer(&L, (i == T.depth - 1) ? kBins : T.width, k);      // hidden layers: rows padded to the width the kernels run
     if (!set_rows(&L, 0, W, B, k, err, "layers." + std::to_string(i))) return false;
+    // multiDepthFeatures = D < 128: the selection kernels work on 128 values per ray; the bins the network does not have get zero
+    // weights and a bias no threshold, arg-max or softmax ever picks (-1e30: exp() of it is 0, a sigmoid of it 0)
+    if (i == T.depth - 1)
+      for (int r = n_bins; r < kBins; ++r) L.b[r] = kAbsentBin;
     if (i == 0) {
       add_pe_slots(&L, sh.fd0, 0, sh.ld0);        // [dir PE | pos PE]  (src/features.py:868-874)
       add_pe_slots(&L, sh.fp0, n_dir, sh.lp0);

@@ -22,8 +22,10 @@ struct NetTopology {
   int skip = -1;           // NeRF trunk: the first entry of the reference's `skips` (layer skip + 1 takes cat([input_pts, h])); -1 = none
   int cat_mask = 0;        // ... all of them: bit l set <=> layer l takes cat([input_pts, h]) (one bit per skip: the NeRF class accepts a list)
   int ray_samples = 0;     // sampling net: raySampleInput points in layer 0's input
+  int bins = 128;          // sampling net: outputs = depth cells (multiDepthFeatures[0]); fewer than 128 run padded with kAbsentBin rows
   bool is_default(bool shading) const { return depth == 8 && width == 256 && ray_samples == 0 && cat_mask == (shading ? (1 << 5) : 0); }
 };
+constexpr float kAbsentBin = -1.0e30f;      // bias of the output rows a sampling net with fewer than 128 depth cells does not have
 constexpr int kMaxDepth = 8;    // w_off / b_off tables hold depth + 3 entries (kMaxLayers = 12)
 
 // One packed network: every layer's A fragments back to back plus the per-tile bias blocks.

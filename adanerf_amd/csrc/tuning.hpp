@@ -213,6 +213,15 @@ constexpr int kAblateSample = 0;
 #endif
 
 
+// kAblateGeneric (run-time-shaped 16-bit kernels, k_generic16.hip.hpp; wrong results): 1 = the per-tile wait for the staged weights is skipped
+// (barrier only) -- the time the kernel would take if the copies always arrived in time, i.e. the most a deeper prefetch can buy;
+// 2 = no bias loads (accumulators start at 0); 3 = both
+#if ADN_OVERRIDABLE && defined(ADN_ABLATE_G)
+constexpr int kAblateGeneric = ADN_ABLATE_G;
+#else
+constexpr int kAblateGeneric = 0;
+#endif
+
 #undef ADN_OVERRIDABLE
 
 }  // namespace tune

@@ -23,7 +23,7 @@ _PREC = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "fp32": PREC_FP
 
 BUF_RAYS, BUF_ORACLE, BUF_RAY_OFFSETS, BUF_RAY_COUNTS, BUF_SAMPLE_KEY, BUF_SAMPLE_W, BUF_RAW, BUF_TOTAL, BUF_SAMPLE_Z, BUF_RAW_COARSE = range(10)
 SAMPLER_ADAPTIVE, SAMPLER_PDF, SAMPLER_COARSE_FINE = 0, 1, 2
-FLAG_KEEP_ORACLE, FLAG_WAVE_SELECT, FLAG_NO_GUARD_CACHE = 1, 2, 4
+FLAG_KEEP_ORACLE, FLAG_WAVE_SELECT, FLAG_NO_GUARD_CACHE, FLAG_GUARD_AUDIT_FILL = 1, 2, 4, 8
 ABI_VERSION = 4
 GUARD_FROM = {0: "none", 1: "options", 2: "record", 3: "calibration", 4: "monitor"}
 SAMPLING_MODES = {"split": 0, "fp16x3": 0, "fp32": 1, "fp16": 2, "guarded": 3}
@@ -99,7 +99,7 @@ def load_library(path: Optional[str] = None):
     lib.adanerf_ray_features.argtypes = [vp, i32, i32, f32p, f32p]
     lib.adanerf_sample_mlp.argtypes = [vp, i32, i32, f32p, f32p]
     lib.adanerf_compact.argtypes = [vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, vp]
-    lib.adanerf_compact_guarded.argtypes = [vp, vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.adanerf_compact_guarded.argtypes = [vp, vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.adanerf_calibrate_guard.argtypes = [vp, i32, C.c_uint32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.adanerf_guard_calibration_file.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.adanerf_abi_version.argtypes = []
@@ -208,12 +208,15 @@ class NeuralRenderer:
     def __init__(self, settings: Settings, precision="bf16", device_id: int = 0, num_samples: int = 0,
                  threshold: float = -1.0, shard_rank: int = 0, shard_world: int = 1, strip_rows: int = 8,
                  sampling: Optional[str] = None, lib_path: Optional[str] = None, keep_oracle: bool = False, wave_select: bool = False,
-                 guard_eps: float = 0.0, guard_eps_pair: float = 0.0, guard_audit_period: int = 0, guard_cache: bool = True):
+                 guard_eps: float = 0.0, guard_eps_pair: float = 0.0, guard_audit_period: int = 0, guard_cache: bool = True,
+                 guard_audit_fill: Optional[bool] = None):
         """sampling: arithmetic of the sampling network -- "guarded" (plain fp16 for every ray + the split-precision engine where the
         audited guard band cannot decide; the split engine's selections), "split", "fp32", "fp16" (opt-in speed mode).  Default (None),
         as in the `adanerf` CLI and bench.py: "guarded" with a 16-bit shading network; "split" with precision="fp32" -- the
         tight-tolerance parity mode, where the kept oracle values of the rays the guarded mode does not re-evaluate (the fp16 engine's,
         within the band of the exact ones: ~4e-3) would be the largest error of the frame.  guard_*: include/adanerf_hip.h adanerf_options."""
+        if guard_audit_fill is None:      # a shard of a frame: the audit fills the refinement pass's last round instead of adding one (ADANERF_FLAG_GUARD_AUDIT_FILL)
+            guard_audit_fill = shard_world > 1
         if sampling is None:
             sampling = "split" if (_PREC[precision] if isinstance(precision, str) else int(precision)) == PREC_FP32 else "guarded"
         self.settings = settings
@@ -226,7 +229,7 @@ class NeuralRenderer:
                              sampling_mode=SAMPLING_MODES[sampling], guard_eps=guard_eps, guard_eps_pair=guard_eps_pair,
                              guard_audit_period=guard_audit_period,
                              flags=(FLAG_KEEP_ORACLE if keep_oracle else 0) | (FLAG_WAVE_SELECT if wave_select else 0) |
-                                   (0 if guard_cache else FLAG_NO_GUARD_CACHE))
+                                   (0 if guard_cache else FLAG_NO_GUARD_CACHE) | (FLAG_GUARD_AUDIT_FILL if guard_audit_fill else 0))
         self.info = Info()
         self.last_stats = Stats()
         self._own = []
@@ -365,11 +368,12 @@ class NeuralRenderer:
                                              _ptr(ray_counts), _ptr(sample_key), _ptr(sample_w), _ptr(total)))
 
     def compact_guarded(self, oracle_approx, oracle_exact, n_rays: int, n_max: int, thr: float, eps: float, ray_offsets, ray_counts,
-                        sample_key, sample_w, total, refined, eps_pair: float = 0.0, audit_period: int = 0, audit_phase: int = 0, monitor=None):
+                        sample_key, sample_w, total, refined, eps_pair: float = 0.0, audit_period: int = 0, audit_phase: int = 0, monitor=None,
+                        audit_fill_cap: int = 0, audit_cycle: int = 0):
         """monitor: optional device uint32[5] the caller zeroed (largest error bits, rows beyond a bound, largest pair error bits,
         audit mismatches, audited rows)."""
         self._check(self.lib.adanerf_compact_guarded(self.handle, _ptr(oracle_approx), _ptr(oracle_exact), n_rays, n_max, thr, eps, eps_pair,
-                                                     audit_period, audit_phase, _ptr(ray_offsets), _ptr(ray_counts), _ptr(sample_key),
+                                                     audit_period, audit_phase, audit_fill_cap, audit_cycle, _ptr(ray_offsets), _ptr(ray_counts), _ptr(sample_key),
                                                      _ptr(sample_w), _ptr(total), _ptr(refined), _ptr(monitor)))
 
     def refresh_info(self) -> "Info":

@@ -119,8 +119,15 @@ enum {
                                    in the sampling kernel's epilogue and that buffer is not written */
   ADANERF_FLAG_WAVE_SELECT = 2, /* selection by the wave-per-ray kernel (the only one for numRaymarchSamples > 16) even where the
                                    lane-pair selection applies; implies the separate launch */
-  ADANERF_FLAG_NO_GUARD_CACHE = 4 /* ADANERF_SAMPLING_GUARDED: neither read nor write the calibration record next to the model
+  ADANERF_FLAG_NO_GUARD_CACHE = 4, /* ADANERF_SAMPLING_GUARDED: neither read nor write the calibration record next to the model
                                    (adanerf_guard_calibration_file); the band is measured at the first guarded frame */
+  ADANERF_FLAG_GUARD_AUDIT_FILL = 8 /* ADANERF_SAMPLING_GUARDED: audit only as many decided rays per frame as the last, partly filled
+                                   round of the refinement pass has room for (its grid x 128 rays per round; the undecided rays fix
+                                   the number of rounds), so that the audit never costs a round of its own -- what a small share
+                                   of a sharded frame wants (31 000 undecided rays of an 80 000-ray share are one round, 34 000 with
+                                   the full 1 / period quota two).  The audited window moves through the frame's audit candidates
+                                   from cycle to cycle, so every ray is still audited; how soon depends on the room the frames leave
+                                   (adanerf_stats.guard_audited counts).  Without the flag every frame audits its full quota. */
 };
 
 typedef struct adanerf_ctx adanerf_ctx;
@@ -304,7 +311,8 @@ int adanerf_collect_stats(adanerf_ctx* ctx, adanerf_stats* stats, int32_t* frame
 int adanerf_ray_features(adanerf_ctx* ctx, int32_t first_ray, int32_t n_rays,
                          float* d_features_out, float* d_rays_out);
 
-/* Fused ray generation + PE + sampling MLP -> raw oracle values [n_rays,128] fp32 (+ ray records). */
+/* Fused ray generation + PE + sampling MLP -> raw oracle values [n_rays,128] fp32 (+ ray records).  A model with
+ * multiDepthFeatures = D < 128 fills bins D..127 with -1e30 ("absent": never selected). */
 int adanerf_sample_mlp(adanerf_ctx* ctx, int32_t first_ray, int32_t n_rays,
                        float* d_oracle_out, float* d_rays_out);
 
@@ -323,7 +331,8 @@ int adanerf_compact(adanerf_ctx* ctx, const float* d_oracle, int32_t n_rays, int
 
 /* The guarded two-precision selection (ADANERF_SAMPLING_GUARDED) on caller-provided values, for tests: selects from
  * d_oracle_approx [n_rays,128] with the guard band (eps, eps_pair <= 0 -> 2 eps), lists the undecided rays plus the rays audited at
- * (audit_period, audit_phase) (audit_period <= 0: none), re-selects the undecided ones from d_oracle_exact [n_rays,128], compares
+ * (audit_period, audit_phase) (audit_period <= 0: none; audit_fill_cap > 0: only as many of them as fill the last round of
+ * audit_fill_cap rays, the window chosen by audit_cycle -- ADANERF_FLAG_GUARD_AUDIT_FILL), re-selects the undecided ones from d_oracle_exact [n_rays,128], compares
  * the audited decided ones, then compacts.  If the two bounds hold on every row the outputs equal adanerf_compact(d_oracle_exact, ...)
  * except that d_sample_w holds the approximate values on the rays that were not re-selected.  d_refined [1] int32: how many rays
  * were looked at again.  d_monitor (may be NULL) [5] uint32, ADDED to / maximised into (the caller zeroes it): [0] float bits of
@@ -332,7 +341,7 @@ int adanerf_compact(adanerf_ctx* ctx, const float* d_oracle, int32_t n_rays, int
  * n_max <= 16, thr > 0. */
 int adanerf_compact_guarded(adanerf_ctx* ctx, const float* d_oracle_approx, const float* d_oracle_exact, int32_t n_rays,
                             int32_t n_max, float thr, float eps, float eps_pair, int32_t audit_period, int32_t audit_phase,
-                            int32_t* d_ray_offsets, int32_t* d_ray_counts, uint32_t* d_sample_key, float* d_sample_w,
+                            int32_t audit_fill_cap, int32_t audit_cycle, int32_t* d_ray_offsets, int32_t* d_ray_counts, uint32_t* d_sample_key, float* d_sample_w,
                             int32_t* d_total, int32_t* d_refined, uint32_t* d_monitor);
 
 /* Calibrates the band of ADANERF_SAMPLING_GUARDED for the loaded model: n_poses cameras drawn inside the view cell

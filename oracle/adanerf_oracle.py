@@ -86,6 +86,7 @@ class Scene:
     # rayMarchSampler [LinearlySpacedZNearZFar, none]; num_samples_coarse uniform samples for net 0 (a NeRF net as well),
     # num_samples more from its weights for net 1
     num_samples_coarse: int = 0
+    depth_bins: int = 128                            # multiDepthFeatures: outputs of the sampling network = depth cells of the sampler (cell_size = 1 / D)
 
     @property
     def radius(self) -> float:
@@ -146,6 +147,8 @@ def load_scene(model_dir: str, num_samples: Optional[int] = None,
         sc.z_far = float(_parse_list(kv.get("zFar", "[1.0,1.0]"))[0])
     ls = _parse_list(kv.get("losses", "[NeRFWeightMultiplicationLoss,MSE]"))
     sc.losses0 = ls[0] if ls else "NeRFWeightMultiplicationLoss"
+    mdf = _parse_list(kv.get("multiDepthFeatures", "[128,128]"))
+    sc.depth_bins = int(mdf[-1]) if mdf else 128
     rsi = _parse_list(kv.get("raySampleInput", "[0,0]"))
     sc.ray_sample_input = int(rsi[0]) if rsi else 0
     if num_samples is not None:
@@ -286,7 +289,7 @@ def load_weights(model_dir: str) -> Weights:
 
 def synthetic_weights(seed: int, n_in0: int = 90, n_in1_pos: int = 63, n_in1_dir: int = 27,
                       oracle_bias: float = 0.0, oracle_scale: float = 1.0, alpha_bias: float = 0.0,
-                      layers: Tuple[int, int] = (8, 8), widths: Tuple[int, int] = (256, 256), skip1: int = 4) -> Weights:
+                      layers: Tuple[int, int] = (8, 8), widths: Tuple[int, int] = (256, 256), skip1: int = 4, bins: int = D_BINS) -> Weights:
     """Seeded Kaiming-normal weights in the exported layout (nn.init.kaiming_normal_ as
     src/models.py:77-78, 246-250: std = sqrt(2/fan_in)); biases U(-1/sqrt(fan_in), ..) like
     nn.Linear's default.  ``oracle_bias`` is added to the sampling net's last bias so a
@@ -303,7 +306,7 @@ def synthetic_weights(seed: int, n_in0: int = 90, n_in1_pos: int = 63, n_in1_dir
 
     n0: Dict[str, np.ndarray] = {}
     d0, w0 = layers[0], widths[0]
-    dims = [n_in0] + [w0] * (d0 - 1) + [D_BINS]
+    dims = [n_in0] + [w0] * (d0 - 1) + [bins]
     for i in range(d0):
         w, b = lin(dims[i + 1], dims[i], oracle_scale if i == d0 - 1 else 1.0)
         if i == d0 - 1:
@@ -375,7 +378,7 @@ def write_model_dir(path: str, scene: Scene, weights: Weights) -> None:
         f.write("zNear = [%r, %r]\n" % (scene.z_near, scene.z_near))
         f.write("zFar = [%r, %r]\n" % (scene.z_far, scene.z_far))
         f.write("adaptiveSamplingThreshold = %r\n" % scene.threshold)
-        f.write("multiDepthFeatures = [128, 128]\n")
+        f.write("multiDepthFeatures = [%d, %d]\n" % (scene.depth_bins, scene.depth_bins))
         f.write("multiDepthIgnoreValue = [1.01, 1.01]\n")
         f.write("accumulationMult = %s\n" % scene.accumulation_mult)
         f.write("useNDC = %s\n" % ("True" if scene.use_ndc else "False"))
@@ -696,6 +699,30 @@ def guard_audit_bits(period: int, phase: int, seg: int) -> int:
     return (pattern << ((phase + seg) & (period - 1))) & 0xFFFFFFFF
 
 
+def guard_refine_list(undecided: np.ndarray, period: int, phase: int, cap_round: int = 0, cycle: int = 0):
+    """The list pass 2 of the guarded selection works through (k_compact.hip.hpp refine_list_kernel), restated: ``undecided`` bool [R].
+    Returns (rays int32 ascending, audit_only bool) -- every undecided ray, plus the decided rays audited at (period, phase): all of
+    them, or with ``cap_round`` > 0 (ADANERF_FLAG_GUARD_AUDIT_FILL) only as many as the last round of ``cap_round`` rays has room for
+    beside the undecided ones, taken as a window of the audit candidates (in ray order) that starts at (cycle * room) mod candidates
+    and wraps round."""
+    und = np.asarray(undecided, bool)
+    r = np.arange(und.shape[0])
+    aud = np.zeros_like(und) if period <= 0 else ((((r & 31) - phase - (r >> 5)) & (period - 1)) == 0) & ~und
+    cand = np.flatnonzero(aud)
+    if cap_round > 0:
+        n_und = int(und.sum())
+        rounds = max(1, -(-n_und // cap_round))
+        room = min(cand.size, max(0, rounds * cap_round - n_und))
+        if room < cand.size:
+            off = (cycle * room) % cand.size if room > 0 else 0
+            keep = ((np.arange(cand.size) - off) % cand.size) < room
+            aud = np.zeros_like(und)
+            aud[cand[keep]] = True
+    take = und | aud
+    rays = np.flatnonzero(take).astype(np.int32)
+    return rays, aud[rays]
+
+
 def compact(count: np.ndarray, bins: np.ndarray, wts: np.ndarray):
     """Ray-major, depth-ascending flat order == ``embedded[mapping]`` order of
     src/features.py:438-446, 481-484.  Returns (ray_offset [R] int32 exclusive prefix,
@@ -708,10 +735,10 @@ def compact(count: np.ndarray, bins: np.ndarray, wts: np.ndarray):
     return off.astype(np.int32), ray, bins[mask].astype(np.int16), wts[mask].astype(F32)
 
 
-def bin_t(bins: np.ndarray) -> np.ndarray:
-    """(k + .5) * cell_size with cell_size = 1/128 in float32
-    (src/nerf_raymarch_common.py:722-723, 737-741)."""
-    return ((bins.astype(F32) + F32(0.5)) * F32(1.0 / D_BINS)).astype(F32)
+def bin_t(bins: np.ndarray, n_bins: int = D_BINS) -> np.ndarray:
+    """(k + .5) * cell_size with cell_size = 1 / multiDepthFeatures (128 in every shipped config) in float32
+    (src/nerf_raymarch_common.py:726-727, 737-741)."""
+    return ((bins.astype(F32) + F32(0.5)) * F32(1.0 / n_bins)).astype(F32)
 
 
 def dense_t(scene: Scene, n: int = D_BINS) -> np.ndarray:
@@ -1077,7 +1104,7 @@ def render_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: 
             tt = np.repeat(dense_t(scene)[None], r, 0)
         else:
             count, bins, wts = select_adaptive(orc_t, scene.num_samples, scene.threshold)
-            tt = bin_t(bins)
+            tt = bin_t(bins, scene.depth_bins)
         off, sray, sbin, sw = compact(count, bins, wts)
         mask = np.arange(bins.shape[1])[None, :] < count[:, None]
         z = to_world_depth(tt[mask], scene)

@@ -66,11 +66,11 @@ def make_config(scene: O.Scene, weights=None):
         inFeatures=["SpherePosDir", "RayMarchFromPoses"], outFeatures=["Raw", "RGBARayMarch"],
         posEnc=["nerf", "nerf"],
         posEncArgs=["%d-%d" % scene.pos_enc[0], "%d-%d" % scene.pos_enc[1]],
-        raySampleInput=[scene.ray_sample_input, 0], multiDepthFeatures=[128, 128], multiDepthIgnoreValue=[1.01, 1.01],
+        raySampleInput=[scene.ray_sample_input, 0], multiDepthFeatures=[scene.depth_bins, scene.depth_bins], multiDepthIgnoreValue=[1.01, 1.01],
         multiDepthWindowSize=[], activation=["relu", "nerf"], layers=layers, layerWidth=widths,
         skips=skips, losses=[scene.losses0, "MSE"],
         numRaymarchSamples=[n, n], rayMarchSampler=["none", sampler],
-        rayMarchSamplingStep=[1 / 128.0, 1 / 128.0], rayMarchSamplingNoise=[0.0, 0.0],
+        rayMarchSamplingStep=[1.0 / scene.depth_bins, 1.0 / scene.depth_bins], rayMarchSamplingNoise=[0.0, 0.0],
         rayMarchNormalization=["InverseSqrtDistCentered", scene.normalization] if scene.normalization else [],
         rayMarchNormalizationCenter=list(scene.normalization_center), adaptiveSamplingThreshold=scene.threshold,
         accumulationMult=scene.accumulation_mult if scene.sampler != "FromClassifiedDepth" else None, zNear=[scene.z_near, scene.z_near],
@@ -103,7 +103,7 @@ def build_reference(R, scene: O.Scene, weights: O.Weights, w, h):
     tc = R.train_data.TrainConfig()
     tc.f_in, tc.f_out = f_in, f_out
     n_in = [f.n_feat for f in f_in]
-    m0 = R.models.ModelSelection.getModel(cfg, n_in[0], 128, "cpu", 0)
+    m0 = R.models.ModelSelection.getModel(cfg, n_in[0], scene.depth_bins, "cpu", 0)
     m1 = R.models.ModelSelection.getModel(cfg, n_in[1], 4, "cpu", 1)
     d1, sk = O.shading_topology(weights.net1, 3 + 6 * scene.pos_enc[1][0])
     if len(sk) > 1:
@@ -177,7 +177,7 @@ def z_to_bins(z_slot, count, scene: O.Scene, n_max):
     else:
         d0, d1 = scene.depth_range
         t = (z - d0) / (d1 - d0)
-    k = np.rint(t * 128.0 - 0.5).astype(np.int64)
+    k = np.rint(t * float(scene.depth_bins) - 0.5).astype(np.int64)
     mask = np.arange(n_max)[None, :] < count[:, None]
     return np.where(mask, k, -1).astype(np.int16)
 
@@ -221,6 +221,7 @@ def save_case(name, scene, meta, dirs, pose, rot, ref, n_max, weights_tag):
                   pos_enc=[list(scene.pos_enc[0]), list(scene.pos_enc[1])],
                   normalization=scene.normalization, accumulation_mult=scene.accumulation_mult,
                   **({"normalization_center": list(scene.normalization_center)} if scene.normalization_center else {}),
+                  **({"depth_bins": scene.depth_bins} if scene.depth_bins != 128 else {}),
                   sampler=scene.sampler, losses0=scene.losses0, ray_sample_input=scene.ray_sample_input, weights=weights_tag))
     n_f = min(64, ref["feat0"].shape[0], max(4, 65536 // ref["feat0"].shape[1]))
     m_f = min(64, ref["feat1"].shape[0])
@@ -613,6 +614,18 @@ def main():
         tc = build_reference(R, sc, w_class, 800, 800)
         ref = run_reference(R, tc, dirs, pose, rot)
         save_case(name, sc, dict(w=800, h=800, crop=[30, 44, 24, 16, 32], yaw=100.0, pitch=0.0), dirs, pose, rot, ref, 8, "sample_pavillon_16")
+
+    # --- cases W1, W2 (SURVEY 8f N4 residuals): multiDepthFeatures != 128 -- a sampling network with 64 / 100 outputs, the adaptive
+    #     sampler over that many depth cells (cell_size = 1 / D, src/nerf_raymarch_common.py:675-677, 726-741)
+    for name, nb, n, thr in [("syn_bins64_n8", 64, 8, 0.65), ("syn_bins100_n6", 100, 6, 0.6)]:
+        sc = dataclasses.replace(classroom_scene(n, thr), depth_bins=nb)
+        syn = dict(seed=41 + nb, oracle_bias=0.1, oracle_scale=0.3, bins=nb)
+        wts = O.synthetic_weights(syn["seed"], n_in0=sc.n_in0, oracle_bias=syn["oracle_bias"], oracle_scale=syn["oracle_scale"], bins=nb)
+        dirs = subset_dirs(400, 400, sc.fov, 12, 20, 24, 16, 16)
+        tc = build_reference(R, sc, wts, 400, 400)
+        ref = run_reference(R, tc, dirs, pose, rot)
+        save_case(name, sc, dict(w=400, h=400, crop=[12, 20, 24, 16, 16], yaw=100.0, pitch=0.0, syn=dict(syn, n_in0=sc.n_in0)),
+                  dirs, pose, rot, ref, n, "synthetic")
 
     # --- cases O, P: small crops that carry the secondary compositing outputs (all cases written from now on do)
     sc = classroom_scene(8, 0.2)

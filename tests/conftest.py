@@ -29,7 +29,7 @@ def load_case(name):
                  accumulation_mult=meta["accumulation_mult"],
                  sampler=meta.get("sampler", "FromClassifiedDepthAdaptive"),
                  losses0=meta.get("losses0", "NeRFWeightMultiplicationLoss"), ray_sample_input=meta.get("ray_sample_input", 0),
-                 num_samples_coarse=meta.get("num_samples_coarse", 0))
+                 num_samples_coarse=meta.get("num_samples_coarse", 0), depth_bins=meta.get("depth_bins", 128))
     return z, meta, sc
 
 
@@ -47,7 +47,8 @@ def case_weights(meta):
         return O.synthetic_weights(s["seed"], n_in0=s.get("n_in0", 90), n_in1_pos=3 + 6 * meta["pos_enc"][1][0],
                                    n_in1_dir=3 + 6 * meta["pos_enc"][1][1], oracle_bias=s["oracle_bias"],
                                    oracle_scale=s["oracle_scale"], alpha_bias=s.get("alpha_bias", 0.0),
-                                   layers=tuple(s.get("layers", (8, 8))), widths=tuple(s.get("widths", (256, 256))), skip1=s.get("skip1", 4))      # skip1: an index or a list of them
+                                   layers=tuple(s.get("layers", (8, 8))), widths=tuple(s.get("widths", (256, 256))), skip1=s.get("skip1", 4),      # skip1: an index or a list of them
+                                   bins=s.get("bins", 128))
     z = np.load(os.path.join(GOLD, "weights_%s.npz" % tag))
     n0 = {k[3:]: z[k] for k in z.files if k.startswith("n0/")}
     n1 = {k[3:]: z[k] for k in z.files if k.startswith("n1/")}
@@ -97,5 +98,7 @@ ENCODING_CASES = ["syn_enc_6-3_12-2", "syn_enc_16-1_1-16"]
 # SURVEY 8f N4 residuals: every rayMarchNormalization the reference knows, a custom centre, and a config without the key
 NORM_CASES = ["classroom_norm_none", "classroom_norm_centered", "classroom_norm_maxdepth", "classroom_norm_maxdepthcentered",
               "classroom_norm_logcentered", "classroom_norm_inversedistcentered", "classroom_norm_isd_custom_centre", "classroom_norm_key_absent"]
+# multiDepthFeatures != 128: a sampling network with 64 / 100 depth cells (the device pads the rows to 128 absent bins)
+BINS_CASES = ["syn_bins64_n8", "syn_bins100_n6"]
 COARSE_FINE_CASES = ["classroom_coarse_fine_16_24", "ndc_coarse_fine_12_20"]      # vanilla NeRF, hierarchical sampling
 AUX_CASES = ["classroom_n8_aux", "ndc_n8_aux", "classroom_n8_mult_weights", "classroom_n8_bce_thr06", "ndc_pdf_n8", "classroom_pdf_ce_n8"]

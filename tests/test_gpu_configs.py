@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import adanerf_oracle as O
-from conftest import AUX_CASES, COARSE_FINE_CASES, ENCODING_CASES, MULT_CASES, NORM_CASES, ROOT, TOPOLOGY_CASES, case_weights, check_identical, load_case, record, residual_budget
+from conftest import AUX_CASES, BINS_CASES, COARSE_FINE_CASES, ENCODING_CASES, MULT_CASES, NORM_CASES, ROOT, TOPOLOGY_CASES, case_weights, check_identical, load_case, record, residual_budget
 
 import adanerf_amd
 from adanerf_amd import renderer as R
@@ -491,6 +491,49 @@ def test_context_lifecycle_returns_all_device_memory(tmp_path_factory):
     for _ in range(6):
         cycle()
     assert abs(free_bytes() - base) <= 8 << 20, (base, free_bytes())      # 90 contexts later: within 8 MiB
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY 8f N4 residuals: multiDepthFeatures != 128 (the adaptive sampler over 64 / 100 depth cells)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", BINS_CASES)
+def test_fewer_depth_cells_match_the_reference(name, tmp_path_factory):
+    """A sampling network with D < 128 outputs on the device (rows padded with absent bins, pack.cpp): raw outputs against the
+    reference-generated fixture in every sampling mode, the absent bins marked, the selection (counts, bins, kept values) bit for bit
+    through the frame path incl. the guarded two-precision mode, sample depths with cell_size = 1 / D, fp32 colours."""
+    from test_gpu_parity import run_rows
+    z, meta, sc = load_case(name)
+    wts = case_weights(meta)
+    D, N = sc.depth_bins, sc.num_samples
+    d = _dir(tmp_path_factory, sc, wts, "bins_" + name)
+    x0, y0, cw, ch, stride = meta["crop"]
+    idx = ((y0 + stride * np.arange(ch))[:, None] * meta["w"] + (x0 + stride * np.arange(cw))[None, :]).reshape(-1)
+    for smp, tol in (("split", 2e-4), ("fp32", 2e-4), ("fp16", 2e-2)):
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, meta["w"], meta["h"]), precision="bf16", sampling=smp) as r:
+            r.set_camera(z["pose"], z["rot"])
+            orc = run_rows(r, meta, lambda f, n, b: r.sample_mlp(f, n, b, None), 128)
+        np.testing.assert_allclose(orc[:, :D], z["oracle_out"], rtol=0, atol=tol)
+        assert (orc[:, D:] <= -9e29).all()
+    for prec, smp in (("fp32", "split"), ("bf16", "guarded"), ("bf16", "split")):
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, meta["w"], meta["h"]), precision=prec, sampling=smp) as r:
+            r.set_camera(z["pose"], z["rot"])
+            rgb, _, st = r.render_numpy()
+            n = meta["w"] * meta["h"]
+            cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (n,))
+            off = r.buffer(R.BUF_RAY_OFFSETS, np.int32, (n,))
+            key = r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (int(st.total_samples),))
+            assert st.guard_violations == 0 and st.guard_audit_mismatch == 0
+        check_identical(cnt[idx] == z["sel_count"], "bins_counts", 0, case=name, mode=smp)
+        assert int((key & 127).max()) < D
+        bins = np.full((len(idx), N), -1, np.int16)
+        for k, i in enumerate(idx):
+            bins[k, :cnt[i]] = (key[off[i]:off[i] + cnt[i]] & 127).astype(np.int16)
+        check_identical((bins == z["sel_bins"]).all(axis=1), "bins_bins", 0, case=name, mode=smp)
+        if prec == "fp32":
+            err = float(np.abs(rgb[idx] - z["rgb"]).max())
+            record("fewer_depth_cells_frame", case=name, max_abs_rgb_err=err)
+            assert err < 3e-4, err
 
 
 # ---------------------------------------------------------------------------------------------

@@ -529,7 +529,7 @@ def test_fused_selection_equals_separate_launches(cases, name, w, h, bs, samplin
 # A3 + A4, guarded two-precision selection (ADANERF_SAMPLING_GUARDED)
 # ---------------------------------------------------------------------------------------------
 
-def _gpu_compact_guarded(r, approx, exact, n_max, thr, eps, eps_pair=0.0, audit_period=0, audit_phase=0, monitor=False):
+def _gpu_compact_guarded(r, approx, exact, n_max, thr, eps, eps_pair=0.0, audit_period=0, audit_phase=0, monitor=False, fill_cap=0, cycle=0):
     n = approx.shape[0]
     d_a, d_e = r.to_device(approx), r.to_device(exact)
     off, cnt = r.empty((n,), np.int32), r.empty((n,), np.int32)
@@ -537,7 +537,7 @@ def _gpu_compact_guarded(r, approx, exact, n_max, thr, eps, eps_pair=0.0, audit_
     tot, ref = r.empty((1,), np.int32), r.empty((1,), np.int32)
     mon = r.to_device(np.zeros(5, np.uint32)) if monitor else None
     r.compact_guarded(d_a, d_e, n, n_max, thr, eps, off, cnt, key, w, tot, ref, eps_pair=eps_pair, audit_period=audit_period,
-                      audit_phase=audit_phase, monitor=mon)
+                      audit_phase=audit_phase, monitor=mon, audit_fill_cap=fill_cap, audit_cycle=cycle)
     t = int(tot.numpy()[0])
     out = (off.numpy(), cnt.numpy(), key.numpy()[:t], w.numpy()[:t], t, int(ref.numpy()[0]))
     if monitor:
@@ -774,6 +774,46 @@ def test_guard_calibration(cases):
     record("guard_calibration", calibrated_max=a, calibrated_pair_max=ap, eps=eps, frame_max_diff=frame_max, frame_max_pair_error=frame_pair)
     assert frame_max <= eps and frame_pair <= min(max(2.0 * ap, 1e-3), 2 * eps)
     assert O.psnr(rgb, rgb_s) > 60.0
+
+
+def test_guard_audit_fill_on_constructed_rows(cases):
+    """ADANERF_FLAG_GUARD_AUDIT_FILL at the stage level: the device's list (its length, and through the monitor how many of its
+    entries were audited decided rays and which of them carried an error) equals the oracle's restatement (guard_refine_list) for
+    every phase and cycle; the listed audit window fills the last round exactly; over the cycles of a phase every candidate's
+    planted error is reported once; outputs never move."""
+    rng = np.random.default_rng(9)
+    n_max, thr, eps, R, cap = 8, 0.2, 0.004, 12000 + 7, 2048
+    exact = _peaky_rows(rng, R, thr)
+    approx = exact.copy()
+    und = O.guard_undecided(approx, n_max, thr, eps)
+    # an error beyond the band on EVERY decided ray (a constant offset on its smallest value: selections unchanged, bound violated)
+    dec = np.flatnonzero(~und)
+    approx[dec, np.argmin(approx[dec], axis=1)] -= np.float32(0.05)
+    assert np.array_equal(O.guard_undecided(approx, n_max, thr, eps), und)
+    z, meta, sc, wts, dpath = cases["classroom_n8_thr02"]
+    n_und = int(und.sum())
+    rounds = max(1, -(-n_und // cap))
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(dpath, 16, 16), precision="bf16") as r:
+        base = _gpu_compact_guarded(r, approx, exact, n_max, thr, eps, monitor=True)
+        for phase in (0, 7):
+            full, full_a = O.guard_refine_list(und, 16, phase)
+            cand = int(full_a.sum())
+            room = min(cand, rounds * cap - n_und)
+            cycles = -(-cand // room)
+            assert 0 < room < cand and cycles >= 2          # the test population makes the window smaller than the quota
+            audited = 0
+            for cycle in range(cycles):
+                out = _gpu_compact_guarded(r, approx, exact, n_max, thr, eps, audit_period=16, audit_phase=phase, monitor=True, fill_cap=cap, cycle=cycle)
+                rays, a = O.guard_refine_list(und, 16, phase, cap, cycle)
+                assert out[5] == rays.size == rounds * cap and out[6]["audited"] == int(a.sum()) == room
+                assert out[6]["violations"] == room and out[6]["audit_mismatch"] == 0      # every audited decided ray shows its planted error
+                for x, y in zip(out[:5], base[:5]):
+                    assert np.array_equal(x, y)
+                audited += out[6]["audited"]
+            assert audited >= cand                          # the windows of the cycles cover the phase's candidates (the last one wraps)
+        full_quota = _gpu_compact_guarded(r, approx, exact, n_max, thr, eps, audit_period=16, audit_phase=0, monitor=True)
+    assert full_quota[5] == n_und + int(O.guard_refine_list(und, 16, 0)[1].sum()) > rounds * cap      # without the flag: a further round
+    record("guard_audit_fill_rows", rays=R, undecided=n_und, cap_round=cap, rounds=rounds, refined_with_full_quota=full_quota[5])
 
 
 def test_guard_calibration_record(cases, tmp_path, monkeypatch):

@@ -174,3 +174,33 @@ def test_audit_rotation_covers_every_ray_once_per_period(period):
     if period > 1:
         assert O.guard_audit_bits(period, 0, 0) != O.guard_audit_bits(period, 0, 1)
     assert O.guard_audit_bits(0, 3, 7) == 0
+
+
+def test_audit_fill_never_adds_a_round_and_starves_no_ray():
+    """ADANERF_FLAG_GUARD_AUDIT_FILL (restated in guard_refine_list): the list is every undecided ray plus a window of the frame's audit
+    candidates that exactly fills the last round of the refinement pass (or all candidates when they fit); the window moves on by its
+    own length from cycle to cycle, so over ceil(candidates / room) cycles of one phase every candidate has been audited."""
+    rng = np.random.default_rng(3)
+    R, period, cap = 20000, 16, 4096
+    for frac in (0.02, 0.19, 0.21, 0.39, 0.41, 0.97):
+        und = rng.random(R) < frac
+        n_und = int(und.sum())
+        rounds = max(1, -(-n_und // cap))
+        for phase in (0, 5, 15):
+            full, full_a = O.guard_refine_list(und, period, phase)
+            cand = full[full_a]
+            assert np.array_equal(full[~full_a], np.flatnonzero(und)) and (np.diff(full) > 0).all()
+            seen = np.zeros(R, bool)
+            room = min(cand.size, rounds * cap - n_und)
+            cycles = 1 if room >= cand.size else (-(-cand.size // room) if room else 0)
+            for cycle in range(cycles):
+                rays, a = O.guard_refine_list(und, period, phase, cap, cycle)
+                assert (np.diff(rays) > 0).all() and np.array_equal(rays[~a], np.flatnonzero(und))
+                assert a.sum() == room and rays.size <= rounds * cap and np.isin(rays[a], cand).all()
+                assert rays.size == rounds * cap or room == cand.size          # the last round is full, or every candidate is in
+                seen[rays[a]] = True
+            if room:
+                assert seen[cand].all(), "audit candidates left out for good"
+    # nothing undecided: one round's worth of audit still runs
+    rays, a = O.guard_refine_list(np.zeros(R, bool), period, 3, cap, 0)
+    assert a.all() and rays.size == min(cap, R // period)

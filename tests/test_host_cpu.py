@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import adanerf_oracle as O
-from conftest import ENCODING_CASES, ROOT, TOPOLOGY_CASES, case_weights, load_case
+from conftest import BINS_CASES, ENCODING_CASES, ROOT, TOPOLOGY_CASES, case_weights, load_case
 from mfma_emulation import (PackedNet, pack_weights, run_sampling_net, run_sampling_net_generic, run_shading_net,
                             run_shading_net_generic)
 
@@ -232,6 +232,40 @@ def test_depth_table_matches_oracle(lib, tmp_path):
         assert lib.adanerf_host_depth_table(d.encode(), C.byref(o), z.ctypes.data) == 0, lib.adanerf_last_error(None)
         t = O.dense_t(sc) if sc.threshold == 0.0 else O.bin_t(np.arange(128))
         np.testing.assert_allclose(z, O.to_world_depth(t, sc), rtol=3e-7, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", BINS_CASES)
+def test_fewer_depth_cells_pack_as_absent_bins(lib, tmp_path, name):
+    """multiDepthFeatures = D < 128 (reference-generated fixtures): the sampling network packs into 128-wide output rows whose bins D..127 are
+    "absent" (zero weights, bias -1e30: no threshold, arg-max or softmax ever picks them); replayed through the kernels' dataflow in numpy
+    the first D outputs are the reference's, the selection from the padded rows is the reference's selection, and the depth table has
+    cell_size = 1 / D (src/nerf_raymarch_common.py:726-741).  Dense mode, the inverse-CDF sampler and mismatching config / network are refused."""
+    import dataclasses
+    z, meta, sc = load_case(name)
+    wts = case_weights(meta)
+    D = sc.depth_bins
+    assert D < 128 and z["oracle_out"].shape[1] == D
+    d, _, _ = _model_dir(tmp_path, sc, wts, name=name)
+    lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+    info = R.Info()
+    assert lib.adanerf_host_parse_model(d.encode(), C.byref(_opts(width=meta["w"], height=meta["h"])), C.byref(info)) == 0, lib.adanerf_last_error(None)
+    n = 64
+    nds = z["nds"][:n]
+    u = (nds / np.sqrt(np.sum(nds * nds, -1, keepdims=True))).astype(np.float32)
+    for prec, tol in ((2, 1e-4), (3, 1e-4)):
+        w, b, lay = pack_weights(lib, d, 0, prec)
+        orc = run_sampling_net(PackedNet(w, b, lay, prec), u, z["p"][:n], *sc.pos_enc[0])
+        np.testing.assert_allclose(orc[:, :D], z["oracle_out"][:n], rtol=0, atol=tol)
+        assert (orc[:, D:] == np.float32(-1e30)).all()
+        cnt, bins, wv = O.select_adaptive(orc, sc.num_samples, sc.threshold)
+        assert np.array_equal(cnt, z["sel_count"][:n]) and np.array_equal(bins, z["sel_bins"][:n])
+    lib.adanerf_host_depth_table.argtypes = [C.c_char_p, C.POINTER(R._Options), C.c_void_p]
+    zt = np.zeros(128, dtype=np.float32)
+    assert lib.adanerf_host_depth_table(d.encode(), C.byref(_opts()), zt.ctypes.data) == 0
+    np.testing.assert_allclose(zt[:D], O.to_world_depth(O.bin_t(np.arange(D), D), sc), rtol=3e-7, atol=1e-6)
+    for k, sc_bad in enumerate((dataclasses.replace(sc, threshold=0.0, num_samples=128), dataclasses.replace(sc, sampler="FromClassifiedDepth", losses0="BCEWithLogitsLoss"))):
+        dd, _, _ = _model_dir(tmp_path, sc_bad, wts, name="%s_bad%d" % (name, k))
+        assert lib.adanerf_host_parse_model(dd.encode(), C.byref(_opts()), C.byref(info)) == -4 and b"multiDepthFeatures" in lib.adanerf_last_error(None)
 
 
 @pytest.mark.parametrize("precision,tol", [(2, 2e-4), (1, 3e-2), (0, 2e-1)])

@@ -43,7 +43,8 @@ for world in worlds:
             r.set_profiling(False)
             rec = dict(world=world, rank=rank, rays=r.info.rays_local, samples=st.total_samples / frames, wall_ms=wall,
                        sample_ms=st.ms_sample_mlp / frames, compact_ms=st.ms_compact / frames,
-                       shade_ms=st.ms_shade_mlp / frames, composite_ms=st.ms_composite / frames)
+                       shade_ms=st.ms_shade_mlp / frames, composite_ms=st.ms_composite / frames,
+                       rays_refined=st.rays_refined / frames, audited_total=int(st.guard_audited))
             rows.append(rec)
             print(json.dumps(rec), flush=True)
 base = rows[0]["wall_ms"] if worlds[0] == 1 else float("nan")

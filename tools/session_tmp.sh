@@ -1,3 +1,4 @@
-O=$PWD/gpurun_out/r04_s9; mkdir -p $O; R=$PWD; export ADANERF_MEASURED_LOG=$O/parity_measured.log
-timeout 900 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; tail -n 6 $O/pytest_gpu.log
-( time FUZZ_ROUND2=1 FUZZ_ROUND3=1 timeout 900 python tests/fuzz_parity.py 150 7002 ) > $O/fuzz_150_seed7002.log 2>&1; tail -n 5 $O/fuzz_150_seed7002.log; grep "FAIL" $O/fuzz_150_seed7002.log | head -20
+O=$PWD/gpurun_out/r04_s18; mkdir -p $O
+for wl in generic_6x128 generic_5x256 generic_4x64; do
+  echo "== $wl"; BENCH_ARGS="--no-speed-mode --no-exact-mode --no-sustained-probe --workload $wl" STEPS=10 bash tools/run_variants.sh
+done 2>&1 | tee $O/variants_generic_ablate_bias.log
