@@ -61,6 +61,7 @@ struct adanerf_ctx {
   int guard_mism_seen = 0;
   int guard_widened = 0;
   uint32_t guard_frame = 0;              // frames rendered in guarded mode: the audit's rotating phase
+  int debug_guard = 0;                   // $ADANERF_DEBUG_GUARD at create (measurement knob, bit 0: no whole-row monitor)
   std::string model_dir;
   uint64_t model0_hash = 0;              // FNV-1a 64 of model0.onnx: key of the calibration record
   adanerf_stats folded{};                // profiling record folded out of a full event pool (see adanerf_render)
@@ -620,9 +621,7 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
     a.sel.audit_phase = c->guard_audit_period > 0 ? static_cast<int32_t>(c->guard_frame & static_cast<uint32_t>(c->guard_audit_period - 1)) : 0;
     a.sel.guard_probe = reinterpret_cast<float*>(c->guard_probe.p);
     a.sel.guard_rows = reinterpret_cast<float*>(c->oracle.p);      // free on this path: the selection is fused, nobody else writes the oracle buffer
-    if (const char* dbg = std::getenv("ADANERF_DEBUG_GUARD")) {      // measurement knob (profiles/r04_guard_monitor_cost.md): 1 = no whole-row monitor
-      if (std::atoi(dbg) & 1) a.sel.guard_rows = nullptr;
-    }
+    if (c->debug_guard & 1) a.sel.guard_rows = nullptr;      // measurement knob (profiles/r04_guard_monitor_cost.md): no whole-row monitor
     a.sel.guard_seen = reinterpret_cast<uint32_t*>(c->total.p) + 8;
   }
   if (c->sampling_mode == 1) {
@@ -1223,6 +1222,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   }
   c->sampling_mode = opt->sampling_mode;
   c->model_dir = model_dir;
+  if (const char* dbg = std::getenv("ADANERF_DEBUG_GUARD")) c->debug_guard = std::atoi(dbg);
   c->guard_eps = opt->guard_eps > 0.f ? opt->guard_eps : 0.f;      // 0: the model's calibration record, or calibrated before the first guarded frame
   c->guard_eps_pair = (c->guard_eps > 0.f && opt->guard_eps_pair > 0.f) ? std::min(opt->guard_eps_pair, 2.0f * c->guard_eps) : 2.0f * c->guard_eps;
   c->guard_audit_period = opt->guard_audit_period == 0 ? ADANERF_GUARD_AUDIT_PERIOD : std::max(opt->guard_audit_period, 0);
