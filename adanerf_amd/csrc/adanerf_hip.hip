@@ -172,6 +172,7 @@ int upload_net(adanerf_ctx* c, const PackedNet& pn, PackedDev* d) {
     d->params.w_off[i] = pn.w_off[i];
     d->params.b_off[i] = pn.b_off[i];
   }
+  d->params.n_bias = static_cast<uint32_t>(pn.bias.size());
   return ADANERF_OK;
 }
 
@@ -1014,6 +1015,9 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
     const int nb_wg = !st ? 1 : topo.width == 64 ? gen_blocks<64>() : topo.width == 128 ? gen_blocks<128>() : gen_blocks<256>();
     const int per_wg = 128 * nb_wg;
     const int tiles = (max_samples + per_wg - 1) / per_wg;
+    const uint32_t bias_cap = topo.width == 64 ? gen_bias_cap<64>() : topo.width == 128 ? gen_bias_cap<128>() : gen_bias_cap<256>();
+    if (st && a.net.n_bias > bias_cap)      // cannot happen for depth <= 8 (pack.hpp kMaxDepth): the kernel keeps the whole table in LDS
+      return fail(c, ADANERF_EUNSUPPORTED, "shading network: bias table exceeds the kernel's LDS capacity");
     int& grid16 = c->shade_gen16_grid[coarse ? 1 : 0][prec == ADANERF_PREC_BF16 ? 0 : 1];
 #define ADN_GEN16_GO(KERNEL)                                                                                             \
   do {                                                                                                                   \

@@ -26,6 +26,7 @@ struct NetParams {
   const float* bias;         // packed bias blocks
   uint32_t w_off[kMaxLayers];
   uint32_t b_off[kMaxLayers];
+  uint32_t n_bias;           // floats in `bias` (the run-time-shaped kernels copy the whole table to LDS once per workgroup)
 };
 
 // Everything ray generation needs (A1 + A2).  Doubles mirror the float64 numpy ray table of

@@ -172,13 +172,36 @@ __device__ __forceinline__ void bias_request(const float* __restrict__ bias_tile
   }
 }
 
+// The shading kernel keeps the network's whole bias table in LDS (copied once per workgroup; <= gen_bias_cap<W>() floats: depth + 3
+// layers of at most W + 32 outputs) and reads a tile's block [m][h][16] with four ds_read_b128 a tile ahead.  As global loads (until
+// round 4) the four 1 KiB-wide requests per tile went through the same vector-memory path as the weight copies -- 4 of the 6 VMEM
+// instructions per tile, all 32 lanes of a half fetching the same 64 bytes -- and, worse, made hipcc wait for them with a counted
+// vmcnt that also covered the copy of the NEXT tile issued in between (its piece count is a run-time value, so the compiler could not
+// leave it in flight): every tile waited for the L2 -> LDS round trip of the tile after it (profiles/r04_generic_bias_loads.md).
+template <int W>
+constexpr int gen_bias_cap() {
+  return 10 * W + 256;
+}
+__device__ __forceinline__ void bias_request_lds(uint32_t tile_addr, int h, float (&br)[16]) {      // tile_addr: LDS byte address of block [m][0][0]
+  typedef const __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
+  const lds_f32x4_ptr bp = (lds_f32x4_ptr)(uintptr_t)(tile_addr + h * 64);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 v = bp[g];
+    br[4 * g + 0] = v[0];
+    br[4 * g + 1] = v[1];
+    br[4 * g + 2] = v[2];
+    br[4 * g + 3] = v[3];
+  }
+}
+
 // One 16-bit layer for NB blocks of 32 samples per wave, every fragment read once from LDS and used NB times.
 // in1 / in2 / out: NB register arrays of I1 / I2 / O dwords each.  br: bias block of the tile about to run (requested a tile ago).
-// (next_off, next_frags, next_bias): first tile of the layer that follows.
-template <class ET, int NB, int BUF_BYTES, int S1, int S2, int MT, bool RELU, int I1, int I2, int O, int KEEP_F32_TILE = -1>
-__device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], uint32_t w_off, const float* __restrict__ bias, int lane,
+// (next_off, next_frags, next_bias): first tile of the layer that follows.  bias / next_bias: LDS byte addresses (bias_request_lds).
+template <class ET, int NB, int BUF_BYTES, int S1, int S2, int MT, bool RELU, int I1, int I2, int O, int KEEP_F32_TILE = -1, bool LDSB = true>
+__device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], uint32_t w_off, uint32_t bias, int lane,
                                                 const uint32_t* in1, const uint32_t* in2, uint32_t* out, uint32_t next_off, int next_frags,
-                                                const float* __restrict__ next_bias, f32x16* keep = nullptr) {
+                                                uint32_t next_bias, f32x16* keep = nullptr, const float* __restrict__ gbias = nullptr) {
   constexpr int KS = S1 + S2, D = KS < kStageAhead ? KS : kStageAhead;
   static_assert(KS * 1024 <= BUF_BYTES, "tile does not fit its LDS buffer");
   const int h = lane >> 5;
@@ -194,7 +217,14 @@ __device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], 
     u32x4 fr[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) fr[i] = lds_read128(rd + i * 1024);
-    bias_request(last ? next_bias : bias + (m + 1) * 32, h, br);
+    if (tune::kAblateGeneric & 2) {      // timing ablation: no bias reads at all
+#pragma unroll
+      for (int r = 0; r < 16; ++r) br[r] = 0.f;
+    } else if constexpr (LDSB) {
+      bias_request_lds(last ? next_bias : bias + (m + 1) * 128, h, br);
+    } else {      // table in global memory: bias / next_bias are byte offsets into it
+      bias_request(gbias + ((last ? next_bias : bias + (m + 1) * 128) >> 2), h, br);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -245,25 +275,39 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
   constexpr int BUF = KSMAX * 1024;
   constexpr int IP = QP / 2, ID = QD / 2, IA = W / 4, IB = W / 4 + 8;      // hB also receives the (MT + 1)-tile feature (+ alpha) layer's packed part
   constexpr int STASH = (QP / 8) * 1024;      // packed position encoding of one block: [group of 4 dwords][lane], wave-private
-  __shared__ __attribute__((aligned(1024))) char stage_mem[2 * BUF + 4 * NB * STASH];
+  constexpr int BIAS_AT = 2 * BUF + 4 * NB * STASH;      // the network's bias table behind the buffers and the stashes
+  // ... except where it would cost a resident workgroup: width 64 on the 16-band layout fills the CU's 160 KB with two workgroups as it is
+  constexpr bool LDSB = !(W == 64 && FP > 10);
+  __shared__ __attribute__((aligned(1024))) char stage_mem[BIAS_AT + (LDSB ? gen_bias_cap<W>() * 4 : 0)];
   typedef __attribute__((address_space(3))) u32x4* lds_u32x4_wptr;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int j = lane & 31, h = lane >> 5;
   int total = a.total ? *a.total : a.max_samples;
   if (total > a.max_samples) total = a.max_samples;
-  const float* const bias0 = a.net.bias;
-  const float* b = bias0;
+  total = __builtin_amdgcn_readfirstlane(total);      // wave-uniform by construction: keeps it (and the clamp below) out of the VGPRs
   if (static_cast<int>(blockIdx.x) * TILE >= total) return;      // workgroup-uniform
   const uint32_t stash = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(stage_mem)) + 2 * BUF + wave * NB * STASH + lane * 16;
   TileStage st;
   ts_start(st, a.net.w, stage_mem, wave, lane);
   ts_issue<BUF>(st, a.net.w_off[0], QP / 8, 0);
+  if constexpr (LDSB) {
+    float* tab = reinterpret_cast<float*>(stage_mem + BIAS_AT);
+    const int nb_f = min(static_cast<int>(a.net.n_bias), gen_bias_cap<W>());      // the host refuses a table beyond the capacity
+    for (int i = static_cast<int>(threadIdx.x); i < nb_f; i += 256) tab[i] = a.net.bias[i];
+    __syncthreads();
+  }
+  // a layer's bias blocks: LDS byte address, or (table left in global memory) byte offset from a.net.bias
+  const uint32_t bl = LDSB ? static_cast<uint32_t>(reinterpret_cast<uintptr_t>(stage_mem)) + BIAS_AT : 0u;
+  auto bias_of = [&](int l) { return bl + a.net.b_off[l] * 4u; };
+  const float* const gbias0 = a.net.bias;
+  const float* gb = gbias0;
   float br[16];
-  bias_request(b + a.net.b_off[0], h, br);
+  if constexpr (LDSB) bias_request_lds(bias_of(0), h, br);
+  else bias_request(gb + a.net.b_off[0], h, br);
   const int lf = t.depth;
   for (int tile = blockIdx.x; tile * TILE < total; tile += gridDim.x) {
-    b = bias0 + bias_launder();                  // keep the bias loads inside the loops (see shade_mlp32_kernel)
+    if constexpr (!LDSB) gb = gbias0 + bias_launder();      // keep the bias loads inside the loops
     // narrow networks spend as long in the encodings as in their MFMAs (60 sin / cos per sample against 243 MFMAs per block at
     // 6 x 128): the position encoding is evaluated once and parked in LDS for the skip layer, the direction encoding is evaluated
     // where it is consumed -- neither lives in registers across the layer stack
@@ -284,14 +328,14 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
           *((lds_u32x4_wptr)(uintptr_t)(stash + nb * STASH + g * 1024)) = v;
         }
       }
-      layer_16_staged<ET, NB, BUF, QP / 8, 0, MT, true, IP, IP, IA>(st, br, a.net.w_off[0], b + a.net.b_off[0], lane, pts, pts, hA, a.net.w_off[1], ks_of(1),
-                                                                    b + a.net.b_off[1]);
+      layer_16_staged<ET, NB, BUF, QP / 8, 0, MT, true, IP, IP, IA, -1, LDSB>(st, br, a.net.w_off[0], bias_of(0), lane, pts, pts, hA, a.net.w_off[1],
+                                                                              ks_of(1), bias_of(1), nullptr, gb);
     }
 #pragma unroll 1
     for (int l = 1; l < t.depth; ++l) {
-      b = bias0 + bias_launder();
+      if constexpr (!LDSB) gb = gbias0 + bias_launder();
       const uint32_t nxt = a.net.w_off[l + 1];
-      const float* nb_ = b + a.net.b_off[l + 1];
+      const uint32_t nb_ = bias_of(l + 1);
       const int nks = ks_of(l + 1);
       if ((t.cat_mask >> l) & 1) {
         uint32_t pts[NB * IP];
@@ -305,9 +349,10 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
             pts[nb * IP + 4 * g + 2] = v[2];
             pts[nb * IP + 4 * g + 3] = v[3];
           }
-        layer_16_staged<ET, NB, BUF, QP / 8, KW, MT, true, IP, IA, IB>(st, br, a.net.w_off[l], b + a.net.b_off[l], lane, pts, hA, hB, nxt, nks, nb_);      // cat([pts, h])
+        layer_16_staged<ET, NB, BUF, QP / 8, KW, MT, true, IP, IA, IB, -1, LDSB>(st, br, a.net.w_off[l], bias_of(l), lane, pts, hA, hB, nxt, nks, nb_, nullptr,
+                                                                                 gb);      // cat([pts, h])
       } else {
-        layer_16_staged<ET, NB, BUF, KW, 0, MT, true, IA, IA, IB>(st, br, a.net.w_off[l], b + a.net.b_off[l], lane, hA, hA, hB, nxt, nks, nb_);
+        layer_16_staged<ET, NB, BUF, KW, 0, MT, true, IA, IA, IB, -1, LDSB>(st, br, a.net.w_off[l], bias_of(l), lane, hA, hA, hB, nxt, nks, nb_, nullptr, gb);
       }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
@@ -315,18 +360,18 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
         for (int i = 0; i < IA; ++i) hA[nb * IA + i] = hB[nb * IB + i];
     }
     f32x16 alpha_tile[NB], rgb_tile[NB];
-    layer_16_staged<ET, NB, BUF, KW, 0, MT + 1, false, IA, IA, IB, MT>(st, br, a.net.w_off[lf], b + a.net.b_off[lf], lane, hA, hA, hB, a.net.w_off[lf + 1],
-                                                                       KW + QD / 8, b + a.net.b_off[lf + 1], alpha_tile);             // feature (+ alpha row)
+    layer_16_staged<ET, NB, BUF, KW, 0, MT + 1, false, IA, IA, IB, MT, LDSB>(st, br, a.net.w_off[lf], bias_of(lf), lane, hA, hA, hB, a.net.w_off[lf + 1],
+                                                                             KW + QD / 8, bias_of(lf + 1), alpha_tile, gb);             // feature (+ alpha row)
     {
       uint32_t dirs[NB * ID];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) pe_pack<ET, FD>(dpe[nb], h, dirs + nb * ID);
-      layer_16_staged<ET, NB, BUF, KW, QD / 8, MT / 2, true, IB, ID, IA>(st, br, a.net.w_off[lf + 1], b + a.net.b_off[lf + 1], lane, hB, dirs, hA,
-                                                                          a.net.w_off[lf + 2], KW / 2, b + a.net.b_off[lf + 2]);      // cat([feature, dir])
+      layer_16_staged<ET, NB, BUF, KW, QD / 8, MT / 2, true, IB, ID, IA, -1, LDSB>(st, br, a.net.w_off[lf + 1], bias_of(lf + 1), lane, hB, dirs, hA,
+                                                                                    a.net.w_off[lf + 2], KW / 2, bias_of(lf + 2), nullptr, gb);      // cat([feature, dir])
     }
     const bool more = (tile + static_cast<int>(gridDim.x)) * TILE < total;      // the last tile of this pass starts the copy of the next pass's first
-    layer_16_staged<ET, NB, BUF, KW / 2, 0, 1, false, IA, IA, IB, 0>(st, br, a.net.w_off[lf + 2], b + a.net.b_off[lf + 2], lane, hA, hA, hB, a.net.w_off[0],
-                                                                      more ? QP / 8 : 0, b + a.net.b_off[0], rgb_tile);
+    layer_16_staged<ET, NB, BUF, KW / 2, 0, 1, false, IA, IA, IB, 0, LDSB>(st, br, a.net.w_off[lf + 2], bias_of(lf + 2), lane, hA, hA, hB, a.net.w_off[0],
+                                                                            more ? QP / 8 : 0, bias_of(0), rgb_tile, gb);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const int s = tile * TILE + (wave * NB + nb) * 32 + j;
