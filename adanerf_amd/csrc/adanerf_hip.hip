@@ -587,7 +587,10 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
   const bool full = c->fp0 == 10 && c->fd0 == 4;
   if (c->generic0) {      // any other topology / encoding layout / raySampleInput: run-time-shaped kernels, no fused selection
     if (generic_split_sampling(c)) {
-      // split-precision engine (fp32-class accuracy at 3 / 16 of the fp32-MFMA cycle count), fragments straight from L2
+      // split-precision engine (fp32-class accuracy at 3 / 16 of the fp32-MFMA cycle count), weight tiles staged through LDS
+      const uint32_t bias_cap = c->topo0.width == 64 ? gen_bias_cap<64>() : c->topo0.width == 128 ? gen_bias_cap<128>() : gen_bias_cap<256>();
+      if (tune::kGenericStaged && a.net16.n_bias > bias_cap)      // cannot happen for depth <= 8: the kernel keeps the whole table in LDS
+        return fail(c, ADANERF_EUNSUPPORTED, "sampling network: bias table exceeds the kernel's LDS capacity");
 #define ADN_GENS(FPv, FDv, Wv) hipLaunchKernelGGL((sample_mlp16x3_gen_kernel<FPv, FDv, Wv, tune::kGenericStaged>), grid, block, 0, c->stream, a, c->gen0)
 #define ADN_GENS_W(FPv, FDv)                                   \
   do {                                                         \
@@ -1012,7 +1015,9 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
     // staged: one copy of every weight tile per workgroup through LDS, NB 32-sample blocks per wave; else fragments straight from L2.
     // Persistent grid = the workgroups the chosen instantiation really keeps resident (registers and LDS differ per width / layout).
     const bool st = tune::kGenericStaged;
-    const int nb_wg = !st ? 1 : topo.width == 64 ? gen_blocks<64>() : topo.width == 128 ? gen_blocks<128>() : gen_blocks<256>();
+    const bool enc104 = enc == kEnc10_4;      // else the catch-all 16-band layout
+    const int nb_wg = !st ? 1 : topo.width == 64 ? gen_blocks<64>() : topo.width == 128 ? (enc104 ? gen_blocks<128, 10>() : gen_blocks<128, kMaxBands>())
+                                                                                         : gen_blocks<256>();
     const int per_wg = 128 * nb_wg;
     const int tiles = (max_samples + per_wg - 1) / per_wg;
     const uint32_t bias_cap = topo.width == 64 ? gen_bias_cap<64>() : topo.width == 128 ? gen_bias_cap<128>() : gen_bias_cap<256>();
@@ -1031,7 +1036,7 @@ int launch_shade_mlp(adanerf_ctx* c, const float* d_rays, const uint32_t* d_key,
 #define ADN_GEN16(ET, FPv, FDv, Wv)                                                                                      \
   do {                                                                                                                   \
     if constexpr (tune::kGenericStaged)                                                                                  \
-      ADN_GEN16_GO((shade_mlp16_gen_staged_kernel<ET, FPv, FDv, Wv, gen_blocks<Wv>(), gen_occupancy<Wv, FPv>()>));            \
+      ADN_GEN16_GO((shade_mlp16_gen_staged_kernel<ET, FPv, FDv, Wv, gen_blocks<Wv, FPv>(), gen_occupancy<Wv, FPv>()>));       \
     else ADN_GEN16_GO((shade_mlp16_gen_kernel<ET, FPv, FDv, Wv>));                                                       \
   } while (0)
 #define ADN_GEN16_W(ET, FPv, FDv)                                  \

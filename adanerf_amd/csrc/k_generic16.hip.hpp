@@ -142,7 +142,7 @@ __device__ __forceinline__ uint32_t ts_next(TileStage& st, uint32_t next_off, in
 // The instruction order inside a tile is pinned (sched_barrier after every k-step): fragment s + kStageAhead is requested from LDS
 // before the MFMAs of k-step s, the bias block of the NEXT tile is requested from global memory while this one computes.  Left to
 // itself the scheduler hoisted every LDS read of a tile to its head (92 registers for a 23-step tile) and spilled.
-constexpr int kStageAhead = 4;
+constexpr int kStageAhead = tune::kGenericAhead;
 
 // Keeps the bias loads of a tile loop inside it (hipcc otherwise hoists every one of them out of the loop and spills) WITHOUT taking the
 // pointer's address space away: an opaque zero added to the kernel-argument pointer.  Round 3 laundered the pointer itself through an
@@ -182,6 +182,25 @@ template <int W>
 constexpr int gen_bias_cap() {
   return 10 * W + 256;
 }
+// copies the table into LDS with every load of a thread in flight at once (a workgroup of the sampling kernel lives for one 128-ray
+// tile: five dependent round trips in front of it would show), then the workgroup barrier
+template <int W>
+__device__ __forceinline__ void bias_table_fill(float* tab, const float* __restrict__ gbias, uint32_t n_bias) {
+  constexpr int PER = (gen_bias_cap<W>() + 255) / 256;
+  const int n = min(static_cast<int>(n_bias), gen_bias_cap<W>());      // the host refuses a table beyond the capacity
+  float v[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = static_cast<int>(threadIdx.x) + 256 * k;
+    v[k] = i < n ? gbias[i] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = static_cast<int>(threadIdx.x) + 256 * k;
+    if (i < gen_bias_cap<W>()) tab[i] = v[k];
+  }
+  __syncthreads();
+}
 __device__ __forceinline__ void bias_request_lds(uint32_t tile_addr, int h, float (&br)[16]) {      // tile_addr: LDS byte address of block [m][0][0]
   typedef const __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
   const lds_f32x4_ptr bp = (lds_f32x4_ptr)(uintptr_t)(tile_addr + h * 64);
@@ -205,25 +224,56 @@ __device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], 
   constexpr int KS = S1 + S2, D = KS < kStageAhead ? KS : kStageAhead;
   static_assert(KS * 1024 <= BUF_BYTES, "tile does not fit its LDS buffer");
   const int h = lane >> 5;
+  // The conversions of tile m - 1 run AFTER tile m's wait + barrier, copy issue and first fragment requests (tune::kGenericDefer): what
+  // a wave would otherwise sit out -- the LDS latency of the first fragment after the barrier -- is covered by 16 x NB values of VALU work
+  // it had to do anyway, and the drain of the tile's last MFMA is covered by the barrier.  Only a layer's last tile converts at once
+  // (the next layer reads its outputs).
+  f32x16 acc[NB];
+  auto convert = [&](int m) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if (KEEP_F32_TILE == m) {
+        keep[nb] = acc[nb];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(acc[nb], m, g, out + nb * O);
+      }
+    }
+  };
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const bool last = m == MT - 1;
     const uint32_t rd = ts_next<BUF_BYTES>(st, last ? next_off : w_off + (m + 1) * KS * 64, last ? next_frags : KS);
-    f32x16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nb][r] = br[r];
     u32x4 fr[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) fr[i] = lds_read128(rd + i * 1024);
-    if (tune::kAblateGeneric & 2) {      // timing ablation: no bias reads at all
+    if (tune::kGenericDefer) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (m > 0) convert(m - 1);
+    }
+    if (LDSB && tune::kGenericBiasDirect && !(tune::kAblateGeneric & 2)) {
+      // the tile's own bias block straight into its accumulators (no copy a tile ahead, no 16 moves per block): the first MFMA
+      // waits for these reads and its first fragment together
 #pragma unroll
-      for (int r = 0; r < 16; ++r) br[r] = 0.f;
-    } else if constexpr (LDSB) {
-      bias_request_lds(last ? next_bias : bias + (m + 1) * 128, h, br);
-    } else {      // table in global memory: bias / next_bias are byte offsets into it
-      bias_request(gbias + ((last ? next_bias : bias + (m + 1) * 128) >> 2), h, br);
+      for (int nb = 0; nb < NB; ++nb) {
+        float b16[16];
+        bias_request_lds(bias + m * 128, h, b16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = b16[r];
+      }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = br[r];
+      if (tune::kAblateGeneric & 2) {      // timing ablation: no bias reads at all
+#pragma unroll
+        for (int r = 0; r < 16; ++r) br[r] = 0.f;
+      } else if constexpr (LDSB) {
+        bias_request_lds(last ? next_bias : bias + (m + 1) * 128, h, br);
+      } else {      // table in global memory: bias / next_bias are byte offsets into it
+        bias_request(gbias + ((last ? next_bias : bias + (m + 1) * 128) >> 2), h, br);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -238,32 +288,23 @@ __device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      if (KEEP_F32_TILE == m) {
-        keep[nb] = acc[nb];
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(acc[nb], m, g, out + nb * O);
-      }
-    }
+    if (!tune::kGenericDefer || last) convert(m);
   }
 }
 
-// 32-sample blocks per wave and workgroups per CU of the staged shading kernel.  Two blocks halve the LDS reads per MFMA; their
-// activations (2 x (W / 2 + 8) packed registers) fit the 256 registers of a two-workgroups-per-CU launch only at width 64 -- the wider
-// networks run one workgroup per CU with the whole 512-register file, as the 8 x 256 kernel does (tuning.hpp).
-template <int W>
+// 32-sample blocks per wave and workgroups per CU of the staged shading kernel (FP: the encoding layout of the instantiation).
+// Two blocks per wave halve the LDS reads and the copies per MFMA.  Width 64 and 128 run two blocks at two workgroups per CU (<= 256
+// registers; round 3 shipped one block at three per CU for width 128 because two blocks spilled 45 registers -- with the bias table
+// in LDS and no bias registers they fit: 0.758 -> 0.709 ms at 6 x 128); width 256 runs two blocks with the whole 512-register file,
+// as the 8 x 256 kernel does.  The catch-all 16-band layout parks 7 KiB of encoding per block in LDS: at width 128 two blocks would
+// leave room for one workgroup only, so it keeps one block there (tuning.hpp).
+template <int W, int FP = 10>
 constexpr int gen_blocks() {
-  return W == 64 ? 2 : W == 128 ? tune::kGenericBlocks128 : tune::kGenericBlocks256;
+  return W == 64 ? 2 : W == 128 ? (FP <= 10 ? tune::kGenericBlocks128 : 1) : tune::kGenericBlocks256;
 }
-// FP: the encoding layout of the instantiation.  Three workgroups per CU at width 128 are for the 10-4 layout only (168 registers);
-// the catch-all 16-band layout needs 184 and its LDS footprint (~58 KB per workgroup) admits two anyway -- asking for three there only
-// made the compiler spill towards a target it could not meet.
 template <int W, int FP = 10>
 constexpr int gen_occupancy() {
-  return W == 64 ? 2 : W == 128 ? (tune::kGenericOcc128 ? (FP <= 10 ? tune::kGenericOcc128 : (tune::kGenericOcc128 < 2 ? tune::kGenericOcc128 : 2))
-                                                        : tune::kGenericBlocks128 == 2 ? 1 : 2) : 1;
+  return W == 64 ? (FP <= 10 ? tune::kGenericOcc64 : 2) : W == 128 ? (FP <= 10 ? tune::kGenericOcc128 : 2) : 1;
 }
 
 // A5 + A6 for any shading-net topology on the 16-bit engine, weights staged per tile.  Workgroup = 4 waves x NB x 32 samples.
@@ -291,12 +332,7 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
   TileStage st;
   ts_start(st, a.net.w, stage_mem, wave, lane);
   ts_issue<BUF>(st, a.net.w_off[0], QP / 8, 0);
-  if constexpr (LDSB) {
-    float* tab = reinterpret_cast<float*>(stage_mem + BIAS_AT);
-    const int nb_f = min(static_cast<int>(a.net.n_bias), gen_bias_cap<W>());      // the host refuses a table beyond the capacity
-    for (int i = static_cast<int>(threadIdx.x); i < nb_f; i += 256) tab[i] = a.net.bias[i];
-    __syncthreads();
-  }
+  if constexpr (LDSB) bias_table_fill<W>(reinterpret_cast<float*>(stage_mem + BIAS_AT), a.net.bias, a.net.n_bias);
   // a layer's bias blocks: LDS byte address, or (table left in global memory) byte offset from a.net.bias
   const uint32_t bl = LDSB ? static_cast<uint32_t>(reinterpret_cast<uintptr_t>(stage_mem)) + BIAS_AT : 0u;
   auto bias_of = [&](int l) { return bl + a.net.b_off[l] * 4u; };
@@ -320,7 +356,9 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         float x[3];
-        load_sample(a, tile * TILE + (wave * NB + nb) * 32 + j, total, x, dpe[nb]);      // past the end: the last sample again
+        // past the end: the last sample again.  (The opaque zero keeps `total - 1` a per-pass scalar: as a loop invariant hipcc parked it
+        // in a VGPR, spilled that, and re-loaded it from scratch at the head of every pass.)
+        load_sample(a, tile * TILE + (wave * NB + nb) * 32 + j, total + bias_launder(), x, dpe[nb]);
         pe_pack<ET, FP>(x, h, pts + nb * IP);
 #pragma unroll
         for (int g = 0; g < QP / 8; ++g) {
@@ -419,29 +457,52 @@ __device__ __forceinline__ void layer_16x3_direct(const u32x4* __restrict__ w, c
 
 // The same layer with the (hi, lo') pairs staged per tile (2 KiB per k-step), order pinned as in layer_16_staged.
 template <int BUF_BYTES, int KS, int MT, bool LAST>
-__device__ __forceinline__ void layer_16x3_staged(TileStage& st, float (&br)[16], uint32_t w_off, const float* __restrict__ bias, int lane,
+__device__ __forceinline__ void layer_16x3_staged(TileStage& st, float (&br)[16], uint32_t w_off, uint32_t bias, int lane,
                                                   const uint32_t* in_hi, const uint32_t* in_lo, uint32_t* out_hi, uint32_t* out_lo, float* out_f32,
-                                                  uint32_t next_off, int next_frags, const float* __restrict__ next_bias) {
+                                                  uint32_t next_off, int next_frags, uint32_t next_bias) {      // bias: LDS byte addresses
   constexpr int D = KS < 2 ? KS : 2;      // pairs requested ahead
   static_assert(KS * 2048 <= BUF_BYTES, "tile does not fit its LDS buffer");
   const int h = lane >> 5;
+  f32x16 acc, cross;      // tile m - 1's split / conversion runs behind tile m's barrier and first fragment requests (see layer_16_staged)
+  auto convert = [&](int m) {
+#pragma unroll
+    for (int pi = 0; pi < 8; ++pi) epilogue_pair_16x3<LAST>(acc, cross, m, pi, out_hi, out_lo, out_f32);
+  };
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const bool last = m == MT - 1;
     const uint32_t rd = ts_next<BUF_BYTES>(st, last ? next_off : w_off + (m + 1) * KS * 128, last ? next_frags : 2 * KS);
-    f32x16 acc, cross;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc[r] = br[r];
-      cross[r] = 0.f;
-    }
     u32x4 fh[D], fl[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       fh[i] = lds_read128(rd + (2 * i) * 1024);
       fl[i] = lds_read128(rd + (2 * i + 1) * 1024);
     }
-    bias_request(last ? next_bias : bias + (m + 1) * 32, h, br);
+    if (tune::kGenericDefer) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (m > 0) convert(m - 1);
+    }
+    if (tune::kGenericBiasDirect && !(tune::kAblateGeneric & 2)) {
+      float b16[16];
+      bias_request_lds(bias + m * 128, h, b16);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[r] = b16[r];
+        cross[r] = 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[r] = br[r];
+        cross[r] = 0.f;
+      }
+      if (tune::kAblateGeneric & 2) {      // timing ablation: no bias reads at all
+#pragma unroll
+        for (int r = 0; r < 16; ++r) br[r] = 0.f;
+      } else {
+        bias_request_lds(last ? next_bias : bias + (m + 1) * 128, h, br);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -457,8 +518,7 @@ __device__ __forceinline__ void layer_16x3_staged(TileStage& st, float (&br)[16]
       cross = Fp16::mfma(wlo, bh, cross);
       __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int pi = 0; pi < 8; ++pi) epilogue_pair_16x3<LAST>(acc, cross, m, pi, out_hi, out_lo, out_f32);
+    if (!tune::kGenericDefer || last) convert(m);
   }
 }
 
@@ -469,7 +529,8 @@ template <int FP, int FD, int W, bool STAGED>
 __global__ __launch_bounds__(256, (STAGED && W <= 128 && FP <= 10) ? 2 : 1) void sample_mlp16x3_gen_kernel(SampleArgs a, GenericTopo t) {
   constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP, MT = W / 32, KW = W / 16;
   constexpr int BUF = (Q0 / 8 > KW ? Q0 / 8 : KW) * 2048;
-  __shared__ __attribute__((aligned(1024))) char stage_mem[(STAGED ? 2 * BUF : 0) + 4 * kPairLdsBytesPerWave];      // + staging block of the fused selection
+  constexpr int BIAS_AT = (STAGED ? 2 * BUF : 0) + 4 * kPairLdsBytesPerWave;      // staged: the bias table behind the selection's staging block
+  __shared__ __attribute__((aligned(1024))) char stage_mem[BIAS_AT + (STAGED ? gen_bias_cap<W>() * 4 : 0)];
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -492,8 +553,11 @@ __global__ __launch_bounds__(256, (STAGED && W <= 128 && FP <= 10) ? 2 : 1) void
     TileStage st;
     ts_start(st, w, stage_mem, wave, lane);
     ts_issue<BUF>(st, a.net16.w_off[0], 2 * (Q0 / 8), 0);
+    bias_table_fill<W>(reinterpret_cast<float*>(stage_mem + BIAS_AT), a.net16.bias, a.net16.n_bias);
+    const uint32_t bl = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(stage_mem)) + BIAS_AT;
+    auto bias_of = [&](int l) { return bl + a.net16.b_off[l] * 4u; };
     float br[16];
-    bias_request(b + a.net16.b_off[0], h, br);
+    bias_request_lds(bias_of(0), h, br);
     {
       float tt[Q0];
       uint32_t iH[Q0 / 2], iL[Q0 / 2];
@@ -501,14 +565,11 @@ __global__ __launch_bounds__(256, (STAGED && W <= 128 && FP <= 10) ? 2 : 1) void
       pe_eval<FP, true>(p, h, tt + QD);
 #pragma unroll
       for (int q = 0; q < Q0 / 2; ++q) split_pack(tt[2 * q], tt[2 * q + 1], &iH[q], &iL[q]);
-      layer_16x3_staged<BUF, Q0 / 8, MT, false>(st, br, a.net16.w_off[0], b + a.net16.b_off[0], lane, iH, iL, bH, bL, nullptr, a.net16.w_off[1], 2 * KW,
-                                                b + a.net16.b_off[1]);
+      layer_16x3_staged<BUF, Q0 / 8, MT, false>(st, br, a.net16.w_off[0], bias_of(0), lane, iH, iL, bH, bL, nullptr, a.net16.w_off[1], 2 * KW, bias_of(1));
     }
 #pragma unroll 1
     for (int l = 1; l + 1 < t.depth; ++l) {
-      b = bias0 + bias_launder();
-      layer_16x3_staged<BUF, KW, MT, false>(st, br, a.net16.w_off[l], b + a.net16.b_off[l], lane, bH, bL, aH, aL, nullptr, a.net16.w_off[l + 1], 2 * KW,
-                                            b + a.net16.b_off[l + 1]);
+      layer_16x3_staged<BUF, KW, MT, false>(st, br, a.net16.w_off[l], bias_of(l), lane, bH, bL, aH, aL, nullptr, a.net16.w_off[l + 1], 2 * KW, bias_of(l + 1));
 #pragma unroll
       for (int i = 0; i < W / 4; ++i) {
         bH[i] = aH[i];
@@ -516,7 +577,7 @@ __global__ __launch_bounds__(256, (STAGED && W <= 128 && FP <= 10) ? 2 : 1) void
       }
     }
     const int ll = t.depth - 1;
-    layer_16x3_staged<BUF, KW, 4, true>(st, br, a.net16.w_off[ll], b + a.net16.b_off[ll], lane, bH, bL, nullptr, nullptr, out, 0, 0, b + a.net16.b_off[ll]);
+    layer_16x3_staged<BUF, KW, 4, true>(st, br, a.net16.w_off[ll], bias_of(ll), lane, bH, bL, nullptr, nullptr, out, 0, 0, bias_of(ll));
   } else {
     {
       float tt[Q0];

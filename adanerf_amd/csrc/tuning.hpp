@@ -51,8 +51,9 @@ constexpr bool kFastPeFp16Pass = true;
 // ---- run-time-shaped 16-bit kernels (k_generic16.hip.hpp) -------------------------------------------------------------
 // kGenericStaged: weights of one output tile staged through LDS for the whole workgroup (false: every wave fetches its own
 // fragments from L2 -- the experiment baseline of profiles/r03_generic_staged.md); kGenericBlocks128 / 256: 32-sample blocks per
-// wave of the staged shading kernel at that width (2: one workgroup per CU with 512 registers per wave; 1 at width 128: two
-// workgroups per CU).  Measured: 1 at width 128 (0.94 vs 1.03 ms), 2 at width 256 (2.82 vs 3.42 ms).
+// wave of the staged shading kernel at that width (10-4 layout; k_generic16.hip.hpp gen_blocks / gen_occupancy).  Measured: 2 at
+// width 256 (2.82 vs 3.42 ms, round 3); at width 128 round 3 shipped 1 block at 3 workgroups per CU (0.889 ms; two blocks spilled),
+// round 4 -- bias table in LDS, no bias registers -- 2 blocks at 2 per CU (0.709 vs 0.758 ms on one box, profiles/r04_lab_log.md).
 #if ADN_OVERRIDABLE && defined(ADN_GEN_STAGED)
 constexpr bool kGenericStaged = ADN_GEN_STAGED != 0;
 #else
@@ -61,15 +62,38 @@ constexpr bool kGenericStaged = true;
 #if ADN_OVERRIDABLE && defined(ADN_GEN_NB128)
 constexpr int kGenericBlocks128 = ADN_GEN_NB128;
 #else
-constexpr int kGenericBlocks128 = 1;
+constexpr int kGenericBlocks128 = 2;
 #endif
-// workgroups per CU asked of the compiler at width 128 (0: 1 with two blocks per wave, 2 with one).  Measured on 6 x 128: one block,
-// 2 per CU 0.944 ms; two blocks, 1 per CU 1.03; two blocks, 2 per CU (45 registers spilled) 0.875; one block, 3 per CU (168
-// registers, the 10-4 layout only -- the 16-band layout needs 184 and stays at 2) 0.889: shipped
+// workgroups per CU asked of the compiler at width 128 (10-4 layout; the 16-band layout runs one block at 2 per CU)
 #if ADN_OVERRIDABLE && defined(ADN_GEN_OCC128)
 constexpr int kGenericOcc128 = ADN_GEN_OCC128;
 #else
-constexpr int kGenericOcc128 = 3;
+constexpr int kGenericOcc128 = 2;
+#endif
+// workgroups per CU at width 64 (two blocks per wave; the 16-band layout's LDS footprint admits two)
+#if ADN_OVERRIDABLE && defined(ADN_GEN_OCC64)
+constexpr int kGenericOcc64 = ADN_GEN_OCC64;
+#else
+constexpr int kGenericOcc64 = 2;
+#endif
+// kGenericDefer: a tile's conversions run behind the NEXT tile's barrier and first fragment requests (k_generic16.hip.hpp, layer_16_staged)
+#if ADN_OVERRIDABLE && defined(ADN_GEN_DEFER)
+constexpr bool kGenericDefer = ADN_GEN_DEFER != 0;
+#else
+constexpr bool kGenericDefer = false;      // measured: no effect with three waves per SIMD to cover for each other (r04_lab_log.md)
+#endif
+// kGenericBiasDirect: a tile's bias block is read from the LDS table straight into its accumulators at the head of the tile
+// (false: requested a tile ahead into 16 registers of their own and copied)
+#if ADN_OVERRIDABLE && defined(ADN_GEN_BIAS_DIRECT)
+constexpr bool kGenericBiasDirect = ADN_GEN_BIAS_DIRECT != 0;
+#else
+constexpr bool kGenericBiasDirect = true;
+#endif
+// kGenericAhead: fragments a wave requests from LDS ahead of the k-step that consumes them
+#if ADN_OVERRIDABLE && defined(ADN_GEN_AHEAD)
+constexpr int kGenericAhead = ADN_GEN_AHEAD;
+#else
+constexpr int kGenericAhead = 4;
 #endif
 #if ADN_OVERRIDABLE && defined(ADN_GEN_NB256)
 constexpr int kGenericBlocks256 = ADN_GEN_NB256;
