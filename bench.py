@@ -189,6 +189,10 @@ def main():
     ap.add_argument("--orbit", type=int, default=0,
                     help="K > 0: step i renders pose i %% K of a K-pose orbit inside the view cell (yaw and position vary) instead of "
                          "the fixed camera; quality / cpu_baseline still refer to pose 0")
+    ap.add_argument("--sub-shares", type=int, default=0, choices=[0, 1, 2],
+                    help="N > 1: every rank renders its share of a frame as this many sub-shares on as many contexts / streams, concurrently "
+                         "(0: 2 for N > 1, else 1); the same frame, so a frame's latency does not grow")
+    ap.add_argument("--no-split-mode", action="store_true", help="N = 1: skip the extra two-sub-shares measurement reported under split_frame_mode")
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2],
                     help="N > 1 only: 1 (default) renders one frame at a time, as on a single GPU and as an interactive viewer needs it; "
                          "2 renders alternate frames on two contexts / streams of the rank, so that the tail rounds, ring prologues and "
@@ -245,24 +249,43 @@ def main():
     rot = M.camera_rotation(100.0, 0.0) if tag != "ndc_random_init" else np.eye(3, dtype=np.float32)   # LLFF: looking down -z
 
     from adanerf_amd import sharding
-    strip_rows = sharding.balanced_strip_rows(h, world)
-    r = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision, sampling=args.sampling,
-                                   guard_eps=args.guard_eps, guard_audit_period=args.guard_audit_period, device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=strip_rows)
-    r.init()
-    r.set_camera(pose, rot)
+    # N > 1: what does not shrink with N (a kernel's last, partly filled round, the weight ring's prologue, dependent-launch gaps) is
+    # ~15 % of an 80 000-ray share.  Each rank therefore renders its share of a frame as P sub-shares -- virtual ranks
+    # rank * P .. rank * P + P - 1 of a world of N * P -- on P contexts / streams at once: one sub-share's kernels take the CUs the
+    # other's tails leave idle.  It is the SAME frame on every stream, so a frame's latency does not grow (measured: it shrinks,
+    # tools/probes/split_shares.py); the gathered payloads are already in virtual-rank order.
+    fif_req = args.frames_in_flight or int(os.environ.get("ADANERF_BENCH_FRAMES_IN_FLIGHT", "0")) or 1
+    P = args.sub_shares or int(os.environ.get("ADANERF_BENCH_SUB_SHARES", "0"))
+    if not P:
+        # default: two sub-shares per rank where the image rows split evenly over 2 N virtual ranks (800 rows do for N = 2, 4, 8; 1080 rows
+        # over 16 do not: 6 % more rays on the largest sub-share cost more than the overlap returns, profiles/r04_split_shares_*.log)
+        even = any(h % sr == 0 and (h // sr) % (2 * world) == 0 for sr in range(1, 9))
+        P = 2 if world > 1 and fif_req == 1 and even else 1
+    if not use_dist:
+        P = 1
+    vworld = world * P
+    strip_rows = sharding.balanced_strip_rows(h, vworld)
+
+    def new_renderer(vrank):
+        q = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision, sampling=args.sampling,
+                                       guard_eps=args.guard_eps, guard_audit_period=args.guard_audit_period, device_id=local_rank, shard_rank=vrank,
+                                       shard_world=vworld, strip_rows=strip_rows)
+        q.init()
+        q.set_camera(pose, rot)
+        return q
+
+    r = new_renderer(rank * P)
     # N > 1: a share of the frame is a few rounds of each kernel's persistent grid, and what does not shrink with N (the last,
     # partly filled round, the weight ring's prologue, dependent-launch gaps) is ~15 % of it at N = 8.  Two frames in
     # flight on two contexts / streams let the next frame's kernels take the CUs a kernel's tail leaves idle.
-    fif = args.frames_in_flight or int(os.environ.get("ADANERF_BENCH_FRAMES_IN_FLIGHT", "0")) or 1
-    if not use_dist:
-        fif = 1
+    fif = fif_req
+    if not use_dist or P > 1:
+        fif = 1                                   # sub-shares and a second frame in flight are alternatives
     rs = [r]
     if fif == 2:
-        r_b = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision, sampling=args.sampling,
-                                         guard_eps=args.guard_eps, guard_audit_period=args.guard_audit_period, device_id=local_rank, shard_rank=rank, shard_world=world, strip_rows=strip_rows)
-        r_b.init()
-        r_b.set_camera(pose, rot)
-        rs.append(r_b)
+        rs.append(new_renderer(rank))
+    for k in range(1, P):
+        rs.append(new_renderer(rank * P + k))
     dev = torch.device("cuda", local_rank)
     # Streams: the renderer enqueues on `tstream`; on N > 1 the exchange of frame k (RGBA8 strip payloads -> rank 0
     # over RCCL/xGMI) runs on `cstream` behind an event, so it overlaps the render of frame k+1.  Payload and gather
@@ -273,19 +296,19 @@ def main():
         q.set_stream(ts.cuda_stream)
     tstream = tstreams[0]
     n_buf = 2 if use_dist else 1
-    outs = [torch.zeros((r.info.rays_local_max, 4), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
-    out = outs[0]
-    rgbs = [torch.zeros((max(r.info.rays_local, 1), 3), dtype=torch.float32, device=dev) for _ in rs]
+    M_pay = r.info.rays_local_max                 # payload rows of a (sub-)share: the same for every virtual rank
+    outs = [torch.zeros((P, M_pay, 4), dtype=torch.uint8, device=dev) for _ in range(n_buf)]
+    rgbs = [torch.zeros((max(q.info.rays_local, 1), 3), dtype=torch.float32, device=dev) for q in rs]
     rgb = rgbs[0]
     gathered = image = images = cstream = None
     ev_render = ev_gather = None
     if use_dist:
         cstream = torch.cuda.Stream(device=dev)
-        ev_render = [torch.cuda.Event() for _ in range(2)]
+        ev_render = [[torch.cuda.Event() for _ in range(P)] for _ in range(2)]
         ev_gather = [torch.cuda.Event() for _ in range(2)]
         gather_lists = [None, None]
         if rank == 0:
-            gathered = [torch.zeros((world, r.info.rays_local_max, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+            gathered = [torch.zeros((world, P, M_pay, 4), dtype=torch.uint8, device=dev) for _ in range(2)]      # = [virtual rank][row][4]
             gather_lists = [list(g.unbind(0)) for g in gathered]
             images = [torch.zeros((h * w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]      # one per buffer: two frames may be assembling
             image = images[0]
@@ -297,7 +320,7 @@ def main():
         with torch.cuda.stream(ts):
             ts.wait_event(ev_gather[b])
             if rank == 0:
-                q.assemble_strips(gathered[b], images[b])
+                q.assemble_strips(gathered[b].view(vworld, M_pay, 4), images[b])
         state["last"] = b
 
     poses = []
@@ -311,19 +334,23 @@ def main():
 
     def step():
         b = state["k"] & (n_buf - 1)
-        q, ts = rs[b % fif], tstreams[b % fif]              # two frames in flight: buffer b belongs to context b
-        if poses:
-            q.set_camera(*poses[state["k"] % len(poses)])
+        # the contexts of this frame: all P sub-shares, or (two frames in flight) the one context buffer b belongs to
+        lanes = list(range(len(rs))) if P > 1 else [b % fif]
         state["k"] += 1
-        with torch.cuda.stream(ts):
-            if use_dist and state["k"] > 2:
-                ts.wait_event(ev_gather[b])                 # frame k-2's payload has left this buffer
-            q.render(outs[b], rgbs[b % fif])
-            if use_dist:
-                ev_render[b].record(ts)
+        for k, i in enumerate(lanes):
+            q, ts = rs[i], tstreams[i]
+            if poses:
+                q.set_camera(*poses[(state["k"] - 1) % len(poses)])
+            with torch.cuda.stream(ts):
+                if use_dist and state["k"] > 2:
+                    ts.wait_event(ev_gather[b])             # frame k-2's payload has left this buffer
+                q.render(outs[b][k], rgbs[i])
+                if use_dist:
+                    ev_render[b][k].record(ts)
         if use_dist:
             with torch.cuda.stream(cstream):
-                cstream.wait_event(ev_render[b])
+                for k in range(len(lanes)):
+                    cstream.wait_event(ev_render[b][k])
                 dist.gather(outs[b], gather_lists[b], dst=0)
                 state["gathers"] += 1
                 ev_gather[b].record(cstream)
@@ -356,10 +383,11 @@ def main():
     dt = time.perf_counter() - t0
     st, frames = r.collect_stats()
     r.set_profiling(False)
-    for q in rs[1:]:                              # second context of the rank: same record, summed
+    for q in rs[1:]:                              # the rank's other contexts (second frame in flight / sub-shares): same record, summed
         st2, f2 = q.collect_stats()
         q.set_profiling(False)
-        frames += f2
+        if P == 1:
+            frames += f2                          # (sub-shares render the same frames)
         for fld in ("total_samples", "batches", "ms_total", "ms_sample_mlp", "ms_compact", "ms_shade_mlp", "ms_composite", "shade_launches",
                     "sample_launches", "rays_refined"):
             setattr(st, fld, getattr(st, fld) + getattr(st2, fld))
@@ -372,7 +400,7 @@ def main():
     if dist:
         exchange = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
                     "world_size": dist.get_world_size(), "gathers": state["gathers"],
-                    "payload_bytes_per_rank": int(outs[0].numel())}
+                    "payload_bytes_per_rank": int(outs[0].numel()), "sub_shares_per_rank": P}
     if dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -390,7 +418,7 @@ def main():
         shard_samples = shard_shade_ms = None
 
     if rank == 0 and args.dump_image:
-        np.save(args.dump_image, (images[state["last"]] if use_dist else outs[0][:h * w]).cpu().numpy().reshape(h, w, 4))
+        np.save(args.dump_image, (images[state["last"]] if use_dist else outs[0][0][:h * w]).cpu().numpy().reshape(h, w, 4))
 
     ms_per_step = dt / args.steps * 1e3
     fps = args.steps / dt
@@ -450,12 +478,12 @@ def main():
         stage_ms = {"sample_mlp": st.ms_sample_mlp / frames, "compact": st.ms_compact / frames,
                     "shade_mlp": st.ms_shade_mlp / frames, "composite": st.ms_composite / frames}
         smp_launch = max(st.sample_launches, 1)
-        smp_tflops = SAMPLE_FLOP_PER_RAY * (r.info.rays_local * frames / smp_launch) / (st.ms_sample_mlp / smp_launch * 1e-3) / 1e12 \
+        smp_tflops = SAMPLE_FLOP_PER_RAY * (sum(q.info.rays_local for q in (rs if P > 1 else rs[:1])) * frames / smp_launch) / (st.ms_sample_mlp / smp_launch * 1e-3) / 1e12 \
             if st.ms_sample_mlp > 0 else 0.0
         # Where the sampling stage sits against the MFMA roofline.  Algorithmic = 898 048 FLOP per ray; executed =
         # what the engine issues for it: the split engine three f16 MFMAs per term, the guarded mode one per term for every ray
         # plus three for each re-evaluated ray, the exact engine one on the fp32-MFMA pipe.
-        R = r.info.rays_local
+        R = sum(q.info.rays_local for q in (rs if P > 1 else rs[:1]))      # this rank's rays per frame
         refined = (st.rays_refined / frames) if args.sampling == "guarded" else 0.0
         exec_mult = {"split": 3.0, "fp16": 1.0, "fp32": 1.0, "guarded": 1.0 + 3.0 * refined / max(R, 1)}[args.sampling]
         smp_peak = PEAK_TFLOPS["fp32" if args.sampling == "fp32" else "fp16"]
@@ -501,7 +529,7 @@ def main():
             if poses:                                   # the quality check refers to the fixed pose
                 r.set_camera(pose, rot)
                 with torch.cuda.stream(tstream):
-                    r.render(outs[0], rgb)
+                    r.render(outs[0][0], rgb)
                 torch.cuda.synchronize()
             mine = rgb.cpu().numpy()[row0 * w:(row0 + rows) * w]
             cnt = r.buffer(3, np.int32, (r.info.rays_local,))[row0 * w:(row0 + rows) * w] if r.info.batch_rays >= r.info.rays_local else None
@@ -557,6 +585,62 @@ def main():
                 exact = {"sampling": "split-fp16 on every ray (ADANERF_SAMPLING_SPLIT_FP16)", "value": args.steps / dt3, "unit": "frames/s",
                          "sample_mlp_ms": st3.ms_sample_mlp, "samples_per_frame": int(st3.total_samples),
                          "rays_with_the_headline_modes_sample_count": float((cnt1 == cnt3).mean()) if cnt1 is not None else None}
+        # the same frame as two concurrent sub-shares (virtual ranks 0 and 1 of a world of 2) on two contexts / streams of this one GPU,
+        # assembled by adanerf_assemble_strips: what `--gpus N` does per rank (P above), measured at N = 1.  Reported beside the
+        # headline: the headline renders one context at a time so that its per-stage times are those of the kernels alone.
+        split = None
+        if world == 1 and not use_dist and not args.no_split_mode and args.batch_rays <= 0:
+            sr2 = sharding.balanced_strip_rows(h, 2)
+            qs = [adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h), precision=args.precision, sampling=args.sampling, guard_eps=args.guard_eps,
+                                             guard_audit_period=args.guard_audit_period, guard_audit_fill=False, device_id=local_rank,
+                                             shard_rank=k, shard_world=2, strip_rows=sr2) for k in range(2)]
+            for q in qs:
+                q.init()
+                q.set_camera(pose, rot)
+            ss = [torch.cuda.Stream(device=dev) for _ in qs]
+            for q, s_ in zip(qs, ss):
+                q.set_stream(s_.cuda_stream)
+            pay = torch.zeros((2, qs[0].info.rays_local_max, 4), dtype=torch.uint8, device=dev)
+            img = torch.zeros((h * w, 4), dtype=torch.uint8, device=dev)
+            ev = torch.cuda.Event()
+
+            def split_step():
+                for k in (1, 0):
+                    with torch.cuda.stream(ss[k]):
+                        qs[k].render(pay[k], None)
+                        if k == 1:
+                            ev.record(ss[1])
+                with torch.cuda.stream(ss[0]):
+                    ss[0].wait_event(ev)
+                    qs[0].assemble_strips(pay, img)
+                    ss[1].wait_stream(ss[0])          # the next frame's sub-share 1 must not overwrite a payload being assembled
+
+            for _ in range(args.warmup):
+                split_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                split_step()
+            torch.cuda.synchronize()
+            dt4 = time.perf_counter() - t1
+            lat = []
+            for _ in range(10):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                split_step()
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t1)
+            same_img = None
+            if not poses:
+                with torch.cuda.stream(tstream):
+                    r.render(outs[0][0], rgb)
+                torch.cuda.synchronize()
+                same_img = bool(torch.equal(img, outs[0][0][:h * w]))
+            split = {"what": "the frame as 2 concurrent sub-shares on 2 contexts / streams + adanerf_assemble_strips (as every rank of --gpus N does)",
+                     "value": args.steps / dt4, "unit": "frames/s", "frame_latency_ms_median": float(np.median(lat)) * 1e3,
+                     "image_identical_to_the_headline_frame": same_img}
+            for q in qs:
+                q.close()
         rec = {"metric": "FPS at %dx%d" % (w, h), "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": args.precision, "data": data,
@@ -565,10 +649,10 @@ def main():
                                        ("%s on the run-time-shaped %s kernel" % (args.workload[8:], "exact-fp32" if args.sampling == "fp32" else "split-fp16")) if generic_wl else
                                        {"split": "split-fp16 (3 MFMAs per term)", "fp32": "fp32 MFMA", "fp16": "plain fp16 (opt-in speed mode)",
                                         "guarded": "guarded two-precision (plain fp16, split-fp16 on the rays inside the band)"}[args.sampling]),
-                          "parallelism": ("image-strip shard x%d (%d-row strips, round-robin) + %s gather overlapped with the next frame" %
-                                          (world, strip_rows, "RCCL" if backend == "nccl" else backend)) if use_dist else "single GPU",
+                          "parallelism": ("image-strip shard x%d (%d-row strips, round-robin over %d virtual ranks, %d concurrent sub-share(s) per GPU) + %s gather "
+                                          "overlapped with the next frame" % (world, strip_rows, vworld, P, "RCCL" if backend == "nccl" else backend)) if use_dist else "single GPU",
                           "exchange": exchange,
-                          "frames_in_flight": fif,
+                          "frames_in_flight": fif, "sub_shares_per_gpu": P,
                           "rays_refined_per_frame": (st.rays_refined / frames) if args.sampling == "guarded" else None,
                           "guard": ({"eps": float(r.info.guard_eps), "eps_pair": float(r.info.guard_eps_pair),
                                      "band_source": R_GUARD_FROM.get(int(r.info.guard_calib_source)), "calibration_poses": int(r.info.guard_calib_poses),
@@ -581,7 +665,8 @@ def main():
                           "batch_rays": r.info.batch_rays, "mean_samples_per_ray": mean_spp, "samples_per_frame": samples_per_frame,
                           "camera": ("%d-pose orbit inside the view cell" % args.orbit) if poses else "fixed: view-cell centre, yaw 100 deg"},
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,
-               "sampling_mlp_algorithmic_tflops": smp_tflops, "sampling_roofline": sampling_roofline, "hbm_stages": hbm, "quality": quality, "exact_mode": exact, "speed_mode": speed}
+               "sampling_mlp_algorithmic_tflops": smp_tflops, "sampling_roofline": sampling_roofline, "hbm_stages": hbm, "quality": quality, "exact_mode": exact, "speed_mode": speed,
+               "split_frame_mode": split}
         if shard_samples:
             mean_s = sum(shard_samples) / len(shard_samples)
             rec["shards"] = {"samples_per_frame": shard_samples, "shade_ms_per_frame": shard_shade_ms,

@@ -1429,10 +1429,12 @@ def test_dataset_evaluator_end_to_end(cases, tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_share_one_gpu(tmp_path):
+@pytest.mark.parametrize("mode", ["sub_shares", "two_frames_in_flight"])
+def test_bench_two_ranks_share_one_gpu(tmp_path, mode):
     """bench.py's N>1 flow (strip shard -> gather -> assemble_strips, max-over-ranks timing, one JSON line from rank 0)
     launched exactly as the driver launches it, but with both ranks on the one GPU of this box and gloo for the
-    exchange (RCCL refuses two ranks on one device).  The assembled frame must equal the single-rank frame byte for byte."""
+    exchange (RCCL refuses two ranks on one device).  The assembled frame must equal the single-rank frame byte for byte.
+    Default: every rank renders its share as two concurrent sub-shares (four virtual ranks); optional: two frames in flight."""
     import json
     import subprocess
     import sys
@@ -1445,17 +1447,21 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     env = dict(os.environ, ADANERF_BENCH_DIST_BACKEND="gloo", ADANERF_BENCH_ONE_DEVICE="1")
     b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29731", "bench.py", "--gpus", "2",
-                        "--dump-image", two] + common, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+                        "--dump-image", two] + common + (["--frames-in-flight", "2"] if mode == "two_frames_in_flight" else []),
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert b.returncode == 0, b.stderr[-2000:]
     lines = [ln for ln in b.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, b.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0 and rec["config"]["frames_in_flight"] == 1
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    want = (1, 2) if mode == "sub_shares" else (2, 1)
+    assert (rec["config"]["frames_in_flight"], rec["config"]["sub_shares_per_gpu"], rec["config"]["exchange"]["sub_shares_per_rank"]) == want + want[1:]
     assert r1_guard_ok(rec)
     r1 = json.loads([ln for ln in a.stdout.splitlines() if ln.startswith("{")][0])
     assert abs(rec["config"]["samples_per_frame"] - r1["config"]["samples_per_frame"]) < 0.5
     assert r1_guard_ok(r1) and r1["exact_mode"]["rays_with_the_headline_modes_sample_count"] == 1.0
     assert r1["exact_mode"]["samples_per_frame"] == r1["config"]["samples_per_frame"]
+    assert r1["split_frame_mode"]["image_identical_to_the_headline_frame"] is True and r1["split_frame_mode"]["value"] > 0
     img1, img2 = np.load(one), np.load(two)
     assert img1.shape == img2.shape == (800, 800, 4)
     assert np.array_equal(img1, img2)
@@ -1470,26 +1476,27 @@ def r1_guard_ok(rec):
 
 @pytest.mark.gpu
 def test_bench_eight_ranks_share_one_gpu(tmp_path):
-    """The driver's N = 8 launch line on this box's one GPU (gloo exchange) with the optional two frames in flight per rank
-    (sixteen contexts on the device -- the default is one frame at a time, which test_bench_two_ranks_share_one_gpu runs): 5-row strips,
-    eight gathers per frame set; the assembled frame equals the single-rank frame."""
+    """The driver's N = 8 launch line on this box's one GPU (gloo exchange), defaults: every rank renders its share of a frame as two
+    concurrent sub-shares (sixteen virtual ranks / contexts on the device, 5-row strips), one frame at a time; the assembled frame
+    equals the single-rank frame."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     one, eight = str(tmp_path / "one.npy"), str(tmp_path / "eight.npy")
     a = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--dump-image", one, "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                        "--no-speed-mode"], cwd=root, capture_output=True, text=True, timeout=600)
+                        "--no-speed-mode", "--no-exact-mode", "--no-split-mode"], cwd=root, capture_output=True, text=True, timeout=600)
     assert a.returncode == 0, a.stderr[-2000:]
     env = dict(os.environ, ADANERF_BENCH_DIST_BACKEND="gloo", ADANERF_BENCH_ONE_DEVICE="1")
     b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                         "--master-port", "29771", "bench.py", "--gpus", "8", "--dump-image", eight, "--steps", "5", "--warmup", "2",
-                        "--no-cpu-baseline", "--frames-in-flight", "2"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert b.returncode == 0, b.stderr[-2000:]
     lines = [ln for ln in b.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, b.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 8 and rec["config"]["frames_in_flight"] == 2 and rec["config"]["exchange"]["world_size"] == 8
+    assert rec["n_gpus"] == 8 and rec["config"]["frames_in_flight"] == 1 and rec["config"]["sub_shares_per_gpu"] == 2
+    assert rec["config"]["exchange"]["world_size"] == 8
     assert len(rec["shards"]["samples_per_frame"]) == 8 and rec["shards"]["sample_imbalance_max_over_mean"] < 1.02
     assert np.array_equal(np.load(one), np.load(eight))
 

@@ -2,7 +2,7 @@
 # on the GPU box: one bench line per BASELINE configuration that fits one GPU -> gpurun_out/bench_all/<name>.json
 cd "$(dirname "$0")/.."
 O=gpurun_out/${ROUND:-r04}_bench_all; mkdir -p $O
-run() { n=$1; shift; python bench.py --no-speed-mode --no-exact-mode "$@" 2>/dev/null | tail -1 > $O/$n.json; python - "$O/$n.json" "$n" <<'PY'
+run() { n=$1; shift; python bench.py --no-speed-mode --no-exact-mode --no-split-mode "$@" 2>/dev/null | tail -1 > $O/$n.json; python - "$O/$n.json" "$n" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
 q = d.get("quality") or {}
