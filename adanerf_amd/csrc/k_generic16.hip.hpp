@@ -304,7 +304,7 @@ constexpr int gen_blocks() {
 }
 template <int W, int FP = 10>
 constexpr int gen_occupancy() {
-  return W == 64 ? (FP <= 10 ? tune::kGenericOcc64 : 2) : W == 128 ? (FP <= 10 ? tune::kGenericOcc128 : 2) : 1;
+  return W == 64 ? (FP <= 10 ? tune::kGenericOcc64 : 2) : W == 128 ? (FP <= 10 ? tune::kGenericOcc128 : 2) : (FP <= 10 ? tune::kGenericOcc256 : 1);
 }
 
 // A5 + A6 for any shading-net topology on the 16-bit engine, weights staged per tile.  Workgroup = 4 waves x NB x 32 samples.

@@ -76,6 +76,12 @@ constexpr int kGenericOcc64 = ADN_GEN_OCC64;
 #else
 constexpr int kGenericOcc64 = 2;
 #endif
+// workgroups per CU at width 256 (10-4 layout): 1 with two blocks per wave (512 registers); 2 is only meaningful with one block
+#if ADN_OVERRIDABLE && defined(ADN_GEN_OCC256)
+constexpr int kGenericOcc256 = ADN_GEN_OCC256;
+#else
+constexpr int kGenericOcc256 = 1;
+#endif
 // kGenericDefer: a tile's conversions run behind the NEXT tile's barrier and first fragment requests (k_generic16.hip.hpp, layer_16_staged)
 #if ADN_OVERRIDABLE && defined(ADN_GEN_DEFER)
 constexpr bool kGenericDefer = ADN_GEN_DEFER != 0;

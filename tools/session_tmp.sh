@@ -1,12 +1,14 @@
 #!/bin/bash
-# session 27: bench.py with sub-shares per GPU (default for N > 1) and split_frame_mode at N = 1
+# session 29: full GPU suite, profiles and bench lines on the current sources
 cd /root/repo
-O=gpurun_out/r04_s27; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "test_bench" > $O/pytest_bench.log 2>&1; tail -5 $O/pytest_bench.log
-python bench.py --no-cpu-baseline --no-speed-mode 2>$O/bench.err | tail -1 > $O/bench_default.json
-python - <<'PY'
+O=gpurun_out/r04_s29; mkdir -p $O
+ADANERF_MEASURED_LOG=$PWD/$O/parity_measured.log timeout 900 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+tools/collect_all_profiles.sh > $O/collect.log 2>&1
+tools/bench_all.sh > $O/bench_all.log 2>&1
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+adanerf_amd/bin/mfma_peak > $O/mfma_peak.log 2>&1
+cat $O/bench_all.log; python - <<'PY'
 import json
-d=json.load(open('gpurun_out/r04_s27/bench_default.json')); print(round(d['value'],1), d['stage_ms_per_frame'], d['exact_mode']['value'], d['split_frame_mode'])
+d=json.load(open('gpurun_out/r04_s29/bench_default.json')); print(round(d['value'],1), d['roofline']['frac'], d['roofline']['traffic'], d['roofline'].get('frac_of_sustained'), d['cpu_baseline']['value'], d['split_frame_mode']['value'], d['exact_mode']['value'])
 PY
-python tools/probes/split_shares.py config4 1,8 1,2 > $O/split_shares_config4.log 2>&1; grep -v amdgpu.ids $O/split_shares_config4.log
-python tools/probes/split_shares.py config5_ndc 1,8 1,2 fp16 > $O/split_shares_config5.log 2>&1; grep -v amdgpu.ids $O/split_shares_config5.log
