@@ -441,7 +441,9 @@ __global__ __launch_bounds__(256) void refine_list_kernel(const uint32_t* __rest
   p.offset = 0;
   if (cap_round > 0) {
     const int rounds = max(1, (p.tot_und + cap_round - 1) / cap_round);
-    p.budget = min(p.tot_aud, max(0, rounds * cap_round - p.tot_und));
+    int room = max(0, rounds * cap_round - p.tot_und);
+    if (room < (p.tot_aud + 3) / 4) room += cap_round;      // never less than a quarter of the frame's quota: then the audit does take a round
+    p.budget = min(p.tot_aud, room);
     if (p.budget > 0 && p.budget < p.tot_aud) p.offset = static_cast<int>((static_cast<long long>(cycle) * p.budget) % p.tot_aud);
   }
   int pu = tot[0] + xu - cu, pa = tot[1] + xa - ca;      // ranks of this word's first undecided / audited-only ray

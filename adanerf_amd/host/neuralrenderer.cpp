@@ -77,8 +77,8 @@ bool NeuralRenderer::init() {
       break;
     }
   opt.shard_world = world;
-  // a share of a frame: the guarded selection's audit fills the last round of its refinement pass instead of adding one (adanerf_hip.h)
-  if (world > 1) opt.flags |= ADANERF_FLAG_GUARD_AUDIT_FILL;
+  // the guarded selection's audit fills the last round of its refinement pass instead of adding one (adanerf_hip.h); as in renderer.py
+  opt.flags |= ADANERF_FLAG_GUARD_AUDIT_FILL;
   opt.strip_rows = strip_rows;
   for (int rank = 0; rank < world; ++rank) {
     opt.shard_rank = rank;

@@ -209,14 +209,14 @@ class NeuralRenderer:
                  threshold: float = -1.0, shard_rank: int = 0, shard_world: int = 1, strip_rows: int = 8,
                  sampling: Optional[str] = None, lib_path: Optional[str] = None, keep_oracle: bool = False, wave_select: bool = False,
                  guard_eps: float = 0.0, guard_eps_pair: float = 0.0, guard_audit_period: int = 0, guard_cache: bool = True,
-                 guard_audit_fill: Optional[bool] = None):
+                 guard_audit_fill: bool = True):
         """sampling: arithmetic of the sampling network -- "guarded" (plain fp16 for every ray + the split-precision engine where the
         audited guard band cannot decide; the split engine's selections), "split", "fp32", "fp16" (opt-in speed mode).  Default (None),
         as in the `adanerf` CLI and bench.py: "guarded" with a 16-bit shading network; "split" with precision="fp32" -- the
         tight-tolerance parity mode, where the kept oracle values of the rays the guarded mode does not re-evaluate (the fp16 engine's,
-        within the band of the exact ones: ~4e-3) would be the largest error of the frame.  guard_*: include/adanerf_hip.h adanerf_options."""
-        if guard_audit_fill is None:      # a shard of a frame: the audit fills the refinement pass's last round instead of adding one (ADANERF_FLAG_GUARD_AUDIT_FILL)
-            guard_audit_fill = shard_world > 1
+        within the band of the exact ones: ~4e-3) would be the largest error of the frame.  guard_*: include/adanerf_hip.h adanerf_options.
+        guard_audit_fill (default, both hosts): the audit fills the refinement pass's last round instead of adding one, and never audits
+        less than a quarter of the 1 / period quota (ADANERF_FLAG_GUARD_AUDIT_FILL); False: exactly 1 / period of all rays every frame."""
         if sampling is None:
             sampling = "split" if (_PREC[precision] if isinstance(precision, str) else int(precision)) == PREC_FP32 else "guarded"
         self.settings = settings

@@ -592,7 +592,7 @@ def main():
         if world == 1 and not use_dist and not args.no_split_mode and args.batch_rays <= 0:
             sr2 = sharding.balanced_strip_rows(h, 2)
             qs = [adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h), precision=args.precision, sampling=args.sampling, guard_eps=args.guard_eps,
-                                             guard_audit_period=args.guard_audit_period, guard_audit_fill=False, device_id=local_rank,
+                                             guard_audit_period=args.guard_audit_period, device_id=local_rank,
                                              shard_rank=k, shard_world=2, strip_rows=sr2) for k in range(2)]
             for q in qs:
                 q.init()
@@ -658,7 +658,9 @@ def main():
                                      "band_source": R_GUARD_FROM.get(int(r.info.guard_calib_source)), "calibration_poses": int(r.info.guard_calib_poses),
                                      "monitor_max_seen": float(st.guard_max_seen), "monitor_pair_seen": float(st.guard_pair_seen),
                                      "monitor_violations": int(st.guard_violations), "band_widened": int(st.guard_widened),
-                                     "audit_period": int(r.info.guard_audit_period), "rays_audited": int(st.guard_audited),
+                                     "audit_period": int(r.info.guard_audit_period),
+                                     "audit_fill": "the audit fills the refinement pass's last round (at least a quarter of the 1 / period quota per frame)",
+                                     "rays_audited": int(st.guard_audited),
                                      "audit_mismatches": int(st.guard_audit_mismatch),
                                      "note": "monitor / audit counters are cumulative since the context was created (warm-up included)"}
                                     if args.sampling == "guarded" else None),

@@ -121,12 +121,13 @@ enum {
                                    lane-pair selection applies; implies the separate launch */
   ADANERF_FLAG_NO_GUARD_CACHE = 4, /* ADANERF_SAMPLING_GUARDED: neither read nor write the calibration record next to the model
                                    (adanerf_guard_calibration_file); the band is measured at the first guarded frame */
-  ADANERF_FLAG_GUARD_AUDIT_FILL = 8 /* ADANERF_SAMPLING_GUARDED: audit only as many decided rays per frame as the last, partly filled
-                                   round of the refinement pass has room for (its grid x 128 rays per round; the undecided rays fix
-                                   the number of rounds), so that the audit never costs a round of its own -- what a small share
-                                   of a sharded frame wants (31 000 undecided rays of an 80 000-ray share are one round, 34 000 with
-                                   the full 1 / period quota two).  The audited window moves through the frame's audit candidates
-                                   from cycle to cycle, so every ray is still audited; how soon depends on the room the frames leave
+  ADANERF_FLAG_GUARD_AUDIT_FILL = 8 /* ADANERF_SAMPLING_GUARDED (both shipped hosts set it): audit only as many decided rays per frame
+                                   as the last, partly filled round of the refinement pass has room for (its grid x 128 rays per
+                                   round; the undecided rays fix the number of rounds), so that the audit does not cost a round of
+                                   its own (the 800 x 800 frame: 8 rounds instead of 9; an 80 000-ray share of it: 1 instead of 2)
+                                   -- unless that room is less than a quarter of the frame's 1 / period quota, in which case it does
+                                   take one more round.  The audited window moves through the frame's audit candidates from cycle
+                                   to cycle, so every ray is audited at least once in 4 x period frames
                                    (adanerf_stats.guard_audited counts).  Without the flag every frame audits its full quota. */
 };
 

@@ -703,8 +703,8 @@ def guard_refine_list(undecided: np.ndarray, period: int, phase: int, cap_round:
     """The list pass 2 of the guarded selection works through (k_compact.hip.hpp refine_list_kernel), restated: ``undecided`` bool [R].
     Returns (rays int32 ascending, audit_only bool) -- every undecided ray, plus the decided rays audited at (period, phase): all of
     them, or with ``cap_round`` > 0 (ADANERF_FLAG_GUARD_AUDIT_FILL) only as many as the last round of ``cap_round`` rays has room for
-    beside the undecided ones, taken as a window of the audit candidates (in ray order) that starts at (cycle * room) mod candidates
-    and wraps round."""
+    beside the undecided ones -- plus one more round where that room is less than a quarter of the candidates -- taken as a window of
+    the audit candidates (in ray order) that starts at (cycle * room) mod candidates and wraps round."""
     und = np.asarray(undecided, bool)
     r = np.arange(und.shape[0])
     aud = np.zeros_like(und) if period <= 0 else ((((r & 31) - phase - (r >> 5)) & (period - 1)) == 0) & ~und
@@ -712,7 +712,10 @@ def guard_refine_list(undecided: np.ndarray, period: int, phase: int, cap_round:
     if cap_round > 0:
         n_und = int(und.sum())
         rounds = max(1, -(-n_und // cap_round))
-        room = min(cand.size, max(0, rounds * cap_round - n_und))
+        room = max(0, rounds * cap_round - n_und)
+        if room < (cand.size + 3) // 4:
+            room += cap_round
+        room = min(cand.size, room)
         if room < cand.size:
             off = (cycle * room) % cand.size if room > 0 else 0
             keep = ((np.arange(cand.size) - off) % cand.size) < room

@@ -178,11 +178,13 @@ def test_audit_rotation_covers_every_ray_once_per_period(period):
 
 def test_audit_fill_never_adds_a_round_and_starves_no_ray():
     """ADANERF_FLAG_GUARD_AUDIT_FILL (restated in guard_refine_list): the list is every undecided ray plus a window of the frame's audit
-    candidates that exactly fills the last round of the refinement pass (or all candidates when they fit); the window moves on by its
-    own length from cycle to cycle, so over ceil(candidates / room) cycles of one phase every candidate has been audited."""
+    candidates that exactly fills the last round of the refinement pass (or all candidates when they fit) -- one more round only where
+    that room is below a quarter of the candidates, so a frame never audits less than that; the window moves on by its own length from
+    cycle to cycle, so over ceil(candidates / room) <= 4 cycles of one phase every candidate has been audited."""
     rng = np.random.default_rng(3)
     R, period, cap = 20000, 16, 4096
-    for frac in (0.02, 0.19, 0.21, 0.39, 0.41, 0.97):
+    extra_rounds = 0
+    for frac in (0.02, 0.19, 0.21, 0.39, 0.405, 0.41, 0.97):
         und = rng.random(R) < frac
         n_und = int(und.sum())
         rounds = max(1, -(-n_und // cap))
@@ -191,16 +193,20 @@ def test_audit_fill_never_adds_a_round_and_starves_no_ray():
             cand = full[full_a]
             assert np.array_equal(full[~full_a], np.flatnonzero(und)) and (np.diff(full) > 0).all()
             seen = np.zeros(R, bool)
-            room = min(cand.size, rounds * cap - n_und)
-            cycles = 1 if room >= cand.size else (-(-cand.size // room) if room else 0)
+            room = rounds * cap - n_und
+            more = room < (cand.size + 3) // 4
+            extra_rounds += more
+            room = min(cand.size, room + (cap if more else 0))
+            cycles = 1 if room >= cand.size else -(-cand.size // room)
+            assert cycles <= 4 and room >= min(cand.size, (cand.size + 3) // 4)
             for cycle in range(cycles):
                 rays, a = O.guard_refine_list(und, period, phase, cap, cycle)
                 assert (np.diff(rays) > 0).all() and np.array_equal(rays[~a], np.flatnonzero(und))
-                assert a.sum() == room and rays.size <= rounds * cap and np.isin(rays[a], cand).all()
-                assert rays.size == rounds * cap or room == cand.size          # the last round is full, or every candidate is in
+                assert a.sum() == room and rays.size <= (rounds + more) * cap and np.isin(rays[a], cand).all()
+                assert rays.size == (rounds + more) * cap or room == cand.size          # the last round is full, or every candidate is in
                 seen[rays[a]] = True
-            if room:
-                assert seen[cand].all(), "audit candidates left out for good"
+            assert seen[cand].all(), "audit candidates left out for good"
+    assert 0 < extra_rounds < 21            # the population has both kinds of frames
     # nothing undecided: one round's worth of audit still runs
     rays, a = O.guard_refine_list(np.zeros(R, bool), period, 3, cap, 0)
     assert a.all() and rays.size == min(cap, R // period)

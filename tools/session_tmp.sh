@@ -1,14 +1,12 @@
 #!/bin/bash
-# session 29: full GPU suite, profiles and bench lines on the current sources
+# session 30: audit-fill with a guaranteed quarter quota as the hosts' default
 cd /root/repo
-O=gpurun_out/r04_s29; mkdir -p $O
-ADANERF_MEASURED_LOG=$PWD/$O/parity_measured.log timeout 900 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-tools/collect_all_profiles.sh > $O/collect.log 2>&1
-tools/bench_all.sh > $O/bench_all.log 2>&1
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
-adanerf_amd/bin/mfma_peak > $O/mfma_peak.log 2>&1
-cat $O/bench_all.log; python - <<'PY'
+O=gpurun_out/r04_s30; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "guard or bench or smoke or frame" > $O/pytest_parity_subset.log 2>&1; tail -3 $O/pytest_parity_subset.log
+timeout 600 python -m pytest tests/test_gpu_configs.py -q -x -m gpu -k "guarded or config4 or config5 or config2" > $O/pytest_configs_subset.log 2>&1; tail -3 $O/pytest_configs_subset.log
+python bench.py --no-cpu-baseline --no-speed-mode 2>/dev/null | tail -1 > $O/bench_fill.json
+python - <<'PY'
 import json
-d=json.load(open('gpurun_out/r04_s29/bench_default.json')); print(round(d['value'],1), d['roofline']['frac'], d['roofline']['traffic'], d['roofline'].get('frac_of_sustained'), d['cpu_baseline']['value'], d['split_frame_mode']['value'], d['exact_mode']['value'])
+d=json.load(open('gpurun_out/r04_s30/bench_fill.json')); print(round(d['value'],1), d['stage_ms_per_frame'], d['config']['rays_refined_per_frame'], d['config']['guard']['rays_audited'], d['exact_mode']['value'], d['split_frame_mode']['value'])
 PY
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
