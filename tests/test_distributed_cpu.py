@@ -1,7 +1,9 @@
 """N > 1 path on CPU: world_size-2 gloo processes shard a small frame by image strips exactly as
 bench.py does on GPUs (each rank renders its rows -- here with the oracle standing in for the device
 renderer --, one gather of padded RGBA8 payloads to rank 0, de-interleave), and the assembled image must
-equal the unsharded frame byte for byte."""
+equal the unsharded frame byte for byte.  With sub > 1 every rank renders its share as `sub` sub-shares -- virtual ranks rank * sub + k of
+a world of world * sub -- into one payload [sub][rows][4]: what bench.py --gpus N --sub-shares 2 does (the gathered buffer is then already
+in virtual-rank order)."""
 import os
 import socket
 import sys
@@ -30,21 +32,23 @@ def _render_rows(sc, wts, rows):
     return O.to_rgba8(res["rgb"])
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, sub=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc, wts = _scene()
-    rows = S.rows_of_rank(H, STRIP, world, rank)
-    rgba = _render_rows(sc, wts, rows)
-    assert rgba.shape[0] == S.rays_local(W, H, STRIP, world, rank)
-    rmax = S.rays_local_max(W, H, STRIP, world)
-    payload = torch.zeros((rmax, 4), dtype=torch.uint8)
-    payload[:rgba.shape[0]] = torch.from_numpy(rgba)
+    vworld = world * sub
+    rmax = S.rays_local_max(W, H, STRIP, vworld)
+    payload = torch.zeros((sub, rmax, 4), dtype=torch.uint8)
+    for k in range(sub):
+        vrank = rank * sub + k
+        rgba = _render_rows(sc, wts, S.rows_of_rank(H, STRIP, vworld, vrank))
+        assert rgba.shape[0] == S.rays_local(W, H, STRIP, vworld, vrank)
+        payload[k, :rgba.shape[0]] = torch.from_numpy(rgba)
     gathered = [torch.zeros_like(payload) for _ in range(world)] if rank == 0 else None
     dist.gather(payload, gathered, dst=0)
     if rank == 0:
-        img = S.assemble(torch.stack(gathered).numpy(), W, H, STRIP, world)
+        img = S.assemble(torch.stack(gathered).numpy().reshape(vworld, rmax, 4), W, H, STRIP, vworld)
         np.save(out_path, img)
     dist.barrier()
     dist.destroy_process_group()
@@ -58,10 +62,10 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_strip_sharded_frame_over_gloo(tmp_path, world):
+@pytest.mark.parametrize("world,sub", [(2, 1), (3, 1), (2, 2)])
+def test_strip_sharded_frame_over_gloo(tmp_path, world, sub):
     out = str(tmp_path / "img.npy")
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, sub), nprocs=world, join=True)
     sc, wts = _scene()
     full = _render_rows(sc, wts, np.arange(H))
     assert np.array_equal(np.load(out), full)
