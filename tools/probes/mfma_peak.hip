@@ -8,6 +8,108 @@
 
 using namespace adanerf::probe;
 
+// The shading kernel's operand delivery around the same MFMA stream (round 4, DESIGN 3.1 "pinned ceiling"): one wave per SIMD, two
+// accumulator chains (= two 32-sample blocks), B operands ReLU-like in registers, and
+//   LDS    every A fragment (1 KiB per wave) read from LDS with ds_read_b128, one read per TWO MFMAs, requested 4 fragments ahead;
+//   DMA    + every wave copies 1 KiB global -> LDS (buffer_load ... lds, L2-resident source) per 8 MFMAs -- the weight ring's refill rate
+//          (1184 KiB per 256-sample tile = 2368 MFMAs per wave);
+//   VALU   + one v_cvt_pk_bf16_f32 and one v_pk_max_i16 per two MFMAs -- the conversions of a 256-wide layer's outputs.
+// No barriers, no waits other than the data's own: what is left when scheduling is perfect.
+enum { kLds = 1, kDma = 2, kValu = 4 };
+
+template <int WHAT>
+__global__ __launch_bounds__(256) void mfma_burn_dataflow(int iters, const uint32_t* __restrict__ gsrc, float* sink, uint64_t* clocks) {
+  __shared__ __attribute__((aligned(1024))) uint32_t lds[16384];      // 64 KiB: 32 KiB read as fragments, 32 KiB DMA target
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 16384; i += 256) lds[i] = rnd_pair(0x2468aceu + i * 7u + blockIdx.x * 131u, false);
+  __syncthreads();
+  u32x4 b0[8], b1[8];
+  for (int k = 0; k < 8; ++k)
+    for (int i = 0; i < 4; ++i) {
+      b0[k][i] = rnd_pair(0x89abcdeu + threadIdx.x * 64u + blockIdx.x * 16384u + k * 8u + i, false, true);
+      b1[k][i] = rnd_pair(0x13579bdu + threadIdx.x * 64u + blockIdx.x * 16384u + k * 8u + i, false, true);
+    }
+  f32x16 acc0, acc1;
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  typedef const __attribute__((address_space(3))) u32x4* lds_rd;
+  const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds));
+  auto frag = [&](int f) -> u32x4 {      // fragment f of this wave's 8 KiB window: lane-linear, conflict-free
+    if (!(WHAT & kLds)) return b0[f & 7];
+    return *((lds_rd)(uintptr_t)(base + wave * 8192 + (f & 7) * 1024 + lane * 16));
+  };
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(gsrc), 0, 0x7fffffff, 0x00020000);
+#endif
+  uint64_t t0 = 0, r0 = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    t0 = __builtin_readcyclecounter();
+    r0 = wall_clock64();
+  }
+  u32x4 fr[4];
+  for (int i = 0; i < 4; ++i) fr[i] = frag(i);
+  uint32_t packed = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {      // 8 fragments -> 16 MFMAs
+      const u32x4 a = fr[u & 3];
+      fr[u & 3] = frag(u + 4);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b0[u]), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b1[u]), acc1, 0, 0, 0);
+      if (WHAT & kValu) {
+        uint32_t p;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(p) : "v"(__builtin_bit_cast(float, b0[u][0])), "v"(__builtin_bit_cast(float, b1[u][1])));
+        packed ^= p;
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+      if ((WHAT & kDma) && (u == 3 || u == 7)) {      // 1 KiB per 8 MFMAs per wave
+        const uint32_t dst = base + 32768 + wave * 8192 + (u >> 2) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)static_cast<uintptr_t>(dst), 16, lane * 16,
+                                                 static_cast<int>(((it * 2 + (u >> 2)) & 1023) * 1024), 0, 0);
+      }
+#endif
+    }
+    if ((it & 127) == 127) {
+      for (int r = 0; r < 16; ++r) {
+        acc0[r] *= 1.0e-6f;
+        acc1[r] *= 1.0e-6f;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clocks[0] = __builtin_readcyclecounter() - t0;
+    clocks[1] = wall_clock64() - r0;
+  }
+  const float s_ = acc0[0] + acc0[7] + acc1[3] + __builtin_bit_cast(float, packed);
+  if (s_ == 12345.678f) sink[0] = s_ + lds[threadIdx.x + 8192];
+}
+
+template <int WHAT>
+void run_dataflow(int cus, const uint32_t* gsrc, float* sink, uint64_t* d_clocks, double target_ms) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  int iters = 200;
+  hipLaunchKernelGGL((mfma_burn_dataflow<WHAT>), dim3(cus), dim3(256), 0, 0, 50, gsrc, sink, d_clocks);
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((mfma_burn_dataflow<WHAT>), dim3(cus), dim3(256), 0, 0, iters, gsrc, sink, d_clocks);
+    hipEventRecord(e1, 0);
+    if (hipEventSynchronize(e1) != hipSuccess) {
+      printf("dataflow launch failed\n");
+      return;
+    }
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep == 0) iters = static_cast<int>(iters * target_ms / (ms > 0.01 ? ms : 0.01)) + 1;
+  }
+  uint64_t ck[2] = {0, 0};
+  hipMemcpy(ck, d_clocks, sizeof(ck), hipMemcpyDeviceToHost);
+  const double tf = 2.0 * 32 * 32 * 16 * 16.0 * iters * 4.0 * cus / ms * 1e-9, mhz = ck[1] ? 100.0 * ck[0] / static_cast<double>(ck[1]) : 0.0;
+  printf("bf16 relu + %-22s 2 chains, 1 wave/SIMD %9.1f ms  %7.0f TFLOP/s  %5.0f MHz  issue-slot use %.3f  (of 2500: %.3f)\n",
+         WHAT == kLds ? "LDS fragments" : WHAT == (kLds | kDma) ? "LDS + DMA refill" : WHAT == (kLds | kDma | kValu) ? "LDS + DMA + conversions" : "registers only",
+         ms, tf, mhz, mhz > 0 ? tf * 1e12 / (cus * 4.0 * 1024.0 * mhz * 1e6) : 0.0, tf / 2500.0);
+}
+
 template <int CHAINS, bool F16, int MODE>
 void run(int waves_per_simd, int cus, float* sink, uint64_t* d_clocks, double target_ms) {
   double tf = 0, mhz = 0, ms = 0;
@@ -40,5 +142,13 @@ int main() {
     run<2, false, kRandom>(1, cus, sink, d_clocks, target);
     run<4, false, kRandom>(2, cus, sink, d_clocks, target);
   }
+  // the shading kernel's dataflow around the ReLU-like stream (sustained only)
+  uint32_t* gsrc;
+  if (hipMalloc(&gsrc, 1024 * 1024 + 4096) != hipSuccess || hipMemset(gsrc, 0x3c, 1024 * 1024 + 4096) != hipSuccess) return 1;
+  printf("-- the shading kernel's operand delivery around the ReLU-like stream (~500 ms per launch)\n");
+  run_dataflow<0>(cus, gsrc, sink, d_clocks, 500.0);
+  run_dataflow<kLds>(cus, gsrc, sink, d_clocks, 500.0);
+  run_dataflow<kLds | kDma>(cus, gsrc, sink, d_clocks, 500.0);
+  run_dataflow<kLds | kDma | kValu>(cus, gsrc, sink, d_clocks, 500.0);
   return 0;
 }
