@@ -224,32 +224,37 @@ __device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], 
   constexpr int KS = S1 + S2, D = KS < kStageAhead ? KS : kStageAhead;
   static_assert(KS * 1024 <= BUF_BYTES, "tile does not fit its LDS buffer");
   const int h = lane >> 5;
-  // The conversions of tile m - 1 run AFTER tile m's wait + barrier, copy issue and first fragment requests (tune::kGenericDefer): what
-  // a wave would otherwise sit out -- the LDS latency of the first fragment after the barrier -- is covered by 16 x NB values of VALU work
-  // it had to do anyway, and the drain of the tile's last MFMA is covered by the barrier.  Only a layer's last tile converts at once
-  // (the next layer reads its outputs).
-  f32x16 acc[NB];
-  auto convert = [&](int m) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      if (KEEP_F32_TILE == m) {
-        keep[nb] = acc[nb];
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(acc[nb], m, g, out + nb * O);
-      }
+  // Where do a tile's conversions (ReLU + pack, 16 x NB values) go?  tune::kGenericSpread<W>: spread, a quad at a time, over the k-steps of
+  // the NEXT tile, between its MFMAs -- with one wave per SIMD (width 256) nothing else would issue while the pipe works, and nothing
+  // else would keep the pipe working while they issue; costs a second accumulator set.  tune::kGenericDefer: in one piece behind the
+  // next tile's wait + barrier and first fragment requests (no second set; measured: no effect).  Otherwise right behind the tile's own
+  // MFMAs.  A layer's last tile always converts at once: the next layer reads its outputs.
+  constexpr bool SPREAD = tune::kGenericSpread != 0 && (tune::kGenericSpread >= 2 || O >= 64);      // O = W / 4 (+ 8): 1 = width 256 only
+  constexpr int QUADS = 4 * NB, QPS = (QUADS + KS - 1) / KS;      // quads of the previous tile converted per k-step
+  f32x16 accs[SPREAD ? 2 : 1][NB];
+  auto convert_quad = [&](f32x16 (&ac)[NB], int mm, int q) {
+    const int nb = q >> 2, g = q & 3;
+    if (KEEP_F32_TILE == mm) {
+      if (g == 0) keep[nb] = ac[nb];
+    } else {
+      epilogue_quad_16<ET, RELU>(ac[nb], mm, g, out + nb * O);
     }
   };
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const bool last = m == MT - 1;
+    f32x16 (&acc)[NB] = accs[SPREAD ? (m & 1) : 0];
+    f32x16 (&pacc)[NB] = accs[SPREAD ? ((m & 1) ^ 1) : 0];
     const uint32_t rd = ts_next<BUF_BYTES>(st, last ? next_off : w_off + (m + 1) * KS * 64, last ? next_frags : KS);
     u32x4 fr[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) fr[i] = lds_read128(rd + i * 1024);
-    if (tune::kGenericDefer) {
+    if (!SPREAD && tune::kGenericDefer) {
       __builtin_amdgcn_sched_barrier(0);
-      if (m > 0) convert(m - 1);
+      if (m > 0) {
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q) convert_quad(acc, m - 1, q);
+      }
     }
     if (LDSB && tune::kGenericBiasDirect && !(tune::kAblateGeneric & 2)) {
       // the tile's own bias block straight into its accumulators (no copy a tile ahead, no 16 moves per block): the first MFMA
@@ -286,9 +291,16 @@ __device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], 
         const u32x4 b = {src[0], src[1], src[2], src[3]};
         acc[nb] = ET::mfma(a, b, acc[nb]);
       }
+      if (SPREAD && m > 0) {
+#pragma unroll
+        for (int q = s * QPS; q < (s + 1) * QPS && q < QUADS; ++q) convert_quad(pacc, m - 1, q);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!tune::kGenericDefer || last) convert(m);
+    if (last || !(SPREAD || tune::kGenericDefer)) {
+#pragma unroll
+      for (int q = 0; q < QUADS; ++q) convert_quad(acc, m, q);
+    }
   }
 }
 

@@ -82,6 +82,14 @@ constexpr int kGenericOcc256 = ADN_GEN_OCC256;
 #else
 constexpr int kGenericOcc256 = 1;
 #endif
+// kGenericSpread: a tile's conversions are spread over the k-steps of the NEXT tile, between its MFMAs, out of a second accumulator set
+// (k_generic16.hip.hpp layer_16_staged).  1: at width 256 only (one wave per SIMD, registers to spare); 2: every width; 0: off.
+// Measured (profiles/r04_variants_generic_spread.log): 5 x 256 2.496 -> 2.444 ms with 1; nothing at width 128, slower at width 64 with 2.
+#if ADN_OVERRIDABLE && defined(ADN_GEN_SPREAD)
+constexpr int kGenericSpread = ADN_GEN_SPREAD;
+#else
+constexpr int kGenericSpread = 1;
+#endif
 // kGenericDefer: a tile's conversions run behind the NEXT tile's barrier and first fragment requests (k_generic16.hip.hpp, layer_16_staged)
 #if ADN_OVERRIDABLE && defined(ADN_GEN_DEFER)
 constexpr bool kGenericDefer = ADN_GEN_DEFER != 0;

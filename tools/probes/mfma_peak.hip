@@ -86,24 +86,24 @@ __global__ __launch_bounds__(256) void mfma_burn_dataflow(int iters, const uint3
 template <int WHAT>
 void run_dataflow(int cus, const uint32_t* gsrc, float* sink, uint64_t* d_clocks, double target_ms) {
   hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
   int iters = 200;
   hipLaunchKernelGGL((mfma_burn_dataflow<WHAT>), dim3(cus), dim3(256), 0, 0, 50, gsrc, sink, d_clocks);
   float ms = 0;
   for (int rep = 0; rep < 2; ++rep) {
-    hipEventRecord(e0, 0);
+    (void)hipEventRecord(e0, 0);
     hipLaunchKernelGGL((mfma_burn_dataflow<WHAT>), dim3(cus), dim3(256), 0, 0, iters, gsrc, sink, d_clocks);
-    hipEventRecord(e1, 0);
+    (void)hipEventRecord(e1, 0);
     if (hipEventSynchronize(e1) != hipSuccess) {
       printf("dataflow launch failed\n");
       return;
     }
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     if (rep == 0) iters = static_cast<int>(iters * target_ms / (ms > 0.01 ? ms : 0.01)) + 1;
   }
   uint64_t ck[2] = {0, 0};
-  hipMemcpy(ck, d_clocks, sizeof(ck), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(ck, d_clocks, sizeof(ck), hipMemcpyDeviceToHost);
   const double tf = 2.0 * 32 * 32 * 16 * 16.0 * iters * 4.0 * cus / ms * 1e-9, mhz = ck[1] ? 100.0 * ck[0] / static_cast<double>(ck[1]) : 0.0;
   printf("bf16 relu + %-22s 2 chains, 1 wave/SIMD %9.1f ms  %7.0f TFLOP/s  %5.0f MHz  issue-slot use %.3f  (of 2500: %.3f)\n",
          WHAT == kLds ? "LDS fragments" : WHAT == (kLds | kDma) ? "LDS + DMA refill" : WHAT == (kLds | kDma | kValu) ? "LDS + DMA + conversions" : "registers only",
