@@ -669,6 +669,9 @@ def main():
                "roofline": roofline, "cpu_baseline": cpu, "stage_ms_per_frame": stage_ms,
                "sampling_mlp_algorithmic_tflops": smp_tflops, "sampling_roofline": sampling_roofline, "hbm_stages": hbm, "quality": quality, "exact_mode": exact, "speed_mode": speed,
                "split_frame_mode": split}
+        if P > 1 or fif > 1:
+            rec["stage_ms_note"] = ("rank 0's contexts run concurrently on their own streams (%s): the per-stage HIP-event times are summed over them "
+                                    "and overlap in time, so they add up to more than ms_per_step" % ("%d sub-shares of the frame" % P if P > 1 else "two frames in flight"))
         if shard_samples:
             mean_s = sum(shard_samples) / len(shard_samples)
             rec["shards"] = {"samples_per_frame": shard_samples, "shade_ms_per_frame": shard_shade_ms,
