@@ -63,9 +63,17 @@ bool NeuralRenderer::init() {
   opt.threshold = settings.threshold;
   opt.sampling_mode = settings.sampling == "split" ? ADANERF_SAMPLING_SPLIT_FP16 : (settings.sampling == "fp32" ? ADANERF_SAMPLING_FP32
                       : (settings.sampling == "fp16" ? ADANERF_SAMPLING_FP16 : ADANERF_SAMPLING_GUARDED));
-  // --gpus N: rows are cut into strips, strip s belongs to GPU s % N; largest strip height <= 8 rows that
-  // gives every GPU the same number of strips
-  const int world = settings.gpus;
+  // --gpus N: rows are cut into strips, strip s belongs to (virtual) rank s % world; largest strip height <= 8 rows that
+  // gives every rank the same number of strips.  --sub-shares P: every GPU hosts P virtual ranks (rank / P = its GPU), i.e. renders its
+  // share of the frame as P concurrent sub-shares on P contexts / streams -- one sub-share's kernels take the CUs the other's tails
+  // leave idle, the frame's latency does not grow (bench.py --sub-shares); default 2 on several GPUs when the rows split evenly
+  auto even_split = [&](int ranks) {
+    for (int sr = 8; sr >= 1; --sr)
+      if (opt.height % sr == 0 && (opt.height / sr) % ranks == 0) return true;
+    return false;
+  };
+  const int parts = settings.sub_shares > 0 ? settings.sub_shares : (settings.gpus > 1 && even_split(2 * settings.gpus) ? 2 : 1);
+  const int world = settings.gpus * parts;
   if (world > 1 && settings.render_oracle) {
     err = "--oracle renders one context's rays; use it with --gpus 1";
     return false;
@@ -82,7 +90,7 @@ bool NeuralRenderer::init() {
   opt.strip_rows = strip_rows;
   for (int rank = 0; rank < world; ++rank) {
     opt.shard_rank = rank;
-    opt.device_id = settings.same_device ? 0 : rank;
+    opt.device_id = settings.same_device ? 0 : rank / parts;
     adanerf_ctx* c = nullptr;
     if (adanerf_create(settings.model_path.c_str(), &opt, &c) != ADANERF_OK) {
       err = adanerf_last_error(nullptr);

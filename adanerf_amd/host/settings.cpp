@@ -12,7 +12,7 @@ const char* Settings::usage() {
          "               [--yaw DEG] [--pitch DEG]\n"
          "               [--samples N] [--threshold T] [--oracle]\n"
          "               [--script FILE] [--log-camera] [--dry-run]     input replay: one line of events per frame\n"
-         "               [--gpus N] [--same-device]\n";
+         "               [--gpus N] [--same-device] [--sub-shares P]\n";
 }
 
 bool Settings::init(int argc, char** argv, std::string* err) {
@@ -80,6 +80,9 @@ bool Settings::init(int argc, char** argv, std::string* err) {
       gpus = std::max(1, std::atoi(argv[++i]));
     } else if (a == "--same-device") {
       same_device = true;
+    } else if (a == "--sub-shares") {
+      if (!need(i, 1)) return false;
+      sub_shares = std::max(1, std::min(4, std::atoi(argv[++i])));
     } else if (a == "--oracle") {
       render_oracle = true;
     } else if (a == "--script") {

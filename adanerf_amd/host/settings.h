@@ -22,6 +22,8 @@ class Settings {
   float threshold = -1.f;
   int gpus = 1;                 // --gpus N: one context per GPU in this process, strips exchanged with peer copies over xGMI
   bool same_device = false;     // --same-device: all N contexts on device 0 (exercises the N-GPU path on a 1-GPU box)
+  int sub_shares = 0;           // --sub-shares P: every GPU renders its share of a frame as P concurrent sub-shares (contexts / streams);
+                                // 0: 2 with --gpus N > 1 when the rows split evenly over 2 N, else 1
   std::string script;           // --script FILE: replay input events, one line per frame (inputhandler.h)
   bool log_camera = false;      // --log-camera: print position / yaw / pitch / view per frame
   bool dry_run = false;         // --dry-run: replay the script without a device (no rendering)

@@ -1639,13 +1639,14 @@ def test_single_process_multi_context_gather(cases, tmp_path):
     md = str(tmp_path / "model")
     O.write_model_dir(md, sc, wts)
     imgs = []
-    for extra in ([], ["--gpus", "3", "--same-device"]):
+    # (--gpus 2: two sub-shares per GPU by default = four contexts; --gpus 1 --sub-shares 2: the frame as two concurrent sub-shares)
+    for extra in ([], ["--gpus", "3", "--same-device"], ["--gpus", "2", "--same-device"], ["--gpus", "1", "--sub-shares", "2"]):
         out = subprocess.run([exe, md, "-s", str(w), str(h), "-w", "--frames", "100", "--yaw", "100", "--pitch", "0"] + extra,
                              capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "avg samples ppx" in out.stdout
         imgs.append(open(os.path.join(md, "out.bmp"), "rb").read())
-    assert imgs[0] == imgs[1]
+    assert all(im == imgs[0] for im in imgs[1:])
 
 
 @pytest.mark.gpu
