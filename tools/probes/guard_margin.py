@@ -1,6 +1,7 @@
 """How much head-room the calibrated guard band has over many poses: config-2 model at 800 x 800, P random poses inside the view cell.
-Per pose: the monitor's running maximum (largest |fp16 - split| on the top value of a re-evaluated ray so far), violations, refined
-rays; for every 8th pose also the true maximum over ALL raw outputs of the frame (both engines through the stage API)."""
+Per pose: the monitor's running maxima (largest |fp16 - split| over all 128 outputs of a re-evaluated ray so far, largest pair error),
+violations, audited rays and audit mismatches, refined rays; for every 8th pose also the true maximum over ALL raw outputs of the frame
+(both engines through the stage API)."""
 import json, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -26,7 +27,9 @@ with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h), precision="bf16"
         rg.set_camera(pose, rot)
         st = rg.render(None, None, stats=True)
         rg.lib.adanerf_get_info(rg.handle, rg.info)
-        rec = dict(pose=i, eps=float(rg.info.guard_eps), monitor_running_max=float(st.guard_max_seen), violations=int(st.guard_violations),
+        rec = dict(pose=i, eps=float(rg.info.guard_eps), eps_pair=float(rg.info.guard_eps_pair), monitor_running_max=float(st.guard_max_seen),
+                   monitor_pair_running_max=float(st.guard_pair_seen), violations=int(st.guard_violations), audited=int(st.guard_audited),
+                   audit_mismatches=int(st.guard_audit_mismatch), widened=int(st.guard_widened),
                    refined_frac=st.rays_refined / float(w * h), spp=st.total_samples / float(w * h))
         if i % 8 == 0:
             for r, b in ((rs, bs), (rf, bf)):
@@ -36,4 +39,6 @@ with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h), precision="bf16"
             worst = max(worst, d)
             rec["true_max_all_outputs"] = d
         print(json.dumps(rec), flush=True)
-    print(json.dumps(dict(poses=P, eps=rec["eps"], monitor_max=rec["monitor_running_max"], violations=rec["violations"], worst_true_max_sampled=worst)))
+    print(json.dumps(dict(poses=P, eps=rec["eps"], eps_pair=rec["eps_pair"], monitor_max=rec["monitor_running_max"], monitor_pair_max=rec["monitor_pair_running_max"],
+                          violations=rec["violations"], audited=rec["audited"], audit_mismatches=rec["audit_mismatches"], widened=rec["widened"],
+                          worst_true_max_sampled=worst)))
