@@ -429,6 +429,9 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
         *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(rgb_tile[nb][0], rgb_tile[nb][1], rgb_tile[nb][2], alpha_tile[nb][0]);
     }
   }
+  // no LDS-DMA may outlive the workgroup's LDS allocation.  (Nothing is in flight here -- the last pass issues no copy for a next one and
+  // every tile waited for its own -- but the drain keeps that true by construction: tests/test_host_cpu.py checks it on the assembly.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---- sampling network of any topology on the split-precision engine ----------------------------------------------------------------
@@ -475,6 +478,8 @@ __device__ __forceinline__ void layer_16x3_staged(TileStage& st, float (&br)[16]
   constexpr int D = KS < 2 ? KS : 2;      // pairs requested ahead
   static_assert(KS * 2048 <= BUF_BYTES, "tile does not fit its LDS buffer");
   const int h = lane >> 5;
+  // (spreading tile m - 1's pairs over tile m's k-steps out of a second accumulator pair, as layer_16_staged does at width 256, gains
+  // 0.7 % at 5 x 256 -- profiles/r04_variants_generic_spread_sampling.log -- and was not kept)
   f32x16 acc, cross;      // tile m - 1's split / conversion runs behind tile m's barrier and first fragment requests (see layer_16_staged)
   auto convert = [&](int m) {
 #pragma unroll
@@ -645,6 +650,7 @@ __global__ __launch_bounds__(256, (STAGED && W <= 128 && FP <= 10) ? 2 : 1) void
       else r[1] = make_float4(rd[0], rd[1], rd[2], 0.f);
     }
   }
+  if constexpr (STAGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup's LDS allocation (see above)
 }
 
 }  // namespace adanerf

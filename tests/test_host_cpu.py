@@ -86,6 +86,57 @@ def test_no_kernel_goes_through_the_lds_crossbar_for_lane_exchanges():
         assert "ds_bpermute" not in text and "ds_permute" not in text
 
 
+def _device_assembly():
+    """gfx950 assembly of the library's two translation units with the shipped flags, cached in /tmp under the source hash (one ~60 s
+    compile per change of the sources); None without hipcc."""
+    import shutil
+    import subprocess
+    from adanerf_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        return None
+    texts = []
+    for src in ("adanerf_hip.hip", "launch_f32.hip"):
+        out = "/tmp/adanerf_isa_%s_%s.s" % (B.source_hash(), src)
+        if not os.path.exists(out):
+            tmp = out + ".tmp%d" % os.getpid()
+            subprocess.run([hipcc] + B.HIPCC_FLAGS + B.TU_FLAGS.get(src, []) + ["-I", os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                            os.path.join(B.CSRC, src), "-o", tmp], check=True, stderr=subprocess.DEVNULL)
+            os.replace(tmp, out)
+        texts.append(open(out).read())
+    return "\n".join(texts)
+
+
+def test_device_code_has_no_crossbar_exchange_and_no_lds_dma_outliving_its_workgroup():
+    """Instruction-level companions of the test above, on the shipped flags' gfx950 assembly: (1) no ds_bpermute / ds_permute
+    in any kernel; (2) every kernel that copies global -> LDS with buffer_load ... lds (the weight rings and tile stages of the MLP
+    kernels) drains its vector-memory counter -- s_waitcnt vmcnt(0) -- after the last such copy in program order and before its final
+    s_endpgm: no LDS-DMA write can land after the workgroup's LDS allocation has been handed to another workgroup."""
+    text = _device_assembly()
+    if text is None:
+        pytest.skip("no hipcc")
+    assert "ds_bpermute" not in text and "ds_permute" not in text
+    kernels = re.split(r"\n\s*\.globl\s+", text)
+    checked = []
+    for k in kernels:
+        name = k.split("\n", 1)[0].strip()
+        body = k.split(".end_amdhsa_kernel")[0] if ".amdhsa_kernel" in k else k
+        lines = [ln.split(";")[0].strip() for ln in body.split("\n")]
+        lines = [ln for ln in lines if ln and not ln.startswith(".")]
+        dma = [i for i, ln in enumerate(lines) if re.match(r"(buffer|global)_load_\w+ .*\blds\b", ln)]
+        if not dma:
+            continue
+        ends = [i for i, ln in enumerate(lines) if ln.startswith("s_endpgm")]
+        assert ends, name
+        tail = lines[dma[-1] + 1:ends[-1]]
+        assert any(re.match(r"s_waitcnt\b.*vmcnt\(0\)", ln) for ln in tail), "%s: LDS-DMA in flight at s_endpgm" % name
+        checked.append(name)
+    # the kernels this is about: both 8 x 256 engines, the fp16 sampling pass, the run-time-shaped 16-bit kernels
+    for frag in ("shade_mlp16x2_kernel", "shade_mlp16_kernel", "sample_mlp16x3_kernel", "sample_mlp16_kernel", "shade_mlp16_gen_staged_kernel",
+                 "sample_mlp16x3_gen_kernel"):
+        assert any(frag in n for n in checked), frag
+
+
 def test_abi_handshake(lib):
     """adanerf_abi_version / adanerf_struct_sizes against the ctypes mirrors (load_library refuses a library that disagrees)."""
     sizes = (C.c_int32 * 3)()
