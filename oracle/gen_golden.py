@@ -627,6 +627,17 @@ def main():
         save_case(name, sc, dict(w=400, h=400, crop=[12, 20, 24, 16, 16], yaw=100.0, pitch=0.0, syn=dict(syn, n_in0=sc.n_in0)),
                   dirs, pose, rot, ref, n, "synthetic")
 
+    # --- case W3: the N4 residuals together -- 100 depth cells, hidden widths 96 / 160, two trunk skips, LogCentered positions
+    sc = dataclasses.replace(classroom_scene(6, 0.6), depth_bins=100, normalization="LogCentered")
+    syn = dict(seed=147, oracle_bias=0.1, oracle_scale=0.3, bins=100, layers=[4, 6], widths=[96, 160], skip1=[1, 3])
+    wts = O.synthetic_weights(syn["seed"], n_in0=sc.n_in0, oracle_bias=syn["oracle_bias"], oracle_scale=syn["oracle_scale"], bins=100,
+                              layers=tuple(syn["layers"]), widths=tuple(syn["widths"]), skip1=syn["skip1"])
+    dirs = subset_dirs(400, 400, sc.fov, 12, 20, 24, 16, 16)
+    tc = build_reference(R, sc, wts, 400, 400)
+    ref = run_reference(R, tc, dirs, pose, rot)
+    save_case("syn_combo_bins100_w96_w160_skips_logcentered", sc, dict(w=400, h=400, crop=[12, 20, 24, 16, 16], yaw=100.0, pitch=0.0, syn=dict(syn, n_in0=sc.n_in0)),
+              dirs, pose, rot, ref, 6, "synthetic")
+
     # --- cases O, P: small crops that carry the secondary compositing outputs (all cases written from now on do)
     sc = classroom_scene(8, 0.2)
     dirs = subset_dirs(800, 800, sc.fov, 24, 40, 24, 16, 32)

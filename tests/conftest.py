@@ -99,6 +99,6 @@ ENCODING_CASES = ["syn_enc_6-3_12-2", "syn_enc_16-1_1-16"]
 NORM_CASES = ["classroom_norm_none", "classroom_norm_centered", "classroom_norm_maxdepth", "classroom_norm_maxdepthcentered",
               "classroom_norm_logcentered", "classroom_norm_inversedistcentered", "classroom_norm_isd_custom_centre", "classroom_norm_key_absent"]
 # multiDepthFeatures != 128: a sampling network with 64 / 100 depth cells (the device pads the rows to 128 absent bins)
-BINS_CASES = ["syn_bins64_n8", "syn_bins100_n6"]
+BINS_CASES = ["syn_bins64_n8", "syn_bins100_n6", "syn_combo_bins100_w96_w160_skips_logcentered"]      # the last: with odd widths, two skips, LogCentered too
 COARSE_FINE_CASES = ["classroom_coarse_fine_16_24", "ndc_coarse_fine_12_20"]      # vanilla NeRF, hierarchical sampling
 AUX_CASES = ["classroom_n8_aux", "ndc_n8_aux", "classroom_n8_mult_weights", "classroom_n8_bce_thr06", "ndc_pdf_n8", "classroom_pdf_ce_n8"]
