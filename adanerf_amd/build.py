@@ -24,6 +24,8 @@ def include_closure(sources=None):
             continue
         path = os.path.join(CSRC, rel)
         if not os.path.exists(path):
+            if os.path.basename(rel).startswith("x_"):      # experiment-only headers live in tools/experiments/ (reached through -I in
+                continue                                    # -DADN_EXPERIMENT builds only: tools/ablate.sh); never part of the shipped library
             raise RuntimeError("%s: included by the library sources but missing" % path)
         seen.add(rel)
         for inc in _INCLUDE.findall(open(path, encoding="utf-8", errors="replace").read()):
@@ -76,10 +78,10 @@ def _stale(target, deps):
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False, out=None, extra_flags=()):
+def build_library(force=False, verbose=False, out=None, extra_flags=(), tu_flags=None):
     """hipcc --offload-arch=gfx950: one object per translation unit (TU_FLAGS), then -shared ->
-    adanerf_amd/lib/libadanerf_hip.so (cross-compiles without a GPU).  ``out`` / ``extra_flags``: experiment variants
-    (tools/ablate.sh)."""
+    adanerf_amd/lib/libadanerf_hip.so (cross-compiles without a GPU).  ``out`` / ``extra_flags`` / ``tu_flags`` ({source: [flags]},
+    on top of TU_FLAGS): experiment variants (tools/ablate.sh)."""
     variant = out is not None
     out = out or library_path()
     deps = [os.path.join(CSRC, d) for d in LIB_DEPS]
@@ -93,7 +95,8 @@ def build_library(force=False, verbose=False, out=None, extra_flags=()):
     procs, objs = [], []
     for src in LIB_SOURCES:
         obj = os.path.join(objdir, src + ".o")
-        cmd = [_hipcc()] + HIPCC_FLAGS + TU_FLAGS.get(src, []) + list(extra_flags) + ["-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        exp = ["-I", os.path.join(os.path.dirname(HERE), "tools", "experiments")] if "-DADN_EXPERIMENT" in extra_flags else []
+        cmd = [_hipcc()] + HIPCC_FLAGS + TU_FLAGS.get(src, []) + exp + list(extra_flags) + list((tu_flags or {}).get(src, [])) + ["-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
@@ -152,10 +155,18 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser(description=__doc__)
     ap.add_argument("--out", default=None, help="build an experiment variant of the library to this path instead")
     ap.add_argument("--flags", default="", help="extra hipcc flags for every translation unit (quoted string)")
+    ap.add_argument("--tu-flags", action="append", default=[], metavar="SOURCE=FLAGS",
+                    help="extra hipcc flags for ONE translation unit, e.g. --tu-flags 'launch_f32.hip=-fno-slp-vectorize' (repeatable)")
     a = ap.parse_args()
+    tu = {}
+    for spec in a.tu_flags:
+        src, _, fl = spec.partition("=")
+        if src not in LIB_SOURCES:
+            raise SystemExit("--tu-flags: %s is not one of %s" % (src, LIB_SOURCES))
+        tu.setdefault(src, []).extend(fl.split())
     if a.out:
-        print(build_library(force=True, verbose=True, out=os.path.abspath(a.out), extra_flags=a.flags.split()))
+        print(build_library(force=True, verbose=True, out=os.path.abspath(a.out), extra_flags=a.flags.split(), tu_flags=tu))
     else:
-        print(build_library(force=True, verbose=True, extra_flags=a.flags.split()))
+        print(build_library(force=True, verbose=True, extra_flags=a.flags.split(), tu_flags=tu))
         print(build_cli(force=True, verbose=True))
         print(build_probes(force=True, verbose=True))

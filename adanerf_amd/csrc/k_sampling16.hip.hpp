@@ -15,13 +15,34 @@ namespace adanerf {
 // kSplitScale (2^11) is defined in pack.hpp
 
 
+// Three bit-identical forms (v - hi is exact in fp32, and so is its product with 2^11; tune::kSplitPack, profiles/r05_lab_log.md):
+//  0  packed fp32 (v_pk_add_f32 + v_pk_mul_f32 on the pair): 6 instructions, two of them packed-fp32 ops inside an MFMA stream
+//  1  the same with scalar fp32 ops: 8 instructions
+//  2  v_fma_mix: the fp16 halves of hi are read as fp16 operands (no v_cvt_f32_f16), the scaled residual is rounded to fp16 by
+//     v_fma_mixlo / mixhi (no v_cvt_pk): 5 instructions, none packed
 __device__ __forceinline__ void split_pack(float v0, float v1, uint32_t* hi, uint32_t* lo) {
   f32x2 v = {v0, v1};
   f16x2 h = __builtin_convertvector(v, f16x2);
-  f32x2 hf = __builtin_convertvector(h, f32x2);
-  f32x2 r = (v - hf) * kSplitScale;
   *hi = __builtin_bit_cast(uint32_t, h);
-  *lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+  if (tune::kSplitPack == 2) {
+    const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+    float d0, d1;
+    uint32_t l;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(d0) : "v"(v0), "v"(hb));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d1) : "v"(v1), "v"(hb));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l) : "v"(d0), "s"(kSplitScale));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(d1), "s"(kSplitScale));
+    *lo = l;
+  } else if (tune::kSplitPack == 1) {
+    const float r0 = (v0 - static_cast<float>(h[0])) * kSplitScale, r1 = (v1 - static_cast<float>(h[1])) * kSplitScale;
+    uint32_t l;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));      // asm: keeps the SLP vectoriser from re-packing the two chains
+    *lo = l;
+  } else {
+    f32x2 hf = __builtin_convertvector(h, f32x2);
+    f32x2 r = (v - hf) * kSplitScale;
+    *lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+  }
 }
 
 // One layer, fragments arrive as (hi, lo') pairs per k-step.  FPOS: first fragment position mod the chunk size.

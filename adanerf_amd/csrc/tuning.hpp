@@ -224,6 +224,13 @@ constexpr int kRegFrags2 = ADN_NR2;
 constexpr int kRegFrags2 = 16;
 #endif
 
+// split_pack form of the split-precision engines' epilogue (k_sampling16.hip.hpp): 0 packed fp32, 1 scalar fp32, 2 v_fma_mix
+#if ADN_OVERRIDABLE && defined(ADN_SPLIT_PACK)
+constexpr int kSplitPack = ADN_SPLIT_PACK;
+#else
+constexpr int kSplitPack = 0;
+#endif
+
 // ---- selection (k_compact.hip.hpp) -----------------------------------------------------------------------------------
 // Rays per workgroup of the wave-per-ray select_kernel (4 waves x kSelRaysPerBlock / 4 rays) = rays per segment total
 #if ADN_OVERRIDABLE && defined(ADN_SEL_RPB)

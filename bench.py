@@ -166,6 +166,142 @@ def cpu_baseline(model_dir, w, h, pose, rot, budget_s=10.0):
         res, (row0, rows), O.psnr
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
+    arguments>` (one rank per GPU, rendezvous on 127.0.0.1 at a free port).  Does not return."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without a launcher -> %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+class Watchdog:
+    """A rank that is stuck in a collective never prints.  After `seconds` every rank leaves through os._exit; rank 0 first prints the line
+    it has: the finished record if the main measurement is done (a hang in one of the extra measurements behind it), else a line whose
+    `value` is the render-only rate of phase A with the reason under config.exchange.error -- or an error line with value null."""
+
+    def __init__(self, seconds, rank):
+        import threading
+        self.rank, self.seconds, self.record, self.fallback, self.phase = rank, seconds, None, None, "start"
+        self.timer = threading.Timer(seconds, self.fire) if seconds > 0 else None
+        if self.timer:
+            self.timer.daemon = True
+            self.timer.start()
+
+    def fire(self):
+        rec = self.record or self.fallback
+        if self.rank == 0:
+            why = "watchdog: no progress %d s after the start, stuck in phase '%s'" % (self.seconds, self.phase)
+            if rec is None:
+                rec = {"metric": "FPS at 800x800", "value": None, "unit": "frames/s", "error": why}
+            elif rec is self.fallback:
+                rec["config"]["exchange"]["error"] = why
+            else:
+                rec.setdefault("notes", []).append(why)
+            sys.stdout.write(json.dumps(rec) + "\n")
+            sys.stdout.flush()
+        # (a rank other than 0 leaves quietly: the launcher then still waits for rank 0 and returns ITS status)
+        os._exit(0 if self.rank != 0 or rec.get("value") is not None else 3)
+
+    def cancel(self):
+        if self.timer:
+            self.timer.cancel()
+
+
+def run_peer(args):
+    """--exchange peer: ONE process owns all N GPUs (what `adanerf --gpus N` does, adanerf_amd/host/neuralrenderer.cpp): a context per
+    (GPU, sub-share), every context renders its strips on its own stream, each payload is copied to GPU 0 behind its render
+    (adanerf_gather_to = hipMemcpyPeerAsync over xGMI, ordered by events), GPU 0 de-interleaves; one host sync per frame.  No RCCL, no
+    torch.  Prints one JSON line of the same shape; `value` = frames / s of this path."""
+    import adanerf_amd
+    from adanerf_amd import build as B
+    from adanerf_amd import modeldir as M
+    from adanerf_amd import sharding
+    B.build_library()
+    n = args.gpus
+    one_dev = os.environ.get("ADANERF_BENCH_ONE_DEVICE") == "1"
+    w, h, n_max, thr, tag = WORKLOADS[args.workload]
+    if args.threshold is not None:
+        thr = args.threshold
+    td = tempfile.mkdtemp(prefix="adanerf_bench_peer_")
+    scene, data = build_model_dir(td, tag, n_max, thr)
+    pose = np.array(scene["view_cell_center"], dtype=np.float32)
+    rot = M.camera_rotation(100.0, 0.0) if tag != "ndc_random_init" else np.eye(3, dtype=np.float32)
+    P = args.sub_shares
+    if not P:
+        even = any(h % sr == 0 and (h // sr) % (2 * n) == 0 for sr in range(1, 9))
+        P = 2 if n > 1 and even else 1
+    vworld = n * P
+    strip_rows = sharding.balanced_strip_rows(h, vworld)
+    rs = []
+    for v in range(vworld):
+        q = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h, batch_size=args.batch_rays), precision=args.precision, sampling=args.sampling,
+                                       guard_eps=args.guard_eps, guard_audit_period=args.guard_audit_period, device_id=0 if one_dev else v // P,
+                                       shard_rank=v, shard_world=vworld, strip_rows=strip_rows)
+        q.init()
+        q.set_camera(pose, rot)
+        rs.append(q)
+    root = rs[0]
+    stride = root.info.rays_local_max * 4
+    gathered = root.empty((vworld, root.info.rays_local_max, 4), np.uint8)
+    image = root.empty((w * h, 4), np.uint8)
+    payloads = [None] + [q.empty((q.info.rays_local_max, 4), np.uint8) for q in rs[1:]]
+
+    def step():
+        root.render(gathered.ptr, None)                      # virtual rank 0 renders straight into its slot
+        for v in range(1, vworld):
+            rs[v].render(payloads[v], None)
+            root.gather_from(gathered.ptr + v * stride, rs[v], payloads[v], stride)
+        root.assemble_strips(gathered, image)
+        root.sync()                                          # the frame is complete on GPU 0
+
+    for _ in range(args.warmup):
+        step()
+    for q in rs:
+        q.sync()
+    for q in rs:
+        q.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    for q in rs:
+        q.sync()
+    dt = time.perf_counter() - t0
+    samples, shade_ms, per_dev = 0.0, [], [0.0] * n
+    for v, q in enumerate(rs):
+        st, frames = q.collect_stats()
+        q.set_profiling(False)
+        samples += st.total_samples / max(frames, 1)
+        shade_ms.append(st.ms_shade_mlp / max(frames, 1))
+        per_dev[v // P] += st.total_samples / max(frames, 1)
+    if args.dump_image:
+        np.save(args.dump_image, image.numpy().reshape(h, w, 4))
+    mean_s = sum(per_dev) / len(per_dev)
+    rec = {"metric": "FPS at %dx%d" % (w, h), "value": args.steps / dt, "unit": "frames/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision,
+           "data": data,
+           "config": {"workload": "%s: %dx%d, N=%d, threshold %.2f, 8x256 shading MLP %s, sampling MLP %s" % (args.workload, w, h, n_max, thr, args.precision, args.sampling),
+                      "parallelism": "image-strip shard x%d (%d-row strips, round-robin over %d virtual ranks, %d concurrent sub-share(s) per GPU), ONE host "
+                                     "process, payloads copied to GPU 0 with hipMemcpyPeerAsync (adanerf_gather_to), one host sync per frame" % (n, strip_rows, vworld, P),
+                      "exchange": {"mode": "peer", "backend": "hipMemcpyPeerAsync", "rccl_ranks": 0, "world_size": n, "payload_bytes_per_rank": int(stride * P),
+                                   "sub_shares_per_rank": P, "all_contexts_on_device_0": one_dev},
+                      "sub_shares_per_gpu": P, "samples_per_frame": samples, "mean_samples_per_ray": samples / (w * h)},
+           "shards": {"samples_per_frame": per_dev, "shade_ms_per_frame_per_context": shade_ms,
+                      "sample_imbalance_max_over_mean": max(per_dev) / mean_s if mean_s > 0 else None}}
+    print(json.dumps(rec))
+    sys.stdout.flush()
+    for q in rs:
+        q.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,10 +333,30 @@ def main():
                     help="N > 1 only: 1 (default) renders one frame at a time, as on a single GPU and as an interactive viewer needs it; "
                          "2 renders alternate frames on two contexts / streams of the rank, so that the tail rounds, ring prologues and "
                          "launch gaps of one frame's kernels overlap the next frame's (more throughput; a frame's latency doubles)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "all_gather", "gloo", "peer"],
+                    help="N > 1, how the RGBA8 strip payloads reach GPU 0: rccl (default) = one torch.distributed.gather on the RCCL group per frame "
+                         "(falls back to all_gather, then to a host-staged gloo gather, if RCCL refuses -- the line says which ran); all_gather = "
+                         "all_gather_into_tensor on the RCCL group; gloo = host-staged; peer = ONE process owning all GPUs, hipMemcpyPeerAsync to GPU 0 "
+                         "(adanerf_gather_to, the C++ host's path) -- no launcher needed")
+    ap.add_argument("--no-alternatives", action="store_true",
+                    help="N > 1: skip the short extra measurements of the other exchange paths reported under config.exchange.alternatives")
+    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("ADANERF_BENCH_WATCHDOG_S", "900")),
+                    help="seconds after which a run that is stuck (a collective that never returns) prints the line it has and exits; 0: off")
     ap.add_argument("--dump-image", default=None, help="rank 0 writes the last frame's RGBA8 image [h,w,4] as .npy (tests)")
     args = ap.parse_args()
     if args.sampling is None:
         args.sampling = "split" if args.precision == "fp32" else "guarded"
+
+    launched = "RANK" in os.environ                      # under torch.distributed.run (the driver's N > 1 line)
+    if args.exchange == "peer":
+        # one process, all GPUs.  Under a launcher rank 0 is that process and the other ranks have nothing to do.
+        if not launched or int(os.environ.get("RANK", "0")) == 0:
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK"):
+                os.environ.pop(k, None)
+            run_peer(args)
+        return
+    if args.gpus > 1 and not launched:
+        relaunch_under_torchrun(args.gpus)                # plain `python bench.py --gpus N` launches itself
 
     import torch
     import adanerf_amd
@@ -211,33 +367,50 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
+    dog = Watchdog(args.watchdog if world > 1 or launched else 0, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # Validation hooks for a 1-GPU box (tests/test_gpu_parity.py::test_bench_two_ranks_share_one_gpu): all ranks on
     # device 0 and gloo for the exchange, because RCCL refuses two ranks on one device.  Never set by the driver.
     backend = os.environ.get("ADANERF_BENCH_DIST_BACKEND", "nccl")
+    if args.exchange == "gloo":
+        backend = "gloo"
     if os.environ.get("ADANERF_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     # ADANERF_BENCH_FORCE_DIST=1 (tests): take the process-group / gather / assemble path even at world size 1, so the
     # RCCL branch runs on a 1-GPU box exactly as it does on N > 1 (launch under torch.distributed.run --nproc-per-node 1)
-    use_dist = world > 1 or (os.environ.get("ADANERF_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    use_dist = world > 1 or (os.environ.get("ADANERF_BENCH_FORCE_DIST") == "1" and launched)
+    # Two groups: the CONTROL plane (barriers, max-over-ranks timing, per-rank statistics: a few scalars on the host) is always gloo, the DATA
+    # plane (one exchange of the RGBA8 strip payloads per frame) is RCCL.  A data plane that fails -- RCCL with more than one rank has never
+    # run on the builder's side -- then cannot take the line with it: the ranks agree over gloo on what failed and fall back.
+    data_pg, xerrors = None, []
     if use_dist:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dog.phase = "process group init (gloo)"
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=max(300.0, 2.0 * args.watchdog)))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+            dog.phase = "process group init (RCCL)"
+            try:
+                data_pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180), device_id=torch.device("cuda", local_rank))
+            except Exception as e:      # noqa: BLE001 -- anything RCCL raises here is reported, not fatal
+                xerrors.append("new_group(nccl): %s: %s" % (type(e).__name__, str(e)[:300]))
     if rank == 0:
         B.build_library()
     if dist:
         dist.barrier()
+
+    def all_ok(ok):
+        """every rank's flag, agreed over the control plane"""
+        if not dist:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
     w, h, n_max, thr, tag = WORKLOADS[args.workload]
     generic_wl = args.workload.startswith("generic_")
@@ -302,17 +475,38 @@ def main():
     rgb = rgbs[0]
     gathered = image = images = cstream = None
     ev_render = ev_gather = None
+    # how the payloads travel (config.exchange.mode): gather = dist.gather on the data group; all_gather = all_gather_into_tensor on it (every
+    # rank receives the 2.56 MB frame payload; the collective RCCL implements natively, gather being grouped send / recv); gloo_staged = device
+    # -> host, gloo gather, host -> device (synchronous: the fallback of last resort, and `--exchange gloo`)
+    xmode = {"rccl": "gather", "all_gather": "all_gather", "gloo": "gather"}[args.exchange]
+    if use_dist and backend == "nccl" and data_pg is None:
+        xmode = "gloo_staged"
     if use_dist:
         cstream = torch.cuda.Stream(device=dev)
         ev_render = [[torch.cuda.Event() for _ in range(P)] for _ in range(2)]
         ev_gather = [torch.cuda.Event() for _ in range(2)]
         gather_lists = [None, None]
+        # (every rank holds the receive buffers: all_gather needs them everywhere, and a fallback may switch modes after they are made)
+        gathered = [torch.zeros((world, P, M_pay, 4), dtype=torch.uint8, device=dev) for _ in range(2)]      # = [virtual rank][row][4]
         if rank == 0:
-            gathered = [torch.zeros((world, P, M_pay, 4), dtype=torch.uint8, device=dev) for _ in range(2)]      # = [virtual rank][row][4]
             gather_lists = [list(g.unbind(0)) for g in gathered]
             images = [torch.zeros((h * w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]      # one per buffer: two frames may be assembling
             image = images[0]
-    state = {"k": 0, "pending": None, "gathers": 0, "last": 0}
+    state = {"k": 0, "pending": None, "gathers": 0, "last": 0, "exchange": True, "mode": xmode}
+
+    def exchange(b):
+        """frame in buffer b: payloads of all ranks -> gathered[b] on rank 0 (enqueued on the current stream = cstream)"""
+        mode = state["mode"]
+        if mode == "gather":
+            dist.gather(outs[b], gather_lists[b], dst=0, group=data_pg)
+        elif mode == "all_gather":
+            dist.all_gather_into_tensor(gathered[b].view(world * P * M_pay * 4), outs[b].view(P * M_pay * 4), group=data_pg)
+        else:      # gloo_staged
+            host = outs[b].cpu()                               # (synchronises cstream behind the renders it waited for)
+            parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            if rank == 0:
+                gathered[b].copy_(torch.stack(parts), non_blocking=False)
 
     def finish(b):
         # frame in buffer b: its gather is complete -> de-interleave into the image on the stream of the context that rendered it
@@ -347,16 +541,21 @@ def main():
                 q.render(outs[b][k], rgbs[i])
                 if use_dist:
                     ev_render[b][k].record(ts)
-        if use_dist:
+        if use_dist and state["exchange"]:
             with torch.cuda.stream(cstream):
                 for k in range(len(lanes)):
                     cstream.wait_event(ev_render[b][k])
-                dist.gather(outs[b], gather_lists[b], dst=0)
+                exchange(b)
                 state["gathers"] += 1
                 ev_gather[b].record(cstream)
             if state["pending"] is not None:
                 finish(state["pending"])
             state["pending"] = b
+        elif use_dist:                                           # render-only phase: nothing leaves the buffer
+            with torch.cuda.stream(cstream):
+                for k in range(len(lanes)):
+                    cstream.wait_event(ev_render[b][k])
+                ev_gather[b].record(cstream)
 
     def flush():
         if state["pending"] is not None:
@@ -369,12 +568,69 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(n_steps):
+        """n_steps steps between two fences; seconds, max over ranks (control plane)"""
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        flush()
+        fence()
+        dt_ = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([dt_], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_
+
+    # Phase A (N > 1 only): the ranks' renders alone, no data-plane call at all -- what the GPUs do before any exchange is asked of them; the
+    # value the line falls back to (flagged) if the exchange cannot run, and on a healthy run the cost of the exchange = phase B - phase A.
+    render_only = None
+    if use_dist:
+        dog.phase = "phase A (render only)"
+        state["exchange"] = False
+        for _ in range(args.warmup):
+            step()
+        flush()
+        fence()
+        dt_a = timed(args.steps)
+        render_only = {"value": args.steps / dt_a, "unit": "frames/s", "ms_per_step": dt_a / args.steps * 1e3,
+                       "what": "every rank renders its share(s) of each frame, max over ranks; no exchange, no assembled image"}
+        state["exchange"], state["k"] = True, 0
+        if rank == 0:
+            dog.fallback = {"metric": "FPS at %dx%d" % (w, h), "value": render_only["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                            "warmup": args.warmup, "ms_per_step": render_only["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+                            "vs_baseline": None, "dtype": args.precision, "data": data,
+                            "config": {"workload": args.workload, "exchange": {"error": None, "value_excludes_the_exchange": True, "errors": xerrors},
+                                       "render_only": render_only}}
+        # Pre-flight of the data plane: one exchange of the real payload in the chosen mode; a mode that raises on any rank is dropped for the
+        # next one (gather -> all_gather -> gloo_staged), agreed over the control plane.  A mode that HANGS is the watchdog's business.
+        while True:
+            dog.phase = "exchange pre-flight (%s)" % state["mode"]
+            err = None
+            try:
+                with torch.cuda.stream(cstream):
+                    exchange(0)
+                torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001
+                err = "%s: %s: %s" % (state["mode"], type(e).__name__, str(e)[:300])
+            if all_ok(err is None):
+                break
+            xerrors.append(err or "%s: failed on another rank" % state["mode"])
+            nxt = {"gather": "all_gather", "all_gather": "gloo_staged"}.get(state["mode"])
+            if nxt is None or (nxt == "all_gather" and backend != "nccl"):
+                nxt = "gloo_staged" if state["mode"] != "gloo_staged" else None
+            if nxt is None:
+                raise SystemExit("bench.py: no exchange path works: %s" % "; ".join(xerrors))
+            state["mode"] = nxt
+
+    dog.phase = "warm-up"
     for _ in range(args.warmup):
         step()
     flush()
     fence()
     for q in rs:
         q.set_profiling(True)
+    dog.phase = "timed steps (exchange: %s)" % state["mode"]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -396,20 +652,26 @@ def main():
         for fld in ("guard_violations", "guard_audited", "guard_audit_mismatch", "guard_widened"):
             setattr(st, fld, getattr(st, fld) + getattr(st2, fld))
     r.lib.adanerf_get_info(r.handle, r.info)      # the guard band is calibrated at the first guarded frame
-    exchange = None
+    exchange_rec = None
     if dist:
-        exchange = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
-                    "world_size": dist.get_world_size(), "gathers": state["gathers"],
-                    "payload_bytes_per_rank": int(outs[0].numel()), "sub_shares_per_rank": P}
+        on_rccl = backend == "nccl" and state["mode"] in ("gather", "all_gather")
+        exchange_rec = {"mode": state["mode"], "backend": "nccl" if on_rccl else "gloo", "rccl_ranks": dist.get_world_size() if on_rccl else 0,
+                        "control_plane": "gloo", "world_size": dist.get_world_size(), "gathers": state["gathers"],
+                        "payload_bytes_per_rank": int(outs[0].numel()), "sub_shares_per_rank": P, "errors": xerrors, "error": None,
+                        "render_only": render_only,
+                        "exchange_cost_ms_per_frame": (dt / args.steps - render_only["ms_per_step"] * 1e-3) * 1e3 if render_only else None}
     if dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dog.phase = "statistics (control plane)"
+        tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tot = torch.tensor([float(st.total_samples), float(st.ms_shade_mlp), float(st.ms_sample_mlp)], dtype=torch.float64, device=dev)
+        if exchange_rec and render_only:
+            exchange_rec["exchange_cost_ms_per_frame"] = (dt / args.steps) * 1e3 - render_only["ms_per_step"]
+        tot = torch.tensor([float(st.total_samples), float(st.ms_shade_mlp), float(st.ms_sample_mlp)], dtype=torch.float64)
         tot_all = tot.clone()
         dist.all_reduce(tot_all, op=dist.ReduceOp.SUM)
         samples_all = float(tot_all[0].item())
-        per_rank = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(world)]
+        per_rank = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(per_rank, tot)
         shard_samples = [float(x[0].item()) / max(frames, 1) for x in per_rank]
         shard_shade_ms = [float(x[1].item()) / max(frames, 1) for x in per_rank]
@@ -427,6 +689,7 @@ def main():
     samples_per_frame = samples_all / frames
     mean_spp = samples_per_frame / (w * h)
 
+    final_rec = None
     if rank == 0:
         # roofline of the dominant kernel (fused PE + shading MLP), this rank's launches
         launches = max(st.shade_launches, 1)
@@ -650,8 +913,9 @@ def main():
                                        {"split": "split-fp16 (3 MFMAs per term)", "fp32": "fp32 MFMA", "fp16": "plain fp16 (opt-in speed mode)",
                                         "guarded": "guarded two-precision (plain fp16, split-fp16 on the rays inside the band)"}[args.sampling]),
                           "parallelism": ("image-strip shard x%d (%d-row strips, round-robin over %d virtual ranks, %d concurrent sub-share(s) per GPU) + %s gather "
-                                          "overlapped with the next frame" % (world, strip_rows, vworld, P, "RCCL" if backend == "nccl" else backend)) if use_dist else "single GPU",
-                          "exchange": exchange,
+                                          "overlapped with the next frame" % (world, strip_rows, vworld, P, {"gather": "RCCL" if backend == "nccl" else backend, "all_gather": "RCCL all_gather",
+                                                                                                  "gloo_staged": "host-staged gloo"}[state["mode"]])) if use_dist else "single GPU",
+                          "exchange": exchange_rec,
                           "frames_in_flight": fif, "sub_shares_per_gpu": P,
                           "rays_refined_per_frame": (st.rays_refined / frames) if args.sampling == "guarded" else None,
                           "guard": ({"eps": float(r.info.guard_eps), "eps_pair": float(r.info.guard_eps_pair),
@@ -676,7 +940,63 @@ def main():
             mean_s = sum(shard_samples) / len(shard_samples)
             rec["shards"] = {"samples_per_frame": shard_samples, "shade_ms_per_frame": shard_shade_ms,
                              "sample_imbalance_max_over_mean": max(shard_samples) / mean_s if mean_s > 0 else None}
-        print(json.dumps(rec))
+        final_rec = dog.record = rec                    # from here on a hang costs the extras below, not the line
+    # N > 1: short measurements of the other exchange paths, after the line's own numbers are final.  (1) the other RCCL collective, in this
+    # process group; (2) --exchange peer in a child process of rank 0 -- one process driving all N GPUs with hipMemcpyPeerAsync -- while the
+    # other ranks wait at a control-plane barrier with their GPUs idle.  Each is optional: whatever fails is recorded as text.
+    if dist and world > 1 and not args.no_alternatives:
+        alts = {}
+        k_alt = max(2, min(args.steps, 10))
+        main_mode = state["mode"]
+        for mode in (("all_gather",) if main_mode == "gather" else ("gather",) if main_mode == "all_gather" else ()):
+            if backend != "nccl" and mode == "all_gather" and os.environ.get("ADANERF_BENCH_ALT_ALL_GATHER") != "1":
+                continue                                  # (gloo has no all_gather_into_tensor for device tensors worth timing)
+            dog.phase = "alternative exchange (%s)" % mode
+            state["mode"], state["k"], err = mode, 0, None
+            try:
+                with torch.cuda.stream(cstream):
+                    exchange(0)
+                torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001
+                err = "%s: %s" % (type(e).__name__, str(e)[:300])
+            if not all_ok(err is None):
+                alts[mode] = {"error": err or "failed on another rank"}
+                continue
+            for _ in range(2):
+                step()
+            flush()
+            fence()
+            dt_alt = timed(k_alt)
+            alts[mode] = {"value": k_alt / dt_alt, "unit": "frames/s", "ms_per_step": dt_alt / k_alt * 1e3, "steps": k_alt}
+        state["mode"] = main_mode
+        dog.phase = "alternative exchange (peer, child process of rank 0)"
+        dist.barrier()                                    # every rank's GPU is idle from here
+        if rank == 0:
+            import subprocess
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                    "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--exchange", "peer", "--steps", str(max(2, min(args.steps, 20))),
+                   "--warmup", "3", "--workload", args.workload, "--precision", args.precision, "--sampling", args.sampling,
+                   "--sub-shares", str(P), "--batch-rays", str(args.batch_rays)] + (["--threshold", str(args.threshold)] if args.threshold is not None else [])
+            try:
+                out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
+                line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+                if out.returncode == 0 and line:
+                    pr = json.loads(line[-1])
+                    alts["peer"] = {"value": pr["value"], "unit": "frames/s", "ms_per_step": pr["ms_per_step"], "steps": pr["steps"],
+                                    "what": pr["config"]["parallelism"]}
+                else:
+                    alts["peer"] = {"error": "rc %d: %s" % (out.returncode, (out.stderr or out.stdout)[-400:])}
+            except Exception as e:      # noqa: BLE001
+                alts["peer"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        dist.barrier()
+        if rank == 0:
+            final_rec["config"]["exchange"]["alternatives"] = alts
+    if rank == 0:
+        dog.cancel()
+        print(json.dumps(final_rec))
+        sys.stdout.flush()
+    dog.cancel()
     for q in rs:
         q.close()
     if dist:

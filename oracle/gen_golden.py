@@ -393,6 +393,28 @@ def gen_dataset_reader(R, name="dataset_reader"):
     print("wrote %s.npz  %d frames %dx%d, focal %.4f" % (name, n_frames, di.w, di.h, di.view.focal))
 
 
+def gen_ray_table(R, name="ray_table_ref"):
+    """A1 pinned to the reference's OWN pixel-ray table: src/util/raygeneration.py:10-26 called the way
+    src/datasets.py:182, 268 calls it (focal = .5 w / tan(.5 fov); float64, cast to float32 by the dataset), for the frame sizes of the
+    BASELINE configurations.  Whole rows are kept so that the fixture stays small: first, two middle and last row, plus the first and the
+    last column."""
+    if ONLY is not None and name not in ONLY:
+        return
+    from util.raygeneration import generate_ray_directions as ref_dirs
+    out = {}
+    for (w, h, fov) in ((800, 800, 1.1386263370513916), (400, 400, 1.1386263370513916), (1920, 1080, 1.0), (12, 10, 1.1386263370513916), (97, 61, 0.6)):
+        focal = float(.5 * w / np.tan(.5 * fov))
+        d = ref_dirs(w, h, fov, focal).astype(np.float32)          # [h, w, 3]
+        rows = sorted({0, h // 2 - 1, h // 2, h - 1})
+        key = "%dx%d" % (w, h)
+        out[key + "/fov"] = np.float64(fov)
+        out[key + "/rows"] = np.array(rows, np.int32)
+        out[key + "/row_dirs"] = d[rows]
+        out[key + "/col_dirs"] = d[:, [0, w - 1]]
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print("wrote %s.npz  %s" % (name, sorted(k for k in out if k.endswith("/rows"))))
+
+
 def gen_selection_edge_cases(R):
     """Synthetic oracle rows through the reference sampler alone
     (FromClassifiedDepthAdaptive.generate, src/nerf_raymarch_common.py:699-757):
@@ -690,6 +712,7 @@ def main():
     if not args.only:
         gen_selection_edge_cases(R)
     gen_dataset_reader(R)
+    gen_ray_table(R)
     gen_coarse_fine(R)
     gen_coarse_fine(R, "ndc_coarse_fine_12_20", ndc=True)
 

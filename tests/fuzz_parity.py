@@ -37,6 +37,31 @@ def bins_of(r, n_rays, n_max):
     return cnt, bins
 
 
+def selection_fragile(orc, sc, n_max, thr, rng, eps_rel=2e-5, trials=4):
+    """Conditioning of every ray's SELECTION, measured on the oracle's own sampling-network outputs (the harness
+    accepted >= 0.98 identical bin sets without saying which rays may differ).  Two correct fp32-class evaluations of the network differ
+    by summation-order noise of a few 1e-6 (numpy / torch sgemm 2.4e-6 against fp64, the split-fp16 engine 1.9e-6 on the shipped weights);
+    with raw outputs moved by eps_rel (1 + |value|) the values the sampler looks at (after its sigmoid / softmax) move by at most e_r
+    (measured over `trials` draws, doubled).  A ray is fragile iff, at resolution e_r, (a) one of its n_max largest values is within e_r
+    of the threshold, or (b) its n_max-th and (n_max+1)-th values are within e_r of each other while the latter could be kept, or (c) the
+    arg-max fallback applies and its two largest values are within e_r.  Every OTHER ray must come out of the device with exactly the
+    oracle's count and bins; fragile rays are excused and counted.  Returns (fragile [R] bool, e_r [R])."""
+    v0 = O.oracle_transform(orc, sc.losses0).astype(np.float64)
+    e = np.zeros(orc.shape[0])
+    for _ in range(trials):
+        pert = (orc + rng.standard_normal(orc.shape).astype(np.float32) * np.float32(eps_rel) * (1.0 + np.abs(orc))).astype(np.float32)
+        e = np.maximum(e, np.abs(O.oracle_transform(pert, sc.losses0).astype(np.float64) - v0).max(axis=1))
+    e = 2.0 * e + 1e-12
+    v = -np.sort(-v0, axis=1)
+    d = v.shape[1]
+    n = min(n_max, d)
+    frag = (np.abs(v[:, :n] - thr) <= e[:, None]).any(axis=1)
+    if n < d:
+        frag |= ((v[:, n - 1] - v[:, n]) <= e) & (v[:, n] >= thr - e)
+    frag |= (v[:, 0] < thr + e) & ((v[:, 0] - v[:, 1]) <= e)
+    return frag, e
+
+
 def colour_sensitivity(ref, sc, kind, w, h, eps_rel, rng, trials=6, wts=None):
     """Conditioning of every ray's colour, measured on the reference itself: the largest change of the oracle's OWN composite when its
     raw shading outputs move by a relative eps_rel (gaussian, eps_rel (1 + |raw|) per value; `trials` draws).  An engine whose raw
@@ -205,20 +230,32 @@ def one_case(rng, idx):
     rgb, rgba, st, cnt, bins = out["fp32"]
     ok = True
     msg = []
-    if cnt is not None:
-        rbins = ref["bins"] if "bins" in ref else None
-        same = (cnt == ref["count"]) & ((bins == rbins).all(axis=1) if rbins is not None and rbins.shape == bins.shape else True)
-        frac = float(same.mean())
-        if st.total_samples != int(cnt.sum()):
-            ok = False; msg.append("total_samples mismatch")
-    else:
-        same = np.ones(w * h, bool); frac = float("nan")
-        if abs(st.total_samples - int(ref["count"].sum())) > 0.02 * max(1, int(ref["count"].sum())) + 2:
-            ok = False; msg.append("sample total off: %d vs %d" % (st.total_samples, int(ref["count"].sum())))
-    # selection: rays whose N-th / (N+1)-th values or threshold distance are inside fp32 sgemm noise may flip
-    need = 0.98 if w * h >= 200 else 0.9
-    if cnt is not None and frac < need:
-        ok = False; msg.append("identical bin sets %.4f" % frac)
+    if cnt is None:
+        # a batched render leaves only its last batch's buffers behind: the same frame once more in ONE batch gives every ray's count and
+        # bins, and must be the batched frame byte for byte (round 4 compared only the sample total on these cases)
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="fp32") as r:
+            r.set_camera(pose, rot)
+            rgb_u, rgba_u, st_u = r.render_numpy()
+            cnt, bins = bins_of(r, w * h, n_max + sc.num_samples_coarse)
+        if not (np.array_equal(rgba_u, rgba) and np.array_equal(rgb_u, rgb) and st_u.total_samples == st.total_samples):
+            ok = False; msg.append("batched (%d rays per batch) and unbatched fp32 frames differ" % batch)
+    rbins = ref["bins"] if "bins" in ref else None
+    same = (cnt == ref["count"]) & ((bins == rbins).all(axis=1) if rbins is not None and rbins.shape == bins.shape else True)
+    frac = float(same.mean())
+    if st.total_samples != int(cnt.sum()):
+        ok = False; msg.append("total_samples mismatch")
+    # selection: exact on every ray whose selection the oracle's own outputs determine at the resolution of fp32 summation noise
+    # (selection_fragile); the others are excused and counted.  No floor on the fraction of identical rays any more.
+    n_frag = 0
+    if rbins is not None and "orc" in ref and thr > 0.0 and not same.all():
+        frag, _ = selection_fragile(ref["orc"], sc, n_max, thr, np.random.default_rng(3000 + idx))
+        n_frag = int(frag.sum())
+        bad = ~same & ~frag
+        if bad.any():
+            ok = False; msg.append("selection differs on %d rays whose selection is well determined (first: ray %d)" % (int(bad.sum()), int(np.argmax(bad))))
+        msg.append("%d fragile of %d rays, %d of them differ" % (n_frag, w * h, int((~same & frag).sum())))
+    elif not same.all():
+        ok = False; msg.append("sample counts differ on %d rays (sampler without a selection rule)" % int((~same).sum()))
     # Bounds, per ray: |engine - oracle| <= tol max(1, |colour|) + SPREADS x the ray's own sensitivity to raw-output errors of the
     # engine's size (colour_sensitivity).  Rays whose selection differs from the oracle's are not comparable and are left out where the
     # frame was one batch; batched renders leave only the last batch's buffers behind, so there the bound applies to the 97th
@@ -234,7 +271,7 @@ def one_case(rng, idx):
         x = np.where(np.isfinite(e), x, np.inf)                   # ... but a non-finite engine colour on a finite reference is a failure
         x[~np.isfinite(b).all(axis=1)] = 0.0
         rel = e / np.maximum(1.0, np.abs(b).max(axis=1))
-        pick = same if (cnt is not None and same.any()) else None
+        pick = same if same.any() else None
         if pick is not None:
             return float(x[pick].max()), float(rel[pick].max())
         return float(np.quantile(x, 0.97)), float(np.quantile(rel, 0.97))
@@ -272,7 +309,7 @@ def one_case(rng, idx):
         ok = False; msg.append("bf16 rgb err %.3f = %.2f x its conditioned bound" % (e16, x16))
     # guarded two-precision selection (round 3): where it applies (fused selection on the 8 x 256 / 10-4 or 2-2 sampling net, whole
     # frame in one batch) its counts and bins must be the split engine's bit for bit and the monitor must not see its band violated
-    if os.environ.get("FUZZ_ROUND3") and cnt is not None and 0.0 < thr and n_max <= 16 and kind in ("classroom", "barbershop", "random", "ndc", "transform", "mult"):
+    if os.environ.get("FUZZ_ROUND3") and out["bf16"][3] is not None and 0.0 < thr and n_max <= 16 and kind in ("classroom", "barbershop", "random", "ndc", "transform", "mult"):
         with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h, batch_size=batch), precision="bf16", sampling="split") as r:
             r.set_camera(pose, rot)
             r.render_numpy()

@@ -89,6 +89,28 @@ def test_ray_features_match_reference(cases, name):
     np.testing.assert_allclose(feat[:n], z["oracle_in"], rtol=0, atol=2e-3)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["800x800", "1920x1080", "97x61"])
+def test_device_ray_table_equals_the_references(cases, key, tmp_path):
+    """A1 on the device against the reference's own pixel-ray table (tests/golden/ray_table_ref.npz, written by the reference's
+    generate_ray_directions): with the identity as camera rotation the world direction of a ray IS its table entry, so the debug ray
+    kernel must return the table bit for bit (float64 on both sides, one rounding to float32) -- whole rows of a square and of two
+    non-square frames."""
+    zt = np.load(os.path.join(GOLD, "ray_table_ref.npz"))
+    w, h = (int(x) for x in key.split("x"))
+    z, meta, sc, wts, d0 = cases["classroom_n8_thr02"]
+    import dataclasses
+    sc2 = dataclasses.replace(sc, fov=float(zt[key + "/fov"]))
+    d = str(tmp_path / "m")
+    O.write_model_dir(d, sc2, wts)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="fp32") as r:
+        r.set_camera(np.array(sc.view_cell_center, np.float32), np.eye(3, dtype=np.float32))
+        buf = r.empty((w, 8), np.float32)
+        for row, want in zip(zt[key + "/rows"], zt[key + "/row_dirs"]):
+            r.ray_features(int(row) * w, w, None, buf)
+            assert np.array_equal(buf.numpy()[:, 4:7], want), (key, int(row))
+
+
 # ---------------------------------------------------------------------------------------------
 # A3: fused ray gen + PE + sampling MLP (fp32 MFMA)
 # ---------------------------------------------------------------------------------------------
@@ -1469,6 +1491,40 @@ def test_bench_two_ranks_share_one_gpu(tmp_path, mode):
     img1, img2 = np.load(one), np.load(two)
     assert img1.shape == img2.shape == (800, 800, 4)
     assert np.array_equal(img1, img2)
+
+
+@pytest.mark.gpu
+def test_bench_plain_python_launches_itself(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a launcher re-executes itself under torch.distributed.run (free port,
+    127.0.0.1) and prints one line; here with both ranks on this box's one GPU and gloo as the data plane.  The line carries the
+    render-only phase, the exchange mode that ran, and the measured alternative (--exchange peer in a child process of rank 0)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    two, peer = str(tmp_path / "two.npy"), str(tmp_path / "peer.npy")
+    env = dict(os.environ, ADANERF_BENCH_DIST_BACKEND="gloo", ADANERF_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    b = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--dump-image", two],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-3000:]
+    assert "torch.distributed.run" in b.stderr
+    lines = [ln for ln in b.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, b.stdout
+    rec = json.loads(lines[0])
+    x = rec["config"]["exchange"]
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and x["mode"] == "gather" and x["error"] is None and x["errors"] == []
+    assert x["control_plane"] == "gloo" and x["render_only"]["value"] >= 0.9 * rec["value"]
+    assert x["alternatives"]["peer"].get("value", 0) > 0, x["alternatives"]
+    # the single-process path as the headline of its own line; same frame, byte for byte
+    c = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--exchange", "peer", "--steps", "3", "--warmup", "1", "--dump-image", peer],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert c.returncode == 0, c.stderr[-3000:]
+    prec = json.loads([ln for ln in c.stdout.splitlines() if ln.startswith("{")][0])
+    assert prec["n_gpus"] == 2 and prec["config"]["exchange"]["mode"] == "peer" and prec["value"] > 0
+    assert abs(prec["config"]["samples_per_frame"] - rec["config"]["samples_per_frame"]) < 0.5
+    assert np.array_equal(np.load(two), np.load(peer))
 
 
 def r1_guard_ok(rec):

@@ -907,3 +907,30 @@ def test_bench_flop_models_match_the_survey_figures():
     assert bench.shade_flop_per_sample("generic_8x256_random_init") == bench.SHADE_FLOP_PER_SAMPLE
     w, d = 128, 6
     assert bench.shade_flop_per_sample("generic_6x128_random_init") == 2 * (63 * w + (d - 2) * w * w + (w + 63) * w + w * w + w + (w + 27) * (w // 2) + (w // 2) * 3)
+
+
+def test_bench_watchdog_prints_the_line_it_has(tmp_path):
+    """bench.py's Watchdog: a run stuck in a collective still ends with ONE JSON line from rank 0 -- the render-only fallback with the
+    reason under config.exchange.error (exit 0), the finished record if there is one, or an error line with value null (exit 3); ranks
+    other than 0 leave quietly."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "d = bench.Watchdog(0.3, int(sys.argv[1])); d.phase = 'exchange pre-flight (gather)'\n"
+            "if sys.argv[2] == 'fallback': d.fallback = {'value': 5.0, 'config': {'exchange': {'error': None}}}\n"
+            "if sys.argv[2] == 'record': d.record = {'value': 7.0, 'config': {}}\n"
+            "time.sleep(5); print('not reached')\n") % root
+    def run(rank, what):
+        return subprocess.run([sys.executable, "-c", prog, str(rank), what], capture_output=True, text=True, timeout=60)
+    a = run(0, "fallback")
+    rec = json.loads(a.stdout.strip())
+    assert a.returncode == 0 and rec["value"] == 5.0 and "exchange pre-flight (gather)" in rec["config"]["exchange"]["error"]
+    b = run(0, "record")
+    rec = json.loads(b.stdout.strip())
+    assert b.returncode == 0 and rec["value"] == 7.0 and "watchdog" in rec["notes"][0]
+    c = run(0, "nothing")
+    assert c.returncode == 3 and json.loads(c.stdout.strip())["value"] is None
+    d = run(1, "fallback")
+    assert d.returncode == 0 and d.stdout.strip() == ""

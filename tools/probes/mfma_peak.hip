@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256) void mfma_burn_dataflow(int iters, const uint3
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b1[u]), acc1, 0, 0, 0);
       if (WHAT & kValu) {
         uint32_t p;
-        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(p) : "v"(__builtin_bit_cast(float, b0[u][0])), "v"(__builtin_bit_cast(float, b1[u][1])));
+        if (WHAT & 8)      // kClamp (round 5): one clamped conversion instead of cvt + max
+          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(p) : "v"(__builtin_bit_cast(float, b0[u][0])), "v"(__builtin_bit_cast(float, b1[u][1])));
+        else
+          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(p) : "v"(__builtin_bit_cast(float, b0[u][0])), "v"(__builtin_bit_cast(float, b1[u][1])));
         packed ^= p;
       }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -83,6 +86,136 @@ __global__ __launch_bounds__(256) void mfma_burn_dataflow(int iters, const uint3
   if (s_ == 12345.678f) sink[0] = s_ + lds[threadIdx.x + 8192];
 }
 
+
+// Round 5: the same stream with the LDS-DMA refill issued by ANOTHER wave.  Consumers = waves 0-3 (one per SIMD): MFMAs +
+// fragment reads (+ conversions); loaders = LOADERS further waves of the same workgroup (4: one beside each consumer on its SIMD; 1: one per
+// CU) that issue the consumers' 1 KiB pieces at the same rate -- paced by a progress word each consumer publishes in LDS once per 16 MFMAs
+// (one ds_write_b32), polled by the loader with s_sleep between polls, at most AHEAD iterations in front, <= 4 pieces in flight.
+// kClamp: the conversions as ONE instruction per two MFMAs (v_cvt_pk_bf16_f32 ... clamp instead of cvt + v_pk_max_i16).
+// NOTE what this row can and cannot stand for: every wave of a dispatch gets the SAME register allocation (one granulated VGPR count in the
+// kernel descriptor), so a loader wave beside a 484-register MFMA wave is not launchable -- the probe's consumers need ~130 registers.
+enum { kClamp = 8 };
+template <int WHAT, int LOADERS>
+__global__ __launch_bounds__(256 + 64 * LOADERS) void mfma_burn_dataflow_pc(int iters, const uint32_t* __restrict__ gsrc, float* sink, uint64_t* clocks) {
+  __shared__ __attribute__((aligned(1024))) uint32_t lds[16384 + 64];      // 32 KiB fragments, 32 KiB DMA target, progress words
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = rnd_pair(0x2468aceu + i * 7u + blockIdx.x * 131u, false);
+  if (threadIdx.x < 64) lds[16384 + threadIdx.x] = 0u;
+  __syncthreads();
+  typedef const __attribute__((address_space(3))) u32x4* lds_rd;
+  const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds));
+  const uint32_t prog = base + 65536;
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(gsrc), 0, 0x7fffffff, 0x00020000);
+#endif
+  if (wave >= 4) {      // ---- loader ----
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int AHEAD = 2;
+    const int first = (LOADERS == 4) ? wave - 4 : 0, count = (LOADERS == 4) ? 1 : 4;
+    for (int it = 0; it < iters; ++it) {
+      // wait until every consumer this loader serves has reached iteration it - AHEAD
+      while (true) {
+        int behind = 0;
+        for (int c = first; c < first + count; ++c) {
+          uint32_t p;
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(p) : "v"(prog + c * 4) : "memory");
+          behind |= (static_cast<int>(__builtin_amdgcn_readfirstlane(p)) + AHEAD < it);
+        }
+        if (!behind) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      for (int c = first; c < first + count; ++c)
+        for (int half = 0; half < 2; ++half) {
+          const uint32_t dst = base + 32768 + c * 8192 + half * 1024;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)static_cast<uintptr_t>(dst), 16, lane * 16,
+                                                   static_cast<int>(((it * 2 + half) & 1023) * 1024), 0, 0);
+        }
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    return;
+  }
+  // ---- consumer ----
+  u32x4 b0[8], b1[8];
+  for (int k = 0; k < 8; ++k)
+    for (int i = 0; i < 4; ++i) {
+      b0[k][i] = rnd_pair(0x89abcdeu + threadIdx.x * 64u + blockIdx.x * 16384u + k * 8u + i, false, true);
+      b1[k][i] = rnd_pair(0x13579bdu + threadIdx.x * 64u + blockIdx.x * 16384u + k * 8u + i, false, true);
+    }
+  f32x16 acc0, acc1;
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  auto frag = [&](int f) -> u32x4 { return *((lds_rd)(uintptr_t)(base + wave * 8192 + (f & 7) * 1024 + lane * 16)); };
+  uint64_t t0 = 0, r0 = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    t0 = __builtin_readcyclecounter();
+    r0 = wall_clock64();
+  }
+  u32x4 fr[4];
+  for (int i = 0; i < 4; ++i) fr[i] = frag(i);
+  uint32_t packed = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const u32x4 a = fr[u & 3];
+      fr[u & 3] = frag(u + 4);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b0[u]), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b1[u]), acc1, 0, 0, 0);
+      if (WHAT & kValu) {
+        uint32_t p;
+        if (WHAT & kClamp)
+          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2 clamp" : "=v"(p) : "v"(__builtin_bit_cast(float, b0[u][0])), "v"(__builtin_bit_cast(float, b1[u][1])));
+        else
+          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(p) : "v"(__builtin_bit_cast(float, b0[u][0])), "v"(__builtin_bit_cast(float, b1[u][1])));
+        packed ^= p;
+      }
+    }
+    if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(prog + wave * 4), "v"(it + 1) : "memory");
+    if ((it & 127) == 127) {
+      for (int r = 0; r < 16; ++r) {
+        acc0[r] *= 1.0e-6f;
+        acc1[r] *= 1.0e-6f;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clocks[0] = __builtin_readcyclecounter() - t0;
+    clocks[1] = wall_clock64() - r0;
+  }
+  const float s_ = acc0[0] + acc0[7] + acc1[3] + __builtin_bit_cast(float, packed);
+  if (s_ == 12345.678f) sink[0] = s_ + lds[threadIdx.x + 8192];
+}
+
+template <int WHAT, int LOADERS>
+void run_dataflow_pc(int cus, const uint32_t* gsrc, float* sink, uint64_t* d_clocks, double target_ms) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  int iters = 200;
+  const dim3 block(256 + 64 * LOADERS);
+  hipLaunchKernelGGL((mfma_burn_dataflow_pc<WHAT, LOADERS>), dim3(cus), block, 0, 0, 50, gsrc, sink, d_clocks);
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((mfma_burn_dataflow_pc<WHAT, LOADERS>), dim3(cus), block, 0, 0, iters, gsrc, sink, d_clocks);
+    (void)hipEventRecord(e1, 0);
+    if (hipEventSynchronize(e1) != hipSuccess) {
+      printf("producer/consumer dataflow launch failed\n");
+      return;
+    }
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep == 0) iters = static_cast<int>(iters * target_ms / (ms > 0.01 ? ms : 0.01)) + 1;
+  }
+  uint64_t ck[2] = {0, 0};
+  (void)hipMemcpy(ck, d_clocks, sizeof(ck), hipMemcpyDeviceToHost);
+  const double tf = 2.0 * 32 * 32 * 16 * 16.0 * iters * 4.0 * cus / ms * 1e-9, mhz = ck[1] ? 100.0 * ck[0] / static_cast<double>(ck[1]) : 0.0;
+  char what[96];
+  snprintf(what, sizeof(what), "LDS%s, DMA by %s", (WHAT & kValu) ? ((WHAT & kClamp) ? " + cvt-clamp" : " + conversions") : "",
+           LOADERS == 4 ? "a 2nd wave per SIMD" : "1 loader wave per CU");
+  printf("bf16 relu + %-42s %9.1f ms  %7.0f TFLOP/s  %5.0f MHz  issue-slot use %.3f  (of 2500: %.3f)\n", what, ms, tf, mhz,
+         mhz > 0 ? tf * 1e12 / (cus * 4.0 * 1024.0 * mhz * 1e6) : 0.0, tf / 2500.0);
+}
+
 template <int WHAT>
 void run_dataflow(int cus, const uint32_t* gsrc, float* sink, uint64_t* d_clocks, double target_ms) {
   hipEvent_t e0, e1;
@@ -106,7 +239,7 @@ void run_dataflow(int cus, const uint32_t* gsrc, float* sink, uint64_t* d_clocks
   (void)hipMemcpy(ck, d_clocks, sizeof(ck), hipMemcpyDeviceToHost);
   const double tf = 2.0 * 32 * 32 * 16 * 16.0 * iters * 4.0 * cus / ms * 1e-9, mhz = ck[1] ? 100.0 * ck[0] / static_cast<double>(ck[1]) : 0.0;
   printf("bf16 relu + %-22s 2 chains, 1 wave/SIMD %9.1f ms  %7.0f TFLOP/s  %5.0f MHz  issue-slot use %.3f  (of 2500: %.3f)\n",
-         WHAT == kLds ? "LDS fragments" : WHAT == (kLds | kDma) ? "LDS + DMA refill" : WHAT == (kLds | kDma | kValu) ? "LDS + DMA + conversions" : "registers only",
+         WHAT == kLds ? "LDS fragments" : WHAT == (kLds | kDma) ? "LDS + DMA refill" : WHAT == (kLds | kDma | kValu) ? "LDS + DMA + conversions" : WHAT == (kLds | kDma | kValu | 8) ? "LDS + DMA + cvt-clamp" : "registers only",
          ms, tf, mhz, mhz > 0 ? tf * 1e12 / (cus * 4.0 * 1024.0 * mhz * 1e6) : 0.0, tf / 2500.0);
 }
 
@@ -150,5 +283,12 @@ int main() {
   run_dataflow<kLds>(cus, gsrc, sink, d_clocks, 500.0);
   run_dataflow<kLds | kDma>(cus, gsrc, sink, d_clocks, 500.0);
   run_dataflow<kLds | kDma | kValu>(cus, gsrc, sink, d_clocks, 500.0);
+  printf("-- round 5: the refill issued by another wave of the workgroup; conversions as one clamped cvt (~500 ms per launch)\n");
+  run_dataflow_pc<kLds | kDma, 4>(cus, gsrc, sink, d_clocks, 500.0);
+  run_dataflow_pc<kLds | kDma, 1>(cus, gsrc, sink, d_clocks, 500.0);
+  run_dataflow_pc<kLds | kDma | kValu, 4>(cus, gsrc, sink, d_clocks, 500.0);
+  run_dataflow_pc<kLds | kDma | kValu, 1>(cus, gsrc, sink, d_clocks, 500.0);
+  run_dataflow_pc<kLds | kDma | kValu | kClamp, 4>(cus, gsrc, sink, d_clocks, 500.0);
+  run_dataflow<kLds | kDma | kValu | kClamp>(cus, gsrc, sink, d_clocks, 500.0);
   return 0;
 }
