@@ -36,7 +36,11 @@ def include_closure(sources=None):
 LIB_DEPS = include_closure()
 ARCH = "gfx950"
 # -ffp-contract=off: the fused and the debug kernels must generate bit-identical rays.
-HIPCC_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off"]
+# -fno-slp-vectorize (round 5): no packed-fp32 VALU (v_pk_mul / add / fma_f32) anywhere in the device code.  The SLP vectoriser emitted ~4 300 of
+# them; the only reproducibility fault this library has had (round 3, tools/probes/pk_mul_fault/) needs SLP-packed fp32 code around a packed
+# product and disappears with this flag, and the flag costs nothing measurable (profiles/r05_variants_slp_splitpack.log).  tests/test_host_cpu.py
+# checks the assembly.
+HIPCC_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"]
 # Per translation unit: the main one keeps MFMA accumulators in architectural VGPRs, so the VALU epilogues of the 16-bit
 # kernels read them without v_accvgpr_read copies (split-precision sampling kernel 1.48 -> 1.35 ms); the fp32-MFMA
 # kernels (launch_f32.hip) are slower that way and keep the compiler's default (AGPR accumulators).

@@ -261,7 +261,7 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   // the shading net takes no such input on this path (RayMarchFromPoses ignores the key)
   ms->ray_samples = cf.raySampleInput.empty() ? 0 : cf.raySampleInput[0];
   if (ms->ray_samples < 0 || ms->ray_samples > 1024) return bad(ADANERF_EUNSUPPORTED, "raySampleInput[0] must be in 0..1024");
-  if (cf.viewcellCenter.size() != 3 || cf.viewcellSize.size() != 3 || cf.depthRange.size() != 2 || cf.fov <= 0.f)
+  if (cf.viewcellCenter.size() != 3 || cf.viewcellSize.size() != 3 || cf.depthRange.size() != 2 || cf.fov <= 0.0)
     return bad(ADANERF_EIO, "dataset_info.txt: view_cell_center/view_cell_size/depth_range/fov missing or malformed");
   if (cf.numRaymarchSamples.empty()) return bad(ADANERF_EIO, "config.ini: numRaymarchSamples missing");
   ms->fp0 = static_cast<int>(cf.posEncArgs[0][0]);
@@ -370,7 +370,7 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
   I.sampler_mode = coarse_fine ? ADANERF_SAMPLER_COARSE_FINE : (pdf_mode ? ADANERF_SAMPLER_PDF : ADANERF_SAMPLER_ADAPTIVE);
   I.num_samples_coarse = ms->n_coarse;
   I.precision = opt->precision;
-  I.fov = cf.fov;
+  I.fov = static_cast<float>(cf.fov);
   const double fov = cf.fov;
   const double focal = 0.5 * w / std::tan(0.5 * fov);   // src/datasets.py:182
   I.focal = static_cast<float>(focal);

@@ -100,7 +100,7 @@ void Config::store(std::string key, std::string value) {
   else if (key == "depth_range") depthRange = to_floats(L);
   else if (key == "view_cell_size") viewcellSize = to_floats(L);
   else if (key == "view_cell_center") viewcellCenter = to_floats(L);
-  else if (key == "fov") fov = static_cast<float>(std::atof(value.c_str()));
+  else if (key == "fov") fov = std::atof(value.c_str());
   else if (key == "max_depth") max_depth = static_cast<float>(std::atof(value.c_str()));
   else if (key == "raySampleInput") raySampleInput = to_ints(L);
   else if (key == "multiDepthFeatures") multiDepthFeatures = to_ints(L);

@@ -33,7 +33,8 @@ struct Config {
   float adaptiveSamplingThreshold = -1.0f;
   std::string accumulationMult;
   bool useNDC = false;
-  float fov = 0.f, max_depth = 0.f;
+  double fov = 0.0;      // float64 like the PyTorch path's camera_angle_x (src/datasets.py:181-182): the pixel-ray table is float64 arithmetic on it
+  float max_depth = 0.f;
   std::vector<float> viewcellCenter, viewcellSize, depthRange;
 
   // load(dir): config.ini then dataset_info.txt; returns false + message on failure

@@ -482,18 +482,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
 // instruction stream hides latencies: the two accumulator chains alternate (no dependent back-to-back MFMAs), the bias block of
 // tile m + 1 is requested while tile m computes, and the epilogue of tile m - 1 (both blocks: 8 quads) is spread over the
 // first k-steps of tile m.  Both chains start from the bias registers as the C operand (no copies).
-// FILL: work of the NEXT sample tile that rides in this layer's instruction stream (shade_mlp16x2_kernel, ShadePrefetch): tile m of the
-// layer calls fill.tile<m>() in the middle of its k-steps, inside the tile's scheduling region, so that the pinned interleave below hands the
-// filler's VALU the slots the previous tile's epilogue leaves free (it occupies the first 8 of a tile's k-steps only).
-struct NoFill {
-  template <int M>
-  __device__ __forceinline__ void tile() {}
-};
-
-template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1, class FILL = NoFill>
+template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
 __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uint32_t* in1A, const uint32_t* in2A, const uint32_t* in1B,
                                            const uint32_t* in2B, uint32_t* outA, uint32_t* outB, f32x16* keepA = nullptr,
-                                           f32x16* keepB = nullptr, FILL* fill = nullptr) {
+                                           f32x16* keepB = nullptr) {
   constexpr int CF = WS::kChunk;
   constexpr int KS = S1 + S2;
   constexpr int ABL = tune::kAblateShade;
@@ -534,9 +526,6 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
       accA = ET::mfma(st.R[f % WS::kRegs], ba, s == 0 ? bias : accA);
       accB = ET::mfma(st.R[f % WS::kRegs], bb, s == 0 ? bias : accB);
       ws_refill<ABL>(st, f);
-      if constexpr (!std::is_same<FILL, NoFill>::value) {
-        if (s == KS / 2) fill->template tile<m_const(m)>();
-      }
       if (m > 0 && KEEP_F32_TILE != m - 1 && !(ABL & 8)) {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {

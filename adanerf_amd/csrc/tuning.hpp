@@ -224,11 +224,13 @@ constexpr int kRegFrags2 = ADN_NR2;
 constexpr int kRegFrags2 = 16;
 #endif
 
-// split_pack form of the split-precision engines' epilogue (k_sampling16.hip.hpp): 0 packed fp32, 1 scalar fp32, 2 v_fma_mix
+// split_pack form of the split-precision engines' epilogue (k_sampling16.hip.hpp): 0 packed fp32, 1 scalar fp32, 2 v_fma_mix.  Bit-identical;
+// measured the same within noise (profiles/r05_variants_slp_splitpack.log: split-on-every-ray sampling stage 1.293 / 1.291 / 1.336 ms).  Shipped: 1,
+// so that the device code holds no packed-fp32 instruction at all (build.py HIPCC_FLAGS, tools/probes/pk_mul_fault/).
 #if ADN_OVERRIDABLE && defined(ADN_SPLIT_PACK)
 constexpr int kSplitPack = ADN_SPLIT_PACK;
 #else
-constexpr int kSplitPack = 0;
+constexpr int kSplitPack = 1;
 #endif
 
 // ---- selection (k_compact.hip.hpp) -----------------------------------------------------------------------------------

@@ -108,7 +108,11 @@ def test_device_ray_table_equals_the_references(cases, key, tmp_path):
         buf = r.empty((w, 8), np.float32)
         for row, want in zip(zt[key + "/rows"], zt[key + "/row_dirs"]):
             r.ray_features(int(row) * w, w, None, buf)
-            assert np.array_equal(buf.numpy()[:, 4:7], want), (key, int(row))
+            got = buf.numpy()[:, 4:7]
+            bad = got != want
+            assert not bad.any(), "%s row %d: %d of %d values differ, max |diff| %.3e, first at %s: %r vs %r" % (
+                key, int(row), int(bad.sum()), bad.size, float(np.abs(got - want).max()), np.argwhere(bad)[0].tolist(),
+                got[tuple(np.argwhere(bad)[0])], want[tuple(np.argwhere(bad)[0])])
 
 
 # ---------------------------------------------------------------------------------------------

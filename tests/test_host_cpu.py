@@ -49,6 +49,9 @@ def test_dependency_list_is_the_include_closure():
         rel = os.path.normpath(todo.pop())
         if rel in seen:
             continue
+        if os.path.basename(rel).startswith("x_") and not os.path.exists(os.path.join(csrc, rel)):
+            assert os.path.exists(os.path.join(ROOT, "tools", "experiments", os.path.basename(rel)))      # experiment-only, reached through -I
+            continue
         seen.add(rel)
         for line in open(os.path.join(csrc, rel), errors="replace"):
             m = re.match(r'\s*#\s*include\s+"([^"]+)"', line)
@@ -58,7 +61,7 @@ def test_dependency_list_is_the_include_closure():
     assert "k_generic16.hip.hpp" in B.LIB_DEPS and os.path.normpath("../../include/adanerf_hip.h") in B.LIB_DEPS
     every_header = {f for f in os.listdir(csrc) if f.endswith((".hpp", ".h"))}
     assert every_header <= set(B.LIB_DEPS), "headers in csrc/ that no translation unit includes: %s" % sorted(every_header - set(B.LIB_DEPS))
-    # the stamp moves with any hashed file and ignores the experiment-only header
+    assert not any(f.startswith("x_") for f in os.listdir(csrc)), "experiment-only headers belong in tools/experiments/"
     h0 = B.source_hash()
     assert re.fullmatch(r"[0-9a-f]{16}", h0)
 
@@ -135,6 +138,22 @@ def test_device_code_has_no_crossbar_exchange_and_no_lds_dma_outliving_its_workg
     for frag in ("shade_mlp16x2_kernel", "shade_mlp16_kernel", "sample_mlp16x3_kernel", "sample_mlp16_kernel", "shade_mlp16_gen_staged_kernel",
                  "sample_mlp16x3_gen_kernel"):
         assert any(frag in n for n in checked), frag
+
+
+def test_device_code_has_no_packed_fp32_valu():
+    """Round 5: the shipped flags' gfx950 assembly holds no v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32.  The round-3
+    reproducibility fault needs SLP-packed fp32 code around a packed product (tools/probes/pk_mul_fault/README.md: the failing kernel passes
+    when built with -fno-slp-vectorize, with or without a hand-written v_pk_mul_f32 of its own), and beside MFMAs a packed fp32 op costs more
+    than the two scalar ones it replaces (MI355X_MICROARCH.md); the library is built with -fno-slp-vectorize and its one explicit float2
+    computation (split_pack) is scalar."""
+    from adanerf_amd import build as B
+    assert "-fno-slp-vectorize" in B.HIPCC_FLAGS
+    text = _device_assembly()
+    if text is None:
+        pytest.skip("no hipcc")
+    hits = re.findall(r"v_pk_(?:mul|add|fma)_f32", text)
+    assert not hits, "%d packed-fp32 instructions in the device code" % len(hits)
+    assert text.count("v_mfma_f32_32x32x16") > 10000      # (the text really is the library's assembly)
 
 
 def test_abi_handshake(lib):
