@@ -198,7 +198,13 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
     unit3(nds, u);
 
     uint32_t aH[64], aL[64], bH[64], bL[64];
-    {
+    if (tune::kAblateSample & 256) {      // timing ablation (wrong results): no encoding, inputs = cheap functions of the ray
+#pragma unroll
+      for (int q = 0; q < Q0 / 2; ++q) {
+        aH[q] = __builtin_bit_cast(uint32_t, u[q % 3]) >> 3;
+        aL[q] = __builtin_bit_cast(uint32_t, p[q % 3]) >> 5;
+      }
+    } else {
       float t[Q0];
       pe_eval<FD, !(tune::kAblateSample & 128)>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
       pe_eval<FP, !(tune::kAblateSample & 128)>(p, h, t + QD);
@@ -342,8 +348,13 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
     uint32_t hA[64], hB[64];
     {
       float t[Q0];
-      pe_eval<FD, !(tune::kAblateSample & 128) && !tune::kFastPeFp16Pass>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
-      pe_eval<FP, !(tune::kAblateSample & 128) && !tune::kFastPeFp16Pass>(p, h, t + QD);
+      if (tune::kAblateSample & 256) {      // timing ablation (wrong results): no encoding
+#pragma unroll
+        for (int q = 0; q < Q0; ++q) t[q] = (q & 1) ? u[q % 3] : p[q % 3];
+      } else {
+        pe_eval<FD, !(tune::kAblateSample & 128) && !tune::kFastPeFp16Pass>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874)
+        pe_eval<FP, !(tune::kAblateSample & 128) && !tune::kFastPeFp16Pass>(p, h, t + QD);
+      }
       uint32_t in0[Q0 / 2];
 #pragma unroll
       for (int q = 0; q < Q0 / 2; ++q) in0[q] = Fp16::pack(t[2 * q], t[2 * q + 1]);

@@ -108,7 +108,7 @@ bool Settings::init(int argc, char** argv, std::string* err) {
     return false;
   }
   total_size = width * height;
-  if (sampling.empty()) sampling = precision == "fp32" ? "split" : "guarded";
+  if (sampling.empty()) sampling = "split";      // exact by construction; guarded / fp16 are opt-in (the default rule)
   if (!ws_used) {
     window_width = width;
     window_height = height;

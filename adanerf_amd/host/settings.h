@@ -15,8 +15,8 @@ class Settings {
   int frames = 100;             // --frames: frames to render before exiting
   std::string precision = "bf16";
   std::string sampling;               // --sampling guarded|split|fp32|fp16: arithmetic of the sampling network (ADANERF_SAMPLING_*); the
-                                      // viewer itself has one (TensorRT kFP16 = "fp16"); "guarded" keeps the exact engine's selections.
-                                      // Not given: guarded with a 16-bit shading network, split with --precision fp32 (the parity mode)
+                                      // viewer itself has one (TensorRT kFP16 = "fp16"); "guarded" keeps the exact engine's selections while its
+                                      // measured band holds.  Not given: split (exact by construction on every ray; DESIGN 1 has the rule)
   float yaw = -80.f, pitch = 0.f;   // Camera::init defaults (camera.cpp:90-91)
   int num_samples = 0;
   float threshold = -1.f;

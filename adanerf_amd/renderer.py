@@ -210,15 +210,16 @@ class NeuralRenderer:
                  sampling: Optional[str] = None, lib_path: Optional[str] = None, keep_oracle: bool = False, wave_select: bool = False,
                  guard_eps: float = 0.0, guard_eps_pair: float = 0.0, guard_audit_period: int = 0, guard_cache: bool = True,
                  guard_audit_fill: bool = True):
-        """sampling: arithmetic of the sampling network -- "guarded" (plain fp16 for every ray + the split-precision engine where the
-        audited guard band cannot decide; the split engine's selections), "split", "fp32", "fp16" (opt-in speed mode).  Default (None),
-        as in the `adanerf` CLI and bench.py: "guarded" with a 16-bit shading network; "split" with precision="fp32" -- the
-        tight-tolerance parity mode, where the kept oracle values of the rays the guarded mode does not re-evaluate (the fp16 engine's,
-        within the band of the exact ones: ~4e-3) would be the largest error of the frame.  guard_*: include/adanerf_hip.h adanerf_options.
-        guard_audit_fill (default, both hosts): the audit fills the refinement pass's last round instead of adding one, and never audits
-        less than a quarter of the 1 / period quota (ADANERF_FLAG_GUARD_AUDIT_FILL); False: exactly 1 / period of all rays every frame."""
+        """sampling: arithmetic of the sampling network -- "split" (default: split-fp16, fp32-accurate on every ray, the selection exact by
+        construction), "fp32" (fp32 MFMA), "guarded" (opt-in: plain fp16 for every ray + the split engine where the audited guard band cannot
+        decide; the split engine's selections as long as the measured band holds -- monitored, audited, widened when violated), "fp16" (opt-in
+        speed mode, the viewer's TensorRT arithmetic; selections differ on ~1 % of rays).  The default follows a rule: the mode that is
+        exact by construction, unless the guarded mode is >= 8 % faster on the same box in the same bench.py run -- measured 4-5 %.  Same default in
+        the `adanerf` CLI and bench.py.  guard_*: include/adanerf_hip.h adanerf_options.  guard_audit_fill (default): the audit fills the
+        refinement pass's last round instead of adding one, and never audits less than a quarter of the 1 / period quota
+        (ADANERF_FLAG_GUARD_AUDIT_FILL); False: exactly 1 / period of all rays every frame."""
         if sampling is None:
-            sampling = "split" if (_PREC[precision] if isinstance(precision, str) else int(precision)) == PREC_FP32 else "guarded"
+            sampling = "split"
         self.settings = settings
         self.lib = load_library(lib_path)
         self.handle = None

@@ -75,8 +75,8 @@ def check_rows_against_oracle(sc, wts, w, h, pose, rot, rows, cnt, rgb, min_same
 # ---------------------------------------------------------------------------------------------
 
 def test_config4_thr01_eight_way_shard(classroom, tmp_path_factory):
-    """Runs in the host's default sampling mode -- the guarded two-precision selection bench.py measures -- and checks the full-size
-    rows against the oracle in it; the split engine's frame must select the same samples on every ray."""
+    """Runs in the opt-in guarded two-precision selection and checks the full-size rows against the oracle in it; the host's default
+    (the split engine on every ray) must select the same samples on every ray."""
     z, meta, sc, wts = classroom
     sc4 = dataclasses.replace(sc, threshold=0.1)
     d = _dir(tmp_path_factory, sc4, wts, "config4")
@@ -84,18 +84,19 @@ def test_config4_thr01_eight_way_shard(classroom, tmp_path_factory):
     world = 8
     strip = sharding.balanced_strip_rows(h, world)
     assert strip == 5
-    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16") as r:
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded") as r:
         r.set_camera(z["pose"], z["rot"])
         assert abs(r.info.threshold - 0.1) < 1e-7
         rgb, full, st = r.render_numpy()
         cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,))
     assert cnt.min() >= 1 and cnt.max() <= 8 and st.total_samples == int(cnt.sum())
     assert r._opt.sampling_mode == R.SAMPLING_MODES["guarded"] and st.rays_refined > 0 and st.guard_violations == 0 and st.guard_audit_mismatch == 0
-    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="split") as rs:
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16") as rs:      # the default: split precision on every ray
+        assert rs._opt.sampling_mode == R.SAMPLING_MODES["split"]
         rs.set_camera(z["pose"], z["rot"])
         rs.render(None, None, stats=True)
         assert np.array_equal(rs.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,)), cnt)
-    img, samples = render_sharded(d, w, h, z["pose"], z["rot"], world, strip, precision="bf16")
+    img, samples = render_sharded(d, w, h, z["pose"], z["rot"], world, strip, precision="bf16", sampling="guarded")
     assert np.array_equal(img, full)                       # assembled bytes == unsharded frame
     assert sum(samples) == st.total_samples
     record("config4_shard", samples_per_rank=samples, imbalance=max(samples) / (sum(samples) / world))
@@ -166,13 +167,13 @@ def ndc(tmp_path_factory):
 def test_config5_thresholds_01_03(ndc, thr):
     z, meta, sc, wts, d = ndc
     w, h = 1920, 1080
-    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="fp16", threshold=thr) as r:
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="fp16", threshold=thr, sampling="guarded") as r:
         r.set_camera(z["pose"], z["rot"])
         rgb, rgba, st = r.render_numpy()
         cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,))
         off = r.buffer(R.BUF_RAY_OFFSETS, np.int32, (w * h,))
         assert r.last_stats.sampling_overflow == 0
-        # the host's default mode: the guarded selection, band silent, audit clean
+        # the opt-in guarded selection at this frame size: band silent, audit clean
         assert r._opt.sampling_mode == R.SAMPLING_MODES["guarded"] and st.rays_refined > 0 and st.guard_violations == 0 and st.guard_audit_mismatch == 0
     assert cnt.min() >= 1 and cnt.max() <= 8 and st.total_samples == int(cnt.sum())
     assert np.array_equal(off[1:].astype(np.int64), np.cumsum(cnt.astype(np.int64))[:-1])

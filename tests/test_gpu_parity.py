@@ -738,7 +738,7 @@ def test_guarded_sampling_reproduces_the_split_engine(cases, name, w, h, bs):
                         mismatch=int(st.guard_audit_mismatch), source=int(r.info.guard_calib_source))
 
     split = run(sampling="split")
-    guard = run()                                   # the host's default mode; band from the model's calibration record / measured at the first frame
+    guard = run(sampling="guarded")                 # band from the model's calibration record / measured at the first frame
     wide = run(sampling="guarded", guard_eps=1.0)
     meta_keys = ("refined", "eps", "seen", "viol", "eps_pair", "pair_seen", "audited", "mismatch", "source")
     for k in ("total", "cnt", "off", "tot", "key"):
@@ -861,7 +861,7 @@ def test_guard_calibration_record(cases, tmp_path, monkeypatch):
     w, h = 96, 64
 
     def frame(**kw):
-        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", **kw) as r:
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded", **kw) as r:
             path = r.guard_calibration_file()
             r.set_camera(z["pose"], z["rot"])
             _, rgba, st = r.render_numpy()
@@ -904,7 +904,7 @@ def test_guarded_frames_are_audited(cases):
     selection mismatches on audited decided rays in its very first frame and widens the band."""
     z, meta, sc, wts, d = cases["classroom_n8_thr02"]
     w, h = 320, 200
-    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", guard_audit_fill=False) as r:      # the full quota every frame
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded", guard_audit_fill=False) as r:      # the full quota every frame
         r.set_camera(z["pose"], z["rot"])
         assert r.info.guard_audit_period == 16
         frames, sts = [], []
@@ -918,13 +918,13 @@ def test_guarded_frames_are_audited(cases):
     assert all(x[0] - (x[1] - y[1]) == und for x, y in zip(sts[1:], sts)) and sum(audited) == w * h - und
     assert max(audited) - min(audited) <= 0.05 * (w * h - und) / 16 + 64
     assert sts[-1][2] == 0 and sts[-1][3] == 0
-    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", guard_eps=1e-4) as r:
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded", guard_eps=1e-4) as r:
         r.set_camera(z["pose"], z["rot"])
         _, _, st = r.render_numpy()
         narrow = (int(st.rays_refined), int(st.guard_audited), int(st.guard_audit_mismatch), int(st.guard_violations), int(st.guard_widened))
         eps_after = float(r.refresh_info().guard_eps)
         src = int(r.info.guard_calib_source)
-    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", guard_eps=1e-4, guard_audit_period=-1) as r:
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded", guard_eps=1e-4, guard_audit_period=-1) as r:
         r.set_camera(z["pose"], z["rot"])
         _, _, st = r.render_numpy()
         assert r.info.guard_audit_period == 0 and st.guard_audited == 0 and st.guard_audit_mismatch == 0
@@ -976,8 +976,8 @@ def test_guarded_frames_next_to_other_contexts(cases):
     visible next to other contexts).  Integer exchanges of the selection / compaction kernels are DPP since round 4."""
     z, meta, sc, wts, d = cases["classroom_n8_thr02"]
     w, h = 256, 192
-    ctxs = [adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", shard_rank=k, shard_world=2, strip_rows=8) for k in range(2)]
-    ctxs.append(adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16"))
+    ctxs = [adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded", shard_rank=k, shard_world=2, strip_rows=8) for k in range(2)]
+    ctxs.append(adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling="guarded"))
     try:
         outs = []
         for r in ctxs:
@@ -1231,7 +1231,7 @@ def test_headless_cli_matches_library(cases, tmp_path):
     row_bytes = (w * 3 + 3) & ~3
     px = np.frombuffer(bmp[off:off + row_bytes * h], dtype=np.uint8).reshape(h, row_bytes)[:, :w * 3].reshape(h, w, 3)
     img = px[::-1, :, ::-1]                                                       # bottom-up BGR -> top-down RGB
-    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, w, h, batch_size=5000), precision="bf16", sampling="guarded") as r:      # the CLI's default
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, w, h, batch_size=5000), precision="bf16") as r:      # the CLI's default: split precision on every ray
         pose = np.array(sc.view_cell_center, dtype=np.float32)
         r.set_camera(pose, O.camera_rotation(100.0, 0.0))
         _, rgba, _ = r.render_numpy()
@@ -1274,7 +1274,7 @@ def test_headless_cli_scripted_input_session(cases, tmp_path, end_in_oracle_view
     assert abs(yaw - (-80.0 - 50 * 0.15)) < 1e-4 and abs(pitch - (-20 * 0.15)) < 1e-4
     assert last[11] == ("oracle" if end_in_oracle_view else "image")
     img = _bmp_pixels(os.path.join(md, "out.bmp"), w, h)
-    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, w, h), precision="bf16", sampling="guarded") as r:      # the CLI's default
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, w, h), precision="bf16") as r:      # the CLI's default: split precision on every ray
         r.set_camera(pos, O.camera_rotation(yaw, pitch))
         if end_in_oracle_view:
             image = r.empty((w * h, 4), np.uint8)
@@ -1486,11 +1486,13 @@ def test_bench_two_ranks_share_one_gpu(tmp_path, mode):
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
     want = (1, 2) if mode == "sub_shares" else (2, 1)
     assert (rec["config"]["frames_in_flight"], rec["config"]["sub_shares_per_gpu"], rec["config"]["exchange"]["sub_shares_per_rank"]) == want + want[1:]
-    assert r1_guard_ok(rec)
+    assert rec["config"]["guard"] is None and "split-fp16" in rec["config"]["workload"]      # the default: split precision on every ray
     r1 = json.loads([ln for ln in a.stdout.splitlines() if ln.startswith("{")][0])
     assert abs(rec["config"]["samples_per_frame"] - r1["config"]["samples_per_frame"]) < 0.5
-    assert r1_guard_ok(r1) and r1["exact_mode"]["rays_with_the_headline_modes_sample_count"] == 1.0
-    assert r1["exact_mode"]["samples_per_frame"] == r1["config"]["samples_per_frame"]
+    # the opt-in guarded mode, measured beside the headline in the same run: same selection on every ray, band silent, audit clean
+    g = r1["guarded_mode"]
+    assert r1_guard_ok(g["guard"]) and g["rays_with_the_headline_modes_sample_count"] == 1.0 and g["value"] > 0
+    assert g["samples_per_frame"] == r1["config"]["samples_per_frame"] and "default_rule" in g
     assert r1["split_frame_mode"]["image_identical_to_the_headline_frame"] is True and r1["split_frame_mode"]["value"] > 0
     img1, img2 = np.load(one), np.load(two)
     assert img1.shape == img2.shape == (800, 800, 4)
@@ -1531,9 +1533,8 @@ def test_bench_plain_python_launches_itself(tmp_path):
     assert np.array_equal(np.load(two), np.load(peer))
 
 
-def r1_guard_ok(rec):
+def r1_guard_ok(g):
     """the bench line's record of the guarded selection: band from a 64-pose calibration, monitor silent, audit ran and is clean"""
-    g = rec["config"]["guard"]
     return g["band_source"] in ("record", "calibration") and g["calibration_poses"] == 64 and g["monitor_violations"] == 0 and \
         g["audit_mismatches"] == 0 and g["rays_audited"] > 0 and g["audit_period"] == 16 and 0 < g["monitor_max_seen"] <= g["eps"] and 0 < g["eps_pair"] <= 2 * g["eps"]
 

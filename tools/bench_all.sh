@@ -1,8 +1,8 @@
 #!/bin/bash
 # on the GPU box: one bench line per BASELINE configuration that fits one GPU -> gpurun_out/bench_all/<name>.json
 cd "$(dirname "$0")/.."
-O=gpurun_out/${ROUND:-r04}_bench_all; mkdir -p $O
-run() { n=$1; shift; python bench.py --no-speed-mode --no-exact-mode --no-split-mode "$@" 2>/dev/null | tail -1 > $O/$n.json; python - "$O/$n.json" "$n" <<'PY'
+O=gpurun_out/${ROUND:-r05}_bench_all; mkdir -p $O
+run() { n=$1; shift; python bench.py --no-speed-mode --no-exact-mode --no-guarded-mode --no-split-mode "$@" 2>/dev/null | tail -1 > $O/$n.json; python - "$O/$n.json" "$n" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
 q = d.get("quality") or {}
@@ -11,7 +11,8 @@ print("%-22s %7.1f FPS  spp %.2f  stages %s  frac %.3f  psnr %s" % (sys.argv[2],
 PY
 }
 run config2_bf16 --steps 30 --no-cpu-baseline
-run config2_bf16_audit_off --steps 30 --guard-audit-period -1 --no-cpu-baseline
+run config2_bf16_guarded --steps 30 --sampling guarded --no-cpu-baseline
+run config2_bf16_guarded_audit_off --steps 30 --sampling guarded --guard-audit-period -1 --no-cpu-baseline
 run config2_fp16 --steps 30 --precision fp16 --no-cpu-baseline
 run config2_fp32 --steps 10 --precision fp32 --no-cpu-baseline
 run config2_fp32sampling --steps 20 --sampling fp32 --no-cpu-baseline
@@ -21,7 +22,7 @@ for t in 0.05 0.1 0.2 0.3 0.4; do run config5_ndc_fp16_thr$t --steps 20 --worklo
 run config2_orbit16 --steps 32 --orbit 16 --no-cpu-baseline
 run nerf_coarse_fine --steps 5 --warmup 2 --workload nerf_coarse_fine --no-cpu-baseline
 run config2_fp16_sampling_only --steps 30 --sampling fp16 --no-cpu-baseline
-run config2_split_sampling --steps 30 --sampling split --no-cpu-baseline
+run config5_ndc_fp16_thr0.2_guarded --steps 20 --workload config5_ndc --precision fp16 --threshold 0.2 --sampling guarded --no-cpu-baseline
 run generic_6x128_bf16 --steps 10 --workload generic_6x128 --no-cpu-baseline
 run generic_6x128_fp32 --steps 5 --workload generic_6x128 --precision fp32 --no-cpu-baseline
 run generic_4x64_bf16 --steps 20 --workload generic_4x64 --no-cpu-baseline

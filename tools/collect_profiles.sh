@@ -11,7 +11,7 @@ OUT=$R/gpurun_out/${PROF_DIR:-prof}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps ${STEPS:-20} --warmup 5 --no-cpu-baseline --no-speed-mode --no-exact-mode --no-split-mode --no-sustained-probe ${BENCH_ARGS:-}"
+ARGS="--steps ${STEPS:-20} --warmup 5 --no-cpu-baseline --no-speed-mode --no-exact-mode --no-guarded-mode --no-split-mode --no-sustained-probe ${BENCH_ARGS:-}"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py $ARGS > $OUT/stats.log 2>&1
 cp $OUT/stats/bench_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE GRBM_COUNT"; do

@@ -3,7 +3,7 @@
 # subset of the GPU tests against each variant (ADANERF_LIB selects the library the Python host loads)
 cd "$(dirname "$0")/.."
 for f in tools/ablate_libs/*.so; do
-  ADANERF_LIB=$PWD/$f timeout 120 python bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline ${BENCH_ARGS:---no-speed-mode} 2>/dev/null | python -c "
+  ADANERF_LIB=$PWD/$f timeout 120 python bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline ${BENCH_ARGS:---no-speed-mode --no-guarded-mode} 2>/dev/null | python -c "
 import json,sys
 r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$(basename $f .so)', round(r['value'],1), {k: round(x,3) for k,x in r['stage_ms_per_frame'].items()}, round(r['config']['mean_samples_per_ray'],3), round(r['quality'].get('psnr_vs_oracle_db',0),1) if r['quality'] else '')"
   if [ "${CHECK:-0}" = "1" ]; then
