@@ -341,7 +341,7 @@ def main():
                          "(adanerf_gather_to, the C++ host's path) -- no launcher needed")
     ap.add_argument("--no-alternatives", action="store_true",
                     help="N > 1: skip the short extra measurements of the other exchange paths reported under config.exchange.alternatives")
-    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("ADANERF_BENCH_WATCHDOG_S", "900")),
+    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("ADANERF_BENCH_WATCHDOG_S", "600")),
                     help="seconds after which a run that is stuck (a collective that never returns) prints the line it has and exits; 0: off")
     ap.add_argument("--dump-image", default=None, help="rank 0 writes the last frame's RGBA8 image [h,w,4] as .npy (tests)")
     args = ap.parse_args()

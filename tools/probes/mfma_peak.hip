@@ -216,6 +216,114 @@ void run_dataflow_pc(int cus, const uint32_t* gsrc, float* sink, uint64_t* d_clo
          mhz > 0 ? tf * 1e12 / (cus * 4.0 * 1024.0 * mhz * 1e6) : 0.0, tf / 2500.0);
 }
 
+
+// Round 5: the dataflow of the RUN-TIME-SHAPED kernels (k_generic16.hip.hpp, TileStage) around the same ReLU-like stream.
+// Per output tile of 32 features: s_waitcnt vmcnt(0) + s_barrier, the copy of the NEXT tile's KS fragments (global -> LDS, every wave each
+// fourth KiB) into the other of two buffers, the tile's bias block (4 ds_read_b128 per sample block), KS k-steps of NB MFMAs (each fragment
+// read from LDS feeds NB sample blocks, requested up to 4 ahead), then the tile's conversions (8 NB x (v_cvt_pk + v_pk_max)).  KS = W / 16 is what
+// a hidden layer of width W has: 4 / 8 / 16 for 64 / 128 / 256, i.e. 8 / 16 / 32 MFMAs per wave between two barriers at NB = 2.
+// OCC workgroups of 4 waves per CU as the kernels run (2 / 2 / 1).  RESIDENT: the same without wait, barrier and copy -- every fragment already
+// in LDS (what a network that fits would see).
+template <int KS, int NB, int OCC, bool RESIDENT>
+__global__ __launch_bounds__(256, OCC) void tile_stage_dataflow(int tiles, const uint32_t* __restrict__ gsrc, float* sink, uint64_t* clocks) {
+  __shared__ __attribute__((aligned(1024))) uint32_t lds[2 * KS * 256 + 1024];      // two tile buffers + a 4 KiB "bias table"
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  for (int i = threadIdx.x; i < 2 * KS * 256 + 1024; i += 256) lds[i] = rnd_pair(0x2468aceu + i * 7u + blockIdx.x * 131u, false);
+  __syncthreads();
+  typedef const __attribute__((address_space(3))) u32x4* lds_rd;
+  const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds));
+  const uint32_t bias_at = base + 2 * KS * 1024;
+  u32x4 b[NB][KS];
+  for (int nb = 0; nb < NB; ++nb)
+    for (int k = 0; k < KS; ++k)
+      for (int i = 0; i < 4; ++i) b[nb][k][i] = rnd_pair(0x89abcdeu + threadIdx.x * 64u + blockIdx.x * 16384u + (nb * KS + k) * 8u + i, false, true);
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(gsrc), 0, 0x7fffffff, 0x00020000);
+#endif
+  uint64_t t0 = 0, r0 = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    t0 = __builtin_readcyclecounter();
+    r0 = wall_clock64();
+  }
+  constexpr int D = KS < 4 ? KS : 4;
+  uint32_t buf = 0, packed = 0;
+  float keepf = 0.f;
+  for (int t = 0; t < tiles; ++t) {
+    if (!RESIDENT) {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#if defined(__HIP_DEVICE_COMPILE__)
+      for (int i = wave; i < KS; i += 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)static_cast<uintptr_t>(base + (buf ^ 1u) * KS * 1024 + i * 1024), 16,
+                                                 lane * 16, static_cast<int>(((t * KS + i) & 1023) * 1024), 0, 0);
+#endif
+    }
+    const uint32_t rd = base + buf * KS * 1024 + lane * 16;
+    buf ^= 1u;
+    u32x4 fr[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) fr[i] = *((lds_rd)(uintptr_t)(rd + i * 1024));
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u32x4 v = *((lds_rd)(uintptr_t)(bias_at + (lane >> 5) * 64 + g * 16 + ((t & 15) * 128)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[nb][4 * g + e] = __builtin_bit_cast(float, v[e]) * 1.0e-9f;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const u32x4 a = fr[s % D];
+      if (s + D < KS) fr[s % D] = *((lds_rd)(uintptr_t)(rd + (s + D) * 1024));
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[nb][s]), acc[nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        uint32_t p;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(p) : "v"(acc[nb][2 * q]), "v"(acc[nb][2 * q + 1]));
+        packed ^= p;
+      }
+    keepf += acc[0][3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clocks[0] = __builtin_readcyclecounter() - t0;
+    clocks[1] = wall_clock64() - r0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (keepf + __builtin_bit_cast(float, packed) == 12345.678f) sink[0] = keepf + lds[threadIdx.x];
+}
+
+template <int KS, int NB, int OCC, bool RESIDENT>
+void run_tile_stage(int cus, const uint32_t* gsrc, float* sink, uint64_t* d_clocks, double target_ms) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  int tiles = 2000;
+  hipLaunchKernelGGL((tile_stage_dataflow<KS, NB, OCC, RESIDENT>), dim3(cus * OCC), dim3(256), 0, 0, 200, gsrc, sink, d_clocks);
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((tile_stage_dataflow<KS, NB, OCC, RESIDENT>), dim3(cus * OCC), dim3(256), 0, 0, tiles, gsrc, sink, d_clocks);
+    (void)hipEventRecord(e1, 0);
+    if (hipEventSynchronize(e1) != hipSuccess) {
+      printf("tile-stage dataflow launch failed\n");
+      return;
+    }
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep == 0) tiles = static_cast<int>(tiles * target_ms / (ms > 0.01 ? ms : 0.01)) + 1;
+  }
+  uint64_t ck[2] = {0, 0};
+  (void)hipMemcpy(ck, d_clocks, sizeof(ck), hipMemcpyDeviceToHost);
+  const double tf = 2.0 * 32 * 32 * 16 * static_cast<double>(KS) * NB * tiles * 4.0 * cus * OCC / ms * 1e-9, mhz = ck[1] ? 100.0 * ck[0] / static_cast<double>(ck[1]) : 0.0;
+  printf("width %3d: %2d MFMAs per wave per tile, %d workgroup(s) per CU, %-34s %8.1f ms  %7.0f TFLOP/s  %5.0f MHz  (of 2500: %.3f)\n", KS * 16, KS * NB, OCC,
+         RESIDENT ? "fragments resident in LDS" : "wait + barrier + copy per tile", ms, tf, mhz, tf / 2500.0);
+}
+
 template <int WHAT>
 void run_dataflow(int cus, const uint32_t* gsrc, float* sink, uint64_t* d_clocks, double target_ms) {
   hipEvent_t e0, e1;
@@ -290,5 +398,13 @@ int main() {
   run_dataflow_pc<kLds | kDma | kValu, 1>(cus, gsrc, sink, d_clocks, 500.0);
   run_dataflow_pc<kLds | kDma | kValu | kClamp, 4>(cus, gsrc, sink, d_clocks, 500.0);
   run_dataflow<kLds | kDma | kValu | kClamp>(cus, gsrc, sink, d_clocks, 500.0);
+  printf("-- round 5: the run-time-shaped kernels' per-tile staging (k_generic16.hip.hpp) around the ReLU-like stream, two sample blocks per wave (~300 ms per launch)\n");
+  run_tile_stage<4, 2, 2, false>(cus, gsrc, sink, d_clocks, 300.0);
+  run_tile_stage<4, 2, 2, true>(cus, gsrc, sink, d_clocks, 300.0);
+  run_tile_stage<8, 2, 2, false>(cus, gsrc, sink, d_clocks, 300.0);
+  run_tile_stage<8, 2, 2, true>(cus, gsrc, sink, d_clocks, 300.0);
+  run_tile_stage<16, 2, 1, false>(cus, gsrc, sink, d_clocks, 300.0);
+  run_tile_stage<16, 2, 1, true>(cus, gsrc, sink, d_clocks, 300.0);
+  run_tile_stage<16, 2, 2, false>(cus, gsrc, sink, d_clocks, 300.0);
   return 0;
 }

@@ -14,7 +14,7 @@ if len(sys.argv) > 2:
     thr = float(sys.argv[2])
 worlds = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (1, 2, 4, 8)
 prec = sys.argv[4] if len(sys.argv) > 4 else "bf16"
-sampling = sys.argv[5] if len(sys.argv) > 5 else "guarded"      # what bench.py measures by default
+sampling = sys.argv[5] if len(sys.argv) > 5 else "split"      # what bench.py measures by default (round 5)
 from adanerf_amd import sharding
 td = tempfile.mkdtemp()
 scene, _ = Bn.build_model_dir(td, tag, n_max, thr)

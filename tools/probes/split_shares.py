@@ -15,6 +15,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "config2"
 worlds = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 8, 4, 2)
 parts_list = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (1, 2, 3, 4)
 prec = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+sampling = sys.argv[5] if len(sys.argv) > 5 else "split"      # what bench.py measures by default (round 5)
 w, h, n_max, thr, tag = Bn.WORKLOADS[wl]
 td = tempfile.mkdtemp()
 scene, _ = Bn.build_model_dir(td, tag, n_max, thr)
@@ -29,7 +30,7 @@ for world in worlds:
         for rank in range(world):
             rs, streams, outs = [], [], []
             for k in range(parts):
-                r = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h), precision=prec, sampling="guarded", shard_rank=rank * parts + k, shard_world=vw,
+                r = adanerf_amd.NeuralRenderer(adanerf_amd.Settings(td, w, h), precision=prec, sampling=sampling, shard_rank=rank * parts + k, shard_world=vw,
                                                strip_rows=sharding.balanced_strip_rows(h, vw))
                 r.init(); r.set_camera(pose, rot)
                 s = torch.cuda.Stream(device=dev); r.set_stream(s.cuda_stream)
