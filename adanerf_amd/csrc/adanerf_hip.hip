@@ -173,6 +173,8 @@ int upload_net(adanerf_ctx* c, const PackedNet& pn, PackedDev* d) {
     d->params.b_off[i] = pn.b_off[i];
   }
   d->params.n_bias = static_cast<uint32_t>(pn.bias.size());
+  d->params.out_scale[0] = std::ldexp(1.0f, pn.out_exp[0]);      // 1 unless the bf16 packing scaled the layers (pack.cpp scale_layer)
+  d->params.out_scale[1] = std::ldexp(1.0f, pn.out_exp[1]);
   return ADANERF_OK;
 }
 
@@ -463,6 +465,33 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
     const float zw = zn * (1.0f - t) + zf * t;
     ms->ztab_coarse.push_back(cf.depthTransform == "log" ? powf(static_cast<float>(static_cast<double>(d1) - d0 + 1.0), zw) - 1.0f + d0
                                                          : zw * (d1 - d0) + d0);
+  }
+  // bf16 shading nets are packed scaled (pack.cpp scale_layer): every ReLU layer carries a power of two that keeps its activations <= 1 for
+  // encoding inputs whose identity slots stay below kPosIdentityBound (positions) -- a scene whose sample positions can exceed it is refused here
+  // rather than clamped silently.  Positions: camera inside the view cell, samples up to the far end of the depth range along a unit ray.
+  if (opt->precision == ADANERF_PREC_BF16) {
+    double zmax = std::max<double>(std::fabs(cf.depthRange[1]), std::fabs(cf.max_depth));
+    for (float z : ms->ztab) zmax = std::max<double>(zmax, std::fabs(z));
+    for (float z : ms->ztab_coarse) zmax = std::max<double>(zmax, std::fabs(z));
+    double cmax = 0.0, off = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      cmax = std::max<double>(cmax, std::fabs(cf.viewcellCenter[i]));
+      off = std::max<double>(off, std::fabs(static_cast<double>(sp.center[i]) - cf.viewcellCenter[i]));
+    }
+    const double world = cmax + 2.0 * rad + zmax, local = 2.0 * rad + zmax + off, M = std::max<double>(cf.max_depth, 1e-30);
+    double bound = world;
+    if (ndc) bound = 64.0;      // NDC cube [-1, 1]^3 for rays inside the frustum (positions o' + t d', t in [0, 1])
+    else if (sp.normalize == kNormMaxDepth) bound = world / M;
+    else if (sp.normalize == kNormCentered) bound = local;
+    else if (sp.normalize == kNormMaxDepthCentered) bound = local / M;
+    else if (sp.normalize == kNormInverseSqrtDistCentered) bound = std::sqrt(local / M);
+    else if (sp.normalize != kNormNone) bound = local;      // InverseDistCentered (<= |l|), LogCentered (<= |l| for max_depth >= e - 1 ... kept loose)
+    if (!(bound <= kPosIdentityBound)) {
+      char msg[256];
+      std::snprintf(msg, sizeof(msg), "sample positions of this scene can reach %.3g after rayMarchNormalization: beyond the %.0f the bf16 shading path's "
+                    "layer scaling assumes (pack.hpp kPosIdentityBound) -- use precision fp16 or fp32", bound, kPosIdentityBound);
+      return bad(ADANERF_EUNSUPPORTED, msg);
+    }
   }
   return ADANERF_OK;
 }
@@ -1356,7 +1385,8 @@ int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precis
     std::memcpy(bias_out, pn.bias.data(), pn.bias.size() * sizeof(float));
   }
   const bool rsi = net == 0 && pn.topo.ray_samples > 0;     // one more record: the raySampleInput block of layer 0
-  const int32_t n_rec = static_cast<int32_t>(pn.w_off.size()) + (rsi ? 1 : 0);
+  const bool scaled = pn.relu_scaled;                        // one more record: the output exponents of a scaled (bf16) shading net
+  const int32_t n_rec = static_cast<int32_t>(pn.w_off.size()) + (rsi ? 1 : 0) + (scaled ? 1 : 0);
   if (layer_out) {
     if (*n_layers < n_rec) return fail(nullptr, ADANERF_EINVAL, "layer_out too small");
     for (size_t i = 0; i < pn.w_off.size(); ++i) {
@@ -1371,6 +1401,13 @@ int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precis
       layer_out[4 * i + 1] = pn.topo.ray_samples;
       layer_out[4 * i + 2] = pe_slots(sh.lp0 ? sh.lp0 : sh.fp0);
       layer_out[4 * i + 3] = pn.mtiles[0];
+    }
+    if (scaled) {      // {alpha exponent, rgb exponent, 0, -1}: outputs of the packed network x 2^exponent = the network's own
+      const size_t i = pn.w_off.size();
+      layer_out[4 * i + 0] = pn.out_exp[0];
+      layer_out[4 * i + 1] = pn.out_exp[1];
+      layer_out[4 * i + 2] = 0;
+      layer_out[4 * i + 3] = -1;
     }
   }
   *weights_bytes = pn.weights.size();

@@ -27,6 +27,8 @@ struct NetParams {
   uint32_t w_off[kMaxLayers];
   uint32_t b_off[kMaxLayers];
   uint32_t n_bias;           // floats in `bias` (the run-time-shaped kernels copy the whole table to LDS once per workgroup)
+  float out_scale[2];        // shading nets: factors that take the kernel's alpha / rgb outputs back to the network's own scale (exact
+                             // powers of two; 1 unless the bf16 packing scaled the layers: pack.hpp PackedNet::out_exp)
 };
 
 // Everything ray generation needs (A1 + A2).  Doubles mirror the float64 numpy ray table of

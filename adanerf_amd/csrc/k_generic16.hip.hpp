@@ -42,8 +42,9 @@ __device__ __forceinline__ void layer_16_direct(const u32x4* __restrict__ w, con
     if (KEEP_F32_TILE == m) {
       *keep = acc;
     } else {
+      const int gd = mfma_guard<ET, RELU>(acc);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(acc, m, g, out);
+      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(acc, m, g, out, gd);
     }
   }
 }
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void shade_mlp16_gen_kernel(ShadeArgs a, Ge
     f32x16 rgb_tile;
     layer_16_direct<ET, KW / 2, 0, 1, false, 0>(w + a.net.w_off[lf + 2], b + a.net.b_off[lf + 2], lane, hA, hA, hB, &rgb_tile);
     if (h == 0 && s < total)
-      *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(rgb_tile[0], rgb_tile[1], rgb_tile[2], alpha_tile[0]);
+      store_raw(a, s, rgb_tile[0], rgb_tile[1], rgb_tile[2], alpha_tile[0]);
   }
 }
 
@@ -232,12 +233,13 @@ __device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], 
   constexpr bool SPREAD = tune::kGenericSpread != 0 && (tune::kGenericSpread >= 2 || O >= 64);      // O = W / 4 (+ 8): 1 = width 256 only
   constexpr int QUADS = 4 * NB, QPS = (QUADS + KS - 1) / KS;      // quads of the previous tile converted per k-step
   f32x16 accs[SPREAD ? 2 : 1][NB];
-  auto convert_quad = [&](f32x16 (&ac)[NB], int mm, int q) {
+  int guards[SPREAD ? 2 : 1][NB];      // mfma_guard of each finished accumulator (k_mlp16.hip.hpp): set behind a tile's last k-step
+  auto convert_quad = [&](f32x16 (&ac)[NB], int (&gd)[NB], int mm, int q) {
     const int nb = q >> 2, g = q & 3;
     if (KEEP_F32_TILE == mm) {
       if (g == 0) keep[nb] = ac[nb];
     } else {
-      epilogue_quad_16<ET, RELU>(ac[nb], mm, g, out + nb * O);
+      epilogue_quad_16<ET, RELU>(ac[nb], mm, g, out + nb * O, gd[nb]);
     }
   };
 #pragma unroll
@@ -245,6 +247,8 @@ __device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], 
     const bool last = m == MT - 1;
     f32x16 (&acc)[NB] = accs[SPREAD ? (m & 1) : 0];
     f32x16 (&pacc)[NB] = accs[SPREAD ? ((m & 1) ^ 1) : 0];
+    int (&gacc)[NB] = guards[SPREAD ? (m & 1) : 0];
+    int (&gpacc)[NB] = guards[SPREAD ? ((m & 1) ^ 1) : 0];
     const uint32_t rd = ts_next<BUF_BYTES>(st, last ? next_off : w_off + (m + 1) * KS * 64, last ? next_frags : KS);
     u32x4 fr[D];
 #pragma unroll
@@ -253,7 +257,7 @@ __device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], 
       __builtin_amdgcn_sched_barrier(0);
       if (m > 0) {
 #pragma unroll
-        for (int q = 0; q < QUADS; ++q) convert_quad(acc, m - 1, q);
+        for (int q = 0; q < QUADS; ++q) convert_quad(acc, gacc, m - 1, q);
       }
     }
     if (LDSB && tune::kGenericBiasDirect && !(tune::kAblateGeneric & 2)) {
@@ -292,14 +296,22 @@ __device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], 
         acc[nb] = ET::mfma(a, b, acc[nb]);
       }
       if (SPREAD && m > 0) {
+        if (s == 0 && KEEP_F32_TILE != m - 1) {      // the previous tile's guards, a k-step behind its last MFMAs: no wait states
 #pragma unroll
-        for (int q = s * QPS; q < (s + 1) * QPS && q < QUADS; ++q) convert_quad(pacc, m - 1, q);
+          for (int nb = 0; nb < NB; ++nb) gpacc[nb] = mfma_guard<ET, RELU>(pacc[nb]);
+        }
+#pragma unroll
+        for (int q = s * QPS; q < (s + 1) * QPS && q < QUADS; ++q) convert_quad(pacc, gpacc, m - 1, q);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (KEEP_F32_TILE != m && (last || !SPREAD)) {      // converted right here (or, deferred, behind the next tile's barrier)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) gacc[nb] = mfma_guard<ET, RELU>(acc[nb]);
+    }
     if (last || !(SPREAD || tune::kGenericDefer)) {
 #pragma unroll
-      for (int q = 0; q < QUADS; ++q) convert_quad(acc, m, q);
+      for (int q = 0; q < QUADS; ++q) convert_quad(acc, gacc, m, q);
     }
   }
 }
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(256, OCC) void shade_mlp16_gen_staged_kernel(ShadeA
     for (int nb = 0; nb < NB; ++nb) {
       const int s = tile * TILE + (wave * NB + nb) * 32 + j;
       if (h == 0 && s < total)
-        *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(rgb_tile[nb][0], rgb_tile[nb][1], rgb_tile[nb][2], alpha_tile[nb][0]);
+        store_raw(a, s, rgb_tile[nb][0], rgb_tile[nb][1], rgb_tile[nb][2], alpha_tile[nb][0]);
     }
   }
   // no LDS-DMA may outlive the workgroup's LDS allocation.  (Nothing is in flight here -- the last pass issues no copy for a next one and

@@ -24,7 +24,19 @@ struct ShadeArgs {
   float* raw_out;             // [S,4]
 };
 
+// one sample's raw outputs, back in the network's own scale (NetParams::out_scale: 1, or the exact power of two the bf16 packing took out)
+__device__ __forceinline__ void store_raw(const ShadeArgs& a, int s, float r, float g, float b, float alpha) {
+  const float ks = a.net.out_scale[1];
+  *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(r * ks, g * ks, b * ks, alpha * a.net.out_scale[0]);
+}
+
+// kClampRelu: ReLU + conversion of a pair is ONE instruction, `v_cvt_pk_bf16_f32 ... clamp` (clamps to [0, 1]; gfx950 honours the modifier on
+// this conversion: tools/probes/cvt_clamp_probe.hip), instead of v_cvt_pk + v_pk_max_i16.  Legal because the bf16 packing scales every layer by
+// a power of two chosen from a rigorous bound on its activations, so that nothing a ReLU layer can produce exceeds 1 (pack.cpp scale_layer);
+// powers of two commute with every rounding on the way, so the un-scaled outputs are those of the unscaled network bit for bit.  fp16 has no
+// range for this.  Measured: 8 x 256 shading kernel -1.8 %, 5 x 256 -5.7 %, 6 x 128 -2 %, 4 x 64 -3.3 % (profiles/r05_lab_log.md 1).
 struct Bf16 {
+  static constexpr bool kClampRelu = true;
   typedef bf16x8 vec8;
   static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
     f32x2 v = {lo, hi};
@@ -35,6 +47,7 @@ struct Bf16 {
   }
 };
 struct Fp16 {
+  static constexpr bool kClampRelu = false;
   typedef f16x8 vec8;
   static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
     f32x2 v = {lo, hi};
@@ -273,8 +286,28 @@ __device__ __forceinline__ void lds_bias16(uint32_t byte_addr, f32x16* acc) {
 // KEEP_F32_TILE >= 0: that tile's raw accumulator is returned in *keep instead (alpha / rgb rows);
 // kKeepAllF32: all of them, in keep[0 .. MT-1] (the sampling net's 128 raw outputs).
 // epilogue of one accumulator quad g (values 4g..4g+3 of tile m): convert, ReLU on the packed pairs
+// The clamped conversion has no compiler-visible form (hipcc folds a clamp into VOP3 arithmetic, not into this conversion), so it is inline
+// asm -- and the hazard recogniser does not look inside inline asm: it inserts NO wait states between an MFMA and an asm statement that reads
+// the MFMA's result (checked on the ISA: `s_nop 11` in front of a plain v_cvt_pk, nothing in front of the asm; the first version of this read
+// accumulator rows the last MFMA had not written yet).  mfma_guard: one compiler-visible VALU read of the finished accumulator
+// (v_readfirstlane: the recogniser pads THAT as the MFMA -> VALU rule requires); every asm conversion of the tile takes its result as an
+// operand, so none can be scheduled in front of it.  One guard per 16 values.
 template <class ET, bool RELU>
-__device__ __forceinline__ void epilogue_quad_16(const f32x16& acc, int m, int g, uint32_t* out) {
+__device__ __forceinline__ int mfma_guard(const f32x16& acc) {
+  if constexpr (RELU && ET::kClampRelu) return __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[15]));
+  else return 0;
+}
+
+template <class ET, bool RELU>
+__device__ __forceinline__ void epilogue_quad_16(const f32x16& acc, int m, int g, uint32_t* out, int guard = 0) {
+  if constexpr (RELU && ET::kClampRelu) {
+    uint32_t q0, q1;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2 clamp\n\t; after the accumulator's guard %3" : "=v"(q0) : "v"(acc[4 * g + 0]), "v"(acc[4 * g + 1]), "s"(guard));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2 clamp\n\t; after the accumulator's guard %3" : "=v"(q1) : "v"(acc[4 * g + 2]), "v"(acc[4 * g + 3]), "s"(guard));
+    out[8 * m + 2 * g + 0] = q0;
+    out[8 * m + 2 * g + 1] = q1;
+    return;
+  }
   // convert first, then ReLU on the packed pair: max(int16, 0) clears every negative bf16/f16
   // (one v_cvt_pk + one v_pk_max_i16 per two values)
   uint32_t p0 = ET::pack(acc[4 * g + 0], acc[4 * g + 1]), p1 = ET::pack(acc[4 * g + 2], acc[4 * g + 3]);
@@ -334,8 +367,9 @@ __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, c
 #pragma unroll
       for (int g = 0; g < 8; ++g) asm volatile("" : "=v"(out[8 * m + g]));
     } else {
+      const int gd = mfma_guard<ET, RELU>(acc);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(acc, m, g, out);
+      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(acc, m, g, out, gd);
     }
   }
 }
@@ -470,7 +504,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
     if constexpr (tune::kHandSched) ws_settle(st);
 #endif
     if (h == 0 && s < total)
-      *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s) * 4) = make_float4(rgb_tile[0], rgb_tile[1], rgb_tile[2], alpha);
+      store_raw(a, s, rgb_tile[0], rgb_tile[1], rgb_tile[2], alpha);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }
@@ -494,6 +528,7 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
   constexpr int kYounger = (ABL & 2) ? 0 : (tune::kBiasWaitCounted ? KS : 0);
   BiasRegs br;
   f32x16 pA, pB;
+  int gA = 0, gB = 0;      // mfma_guard of the tile whose conversions are pending
   if (!(ABL & 4) && !tune::kBiasPlain) lds_bias_issue(bias_addr, br);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -527,11 +562,15 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
       accB = ET::mfma(st.R[f % WS::kRegs], bb, s == 0 ? bias : accB);
       ws_refill<ABL>(st, f);
       if (m > 0 && KEEP_F32_TILE != m - 1 && !(ABL & 8)) {
+        if (s == 0) {      // the previous tile's guards, taken HERE: its last MFMAs are a k-step behind, so the read costs no wait states
+          gA = mfma_guard<ET, RELU>(pA);
+          gB = mfma_guard<ET, RELU>(pB);
+        }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
           const int q = s * PER + k;
-          if (q < 4) epilogue_quad_16<ET, RELU>(pA, m - 1, q, outA);
-          else if (q < 8) epilogue_quad_16<ET, RELU>(pB, m - 1, q - 4, outB);
+          if (q < 4) epilogue_quad_16<ET, RELU>(pA, m - 1, q, outA, gA);
+          else if (q < 8) epilogue_quad_16<ET, RELU>(pB, m - 1, q - 4, outB, gB);
         }
       }
       if (tune::kSchedGroups) {
@@ -556,10 +595,12 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
       pA = accA;
       pB = accB;
     } else if (KEEP_F32_TILE != m) {
+      gA = mfma_guard<ET, RELU>(accA);
+      gB = mfma_guard<ET, RELU>(accB);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(accA, m, g, outA);
+      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(accA, m, g, outA, gA);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(accB, m, g, outB);
+      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(accB, m, g, outB, gB);
     }
   }
 }
@@ -636,9 +677,9 @@ __global__ __launch_bounds__(256) void shade_mlp16x2_kernel(ShadeArgs a) {
     f32x16 rgb0, rgb1;
     layer_16x2<ET, WS, 8, 0, 1, false, (32 + 4 * 128 + 160 + 2 * 128 + 144 + 72) % CF, 0>(st, bias0 + bo[10] * 4, hB0, hB0, hB1, hB1, hA0, hA1, &rgb0, &rgb1);
     if (h == 0 && s0 < total)
-      *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s0) * 4) = make_float4(rgb0[0], rgb0[1], rgb0[2], alpha0[0]);
+      store_raw(a, s0, rgb0[0], rgb0[1], rgb0[2], alpha0[0]);
     if (h == 0 && s1 < total)
-      *reinterpret_cast<float4*>(a.raw_out + static_cast<size_t>(s1) * 4) = make_float4(rgb1[0], rgb1[1], rgb1[2], alpha1[0]);
+      store_raw(a, s1, rgb1[0], rgb1[1], rgb1[2], alpha1[0]);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
 }

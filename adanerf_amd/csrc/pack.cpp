@@ -1,5 +1,6 @@
 #include "pack.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -127,6 +128,43 @@ void add_act_slots(VLayer* L, int n_features, int col_base, int n_real = -1) {
 // is relu(0) = 0 (the feature layer has no activation: 0 as well) and feeds zero columns -- the results are those of the W-wide network
 // bit for bit in fp32, and to the engine's usual accuracy in 16 bits (the extra products are exact zeros).
 int pad_width(int w) { return w <= 64 ? 64 : (w <= 128 ? 128 : (w <= 256 ? 256 : 0)); }
+
+// ---- scaled packing of bf16 shading nets (PackedNet::relu_scaled) --------------------------------------------------------------------
+// Source column c of a layer holds x_c 2^-ce[c] with |x_c| <= cb[c] (true scale).  The layer's outputs are bounded row by row,
+// |y_r| <= sum_c |w_rc| cb[c] + |b_r|, with 2^-5 of slack for the bf16 rounding of the weights and of the inputs and the fp32 summation.
+// choose: the output exponent e becomes the smallest with bound 2^-e <= 1 (ReLU layers: the kernel's clamped conversion must never
+// clamp); else it is given (layers without an activation keep their input's exponent).  Weights and bias are rescaled in place by exact
+// powers of two -- w_rc 2^(ce[c] - e), b_r 2^-e -- so the packed layer computes y 2^-e with the roundings of the unscaled one.
+double scale_layer(VLayer* L, const std::vector<double>& cb, const std::vector<int>& ce, bool choose, int* e) {
+  double bound = 0.0;
+  for (int r = 0; r < L->rows; ++r) {
+    double s = std::fabs(static_cast<double>(L->b[r]));
+    for (int c = 0; c < L->cols; ++c) s += std::fabs(static_cast<double>(L->w[static_cast<size_t>(r) * L->cols + c])) * cb[c];
+    bound = std::max(bound, s);
+  }
+  bound *= 1.03125;
+  if (choose) {
+    *e = bound > 0.0 ? static_cast<int>(std::ceil(std::log2(bound))) : 0;
+    if (*e > 100) *e = 100;      // (a network whose bound leaves the fp32 range has no finite outputs to protect)
+    if (*e < -100) *e = -100;
+  }
+  for (int r = 0; r < L->rows; ++r) {
+    L->b[r] = std::ldexp(L->b[r], -*e);
+    for (int c = 0; c < L->cols; ++c) {
+      float& w = L->w[static_cast<size_t>(r) * L->cols + c];
+      w = std::ldexp(w, ce[c] - *e);
+    }
+  }
+  return bound;
+}
+
+// bounds / exponents of the source columns of an encoding: 3 identity columns, then sin / cos
+void pe_col_scale(int n_cols, double identity_bound, std::vector<double>* cb, std::vector<int>* ce) {
+  for (int c = 0; c < n_cols; ++c) {
+    cb->push_back(c < 3 ? identity_bound : 1.0);
+    ce->push_back(0);
+  }
+}
 
 void emit(const VLayer& L, Elem elem, PackedNet* out) {
   const int G = (elem == Elem::F32) ? 4 : 8;          // slots per 16-byte fragment element group
@@ -273,6 +311,11 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
   T.real_width = Wr;
   if (Wr < 2 || T.width == 0) return fail(err, "shading net: width " + std::to_string(Wr) + " (2 .. 256 supported)");
   const int Wd = T.width, Wh = Wr / 2;      // views_linears.0 has W // 2 rows (src/models.py:236)
+  // bf16: scaled packing (scale_layer) -- h_bound / h_exp describe the trunk's current activations
+  const bool scaled = elem == Elem::BF16;
+  out->relu_scaled = scaled;
+  double h_bound = 0.0, f_bound = 0.0, v_bound = 0.0;
+  int h_exp = 0, v_exp = 0;
   T.skip = -1;
   for (int i = 1; i < T.depth; ++i) {
     const Tensor* W = find(net1, "pts_linears." + std::to_string(i) + ".weight", err);
@@ -304,6 +347,16 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
     } else {
       add_act_slots(&L, Wd, 0, Wr);
     }
+    if (scaled) {
+      std::vector<double> cb;
+      std::vector<int> ce;
+      if (i == 0 || cat) pe_col_scale(n_pos, kPosIdentityBound, &cb, &ce);
+      if (i > 0) {
+        cb.insert(cb.end(), Wr, h_bound);
+        ce.insert(ce.end(), Wr, h_exp);
+      }
+      h_bound = scale_layer(&L, cb, ce, true, &h_exp);
+    }
     emit(L, elem, out);
   }
   {   // feature_linear rows 0..W-1, alpha_linear as row W (tile W/32, row 0)
@@ -321,6 +374,13 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
     }
     if (!set_rows(&L, Wd, WA, BA, Wr, err, "alpha_linear")) return false;      // the alpha row sits behind the PADDED feature rows
     add_act_slots(&L, Wd, 0, Wr);
+    if (scaled) {      // no activation: the layer keeps its input's exponent; alpha leaves the kernel times 2^h_exp
+      const std::vector<double> cb(Wr, h_bound);
+      const std::vector<int> ce(Wr, h_exp);
+      int e = h_exp;
+      f_bound = scale_layer(&L, cb, ce, false, &e);
+      out->out_exp[0] = h_exp;
+    }
     emit(L, elem, out);
   }
   {   // views_linears.0 on cat([feature, input_views])  (src/models.py:266-270)
@@ -336,6 +396,12 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
     if (!set_rows(&L, 0, W, B, Wr + n_dir, err, "views_linears.0")) return false;
     add_act_slots(&L, Wd, 0, Wr);
     add_pe_slots(&L, sh.fd1, Wr, sh.ld1);
+    if (scaled) {      // cat([feature (the trunk's exponent), dir encoding (unscaled)]) -> ReLU
+      std::vector<double> cb(Wr, f_bound);
+      std::vector<int> ce(Wr, h_exp);
+      pe_col_scale(n_dir, kDirIdentityBound, &cb, &ce);
+      v_bound = scale_layer(&L, cb, ce, true, &v_exp);
+    }
     emit(L, elem, out);
   }
   {   // rgb_linear W/2 -> 3 (tile 0 rows 0..2)
@@ -350,6 +416,13 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
     init_layer(&L, 32, Wh);
     if (!set_rows(&L, 0, W, B, Wh, err, "rgb_linear")) return false;
     add_act_slots(&L, Wd / 2, 0, Wh);
+    if (scaled) {      // no activation: rgb leaves the kernel times 2^v_exp
+      const std::vector<double> cb(Wh, v_bound);
+      const std::vector<int> ce(Wh, v_exp);
+      int e = v_exp;
+      scale_layer(&L, cb, ce, false, &e);
+      out->out_exp[1] = v_exp;
+    }
     emit(L, elem, out);
   }
   return true;

@@ -43,7 +43,18 @@ struct PackedNet {
   std::vector<int> mtiles;           // per layer: 32-row output tiles
   NetTopology topo;
   uint32_t rsi_w_off = 0;            // fp32, ray_samples > 0: 16-byte offset of layer 0's raySampleInput fragments, [a][s4][m][lane][4]
+  // bf16 shading nets are packed SCALED (pack.cpp scale_layer): every ReLU layer's weights and bias carry a power of two chosen so that no
+  // activation can exceed 1 -- the 16-bit kernels then do ReLU + conversion with one clamped v_cvt_pk_bf16_f32 (k_mlp16.hip.hpp Bf16).
+  // out_exp: the packed network's alpha / rgb outputs x 2^out_exp = the network's own (NetParams::out_scale).
+  bool relu_scaled = false;
+  int out_exp[2] = {0, 0};
 };
+
+// |value| bounds the scaled packing assumes for the identity slots of the two encodings (everything else in them is a sin / cos): sample
+// positions after the config's normalisation, and ray directions (unit vectors).  Generous on purpose -- a power of two here only moves
+// exponents: 2^12 for positions (InverseSqrtDistCentered keeps them below ~1.5; un-normalised scenes are world coordinates), 4 for directions.
+constexpr double kPosIdentityBound = 4096.0;
+constexpr double kDirIdentityBound = 4.0;
 
 struct NetShape {
   int fp0 = 10, fd0 = 4;   // posEncArgs[0]  (oracle net input encoding)

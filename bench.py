@@ -400,6 +400,12 @@ def main():
                 data_pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180), device_id=torch.device("cuda", local_rank))
             except Exception as e:      # noqa: BLE001 -- anything RCCL raises here is reported, not fatal
                 xerrors.append("new_group(nccl): %s: %s" % (type(e).__name__, str(e)[:300]))
+            # a communicator that came up on some ranks only is of no use to anybody: every rank keeps it, or none does
+            have = torch.tensor([1 if data_pg is not None else 0], dtype=torch.int32)
+            dist.all_reduce(have, op=dist.ReduceOp.MIN)
+            if not bool(have.item()) and data_pg is not None:
+                xerrors.append("new_group(nccl): failed on another rank")
+                data_pg = None
     if rank == 0:
         B.build_library()
     if dist:

@@ -474,7 +474,10 @@ int adanerf_host_parse_model(const char* model_dir, const adanerf_options* opt, 
  *   bias_out     packed bias blocks, fp32        (*bias_floats)
  *   layer_out    per layer {w_off (16-B units), b_off (floats), slots per lane-half, 32-row tiles}
  *                as int32[4] each                (*n_layers); a sampling net with raySampleInput = A > 0 has one more
- *                record {w_off of layer 0's K-major block for the A extra points, A, slots per point, tiles}.
+ *                record {w_off of layer 0's K-major block for the A extra points, A, slots per point, tiles}; a shading net in
+ *                ADANERF_PREC_BF16 has one more record {alpha exponent, rgb exponent, 0, -1}: it is packed SCALED (every ReLU
+ *                layer's weights and bias carry a power of two that keeps its activations <= 1, so the kernels' ReLU is a clamped
+ *                conversion), and its alpha / rgb outputs x 2^exponent are the network's own.
  * The shading net packs in every precision for every topology.  A sampling net other than 8 x 256 with a 10-4 / 2-2 encoding
  * packs for ADANERF_PREC_FP32 (run-time-shaped fp32 kernel) and, without raySampleInput, as split pairs (3: run-time-shaped
  * split-precision kernel); the plain 16-bit precisions -- and the split pairs with raySampleInput -- return ADANERF_EIO with a message. */

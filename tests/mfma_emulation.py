@@ -71,6 +71,17 @@ class PackedNet:
     def __init__(self, w, b, lay, precision):
         self.w, self.b, self.lay, self.precision = w, b, lay, precision
         self.G = 4 if precision == 2 else 8
+        # a bf16 shading net is packed SCALED (pack.cpp scale_layer): one more record {alpha exponent, rgb exponent, 0, -1}; every ReLU
+        # layer's outputs must then stay <= 1 -- the kernels' clamped conversion would cut them off (checked in layer())
+        self.scaled = lay.shape[0] > 0 and int(lay[-1][3]) == -1
+        self.out_exp = (int(lay[-1][0]), int(lay[-1][1])) if self.scaled else (0, 0)
+        if self.scaled:
+            self.lay = lay[:-1]
+        self.max_relu_out = 0.0
+
+    def unscale(self, rgb_rows, alpha):
+        """the kernels' store_raw: outputs back in the network's own scale (exact powers of two)"""
+        return [np.ldexp(r, self.out_exp[1]).astype(np.float32) for r in rgb_rows], np.ldexp(alpha, self.out_exp[0]).astype(np.float32)
 
     def layer_split(self, l, act, relu):
         """precision 3: (hi, lo') fragment pairs; W.x = Whi.xhi + (Whi.xlo' + Wlo'.xhi) / 2048"""
@@ -123,6 +134,9 @@ class PackedNet:
                     out[hh, 16 * m + r] = D[row] + bias[m, hh, r]
         if relu:
             out = np.maximum(out, 0)
+            if self.scaled:
+                self.max_relu_out = max(self.max_relu_out, float(out.max()))
+                assert out.max() <= 1.0, "a scaled ReLU layer exceeds 1: the kernels' clamped conversion would cut it off"
         return out
 
 
@@ -154,7 +168,8 @@ def run_shading_net(net: PackedNet, x, dpe, fp=10, fd=4):
     alpha = f[0, 128]
     v = net.layer(9, np.concatenate([f[:, :128], dirs], axis=1), True)
     rgb = net.layer(10, v, False)           # rows 0..2 -> half 0, slots 0..2
-    return np.stack([rgb[0, 0], rgb[0, 1], rgb[0, 2], alpha], axis=1)
+    (r, g, b), alpha = net.unscale([rgb[0, 0], rgb[0, 1], rgb[0, 2]], alpha)
+    return np.stack([r, g, b, alpha], axis=1)
 
 
 # ---- any topology, fp32 fragments (the run-time-shaped kernels of k_generic_f32.hip.hpp) -------------------
@@ -212,4 +227,5 @@ def run_shading_net_generic(net: PackedNet, x, dpe, depth, width, skip, fp=10, f
     alpha = f[0, width // 2]
     v = net.layer(depth + 1, np.concatenate([f[:, :width // 2], dirs], axis=1), True)
     rgb = net.layer(depth + 2, v, False)
-    return np.stack([rgb[0, 0], rgb[0, 1], rgb[0, 2], alpha], axis=1)
+    (r, g, b), alpha = net.unscale([rgb[0, 0], rgb[0, 1], rgb[0, 2]], alpha)
+    return np.stack([r, g, b, alpha], axis=1)
