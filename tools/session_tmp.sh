@@ -1,9 +1,15 @@
 #!/bin/bash
+# round 5 final measurement session (sources = HEAD)
 cd "$(dirname "$0")/.."
-O=gpurun_out/r05_s11; mkdir -p $O
-ADANERF_LIB_A=$PWD/tools/ablate_libs/base.so timeout 600 python tools/probes/compare_libs.py > $O/compare_libs_clamp.log 2>&1; grep -c "identical True, raw shading outputs identical True" $O/compare_libs_clamp.log; grep -c "False" $O/compare_libs_clamp.log
-for i in 1 2; do for v in base shipped; do
-  L=$PWD/tools/ablate_libs/base.so; [ $v = shipped ] && L=$PWD/adanerf_amd/lib/libadanerf_hip.so
-  for wl in config2 generic_5x256 generic_6x128 generic_4x64; do ADANERF_LIB=$L timeout 200 python bench.py --workload $wl --steps 20 --no-cpu-baseline --no-speed-mode --no-split-mode --no-guarded-mode --no-sustained-probe 2>/dev/null | python -c "
-import json,sys
-r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v $wl', round(r['value'],1), {k: round(x,3) for k,x in r['stage_ms_per_frame'].items()}, round(r['roofline']['frac'],4))"; done; done; done | tee $O/clamp_ab.log
+export ROUND=r05
+rm -rf gpurun_out/prof_r05_* gpurun_out/r05_bench_all
+O=gpurun_out/r05_final2; mkdir -p $O
+ADANERF_MEASURED_LOG=$PWD/$O/parity_measured.log timeout 1500 python -m pytest tests -q -x -m gpu 2>&1 | tail -6 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
+timeout 300 python __graft_entry__.py smoke 2>&1 | tail -4 > $O/smoke.log; cat $O/smoke.log
+bash tools/collect_all_profiles.sh > $O/collect.log 2>&1
+bash tools/bench_all.sh > $O/bench_all.log 2>&1; cat $O/bench_all.log
+timeout 300 python tools/probes/split_shares.py config2 8 1,2 > $O/split_shares_config2.log 2>&1; tail -2 $O/split_shares_config2.log
+timeout 300 python tools/probes/split_shares.py config4 8 1,2 > $O/split_shares_config4.log 2>&1; tail -2 $O/split_shares_config4.log
+( for smp in split guarded; do timeout 200 python tools/probes/multi_context_stress.py 320 200 3 200 $smp; done; timeout 200 python tools/probes/dense_shard_repro.py 2>&1 | tail -3 ) > $O/multi_context_stress.log 2>&1; cat $O/multi_context_stress.log
+timeout 900 python tests/fuzz_parity.py 150 30303 > $O/fuzz_150_seed30303.log 2>&1; tail -1 $O/fuzz_150_seed30303.log; grep FAIL $O/fuzz_150_seed30303.log | head -3
+du -sh gpurun_out/prof_r05_* $O
