@@ -867,18 +867,20 @@ def main():
                 for _ in range(args.warmup):
                     r4.render(out4, None)
                 r4.sync()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    r4.render(out4, None)
-                r4.sync()
-                dt4g = time.perf_counter() - t1
+                dt4g = None
+                for _ in range(3):      # three short passes, the fastest counts: a side measurement of 30 frames is at the mercy of one hiccup
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        r4.render(out4, None)
+                    r4.sync()
+                    dt4g = min(dt4g or 1e30, time.perf_counter() - t1)
                 st4 = r4.render(out4, None, stats=True)
                 r4.lib.adanerf_get_info(r4.handle, r4.info)
                 cnt4 = r4.buffer(3, np.int32, (w * h,)) if r4.info.batch_rays >= w * h else None
                 cnt1 = r.buffer(3, np.int32, (w * h,)) if (cnt4 is not None and not poses) else None
                 g_fps = args.steps / dt4g
                 guarded = {"sampling": "guarded two-precision (ADANERF_SAMPLING_GUARDED): plain fp16 on every ray, split-fp16 on the rays inside the audited band",
-                           "value": g_fps, "unit": "frames/s", "ahead_of_the_headline": g_fps / fps - 1.0,
+                           "value": g_fps, "unit": "frames/s", "passes": "fastest of 3 x %d frames" % args.steps, "ahead_of_the_headline": g_fps / fps - 1.0,
                            "default_rule": "the default is the mode that is exact by construction unless this mode is >= 8 %% ahead of it here: %s" %
                                            ("it is -- reconsider the default" if g_fps / fps - 1.0 >= 0.08 else "it is not"),
                            "sample_mlp_ms": st4.ms_sample_mlp, "rays_refined": int(st4.rays_refined), "samples_per_frame": int(st4.total_samples),
