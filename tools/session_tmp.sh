@@ -1,9 +1,4 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-O=gpurun_out/r05_final4; mkdir -p $O
-timeout 300 python tools/probes/pass_variance.py 2>&1 | tail -5 | tee $O/pass_variance.log
-timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; python - <<'PY'
-import json
-r=json.loads(open("gpurun_out/r05_final4/bench_default.json").read().strip().splitlines()[-1])
-print(r["value"], r["stage_ms_per_frame"], r["roofline"]["frac"], r["roofline"]["traffic"], r["guarded_mode"]["value"], r["guarded_mode"]["ahead_of_the_headline"], r["speed_mode"]["value"], r["split_frame_mode"]["value"], r["cpu_baseline"]["value"])
-PY
+O=gpurun_out/r05_s16; mkdir -p $O
+for wl in generic_4x64 generic_6x128; do echo "== $wl"; for i in 1 2; do STEPS=20 BENCH_ARGS="--workload $wl --no-speed-mode --no-split-mode --no-sustained-probe --no-exact-mode --no-guarded-mode" bash tools/run_variants.sh; done; done | tee $O/variants.log
