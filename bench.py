@@ -501,9 +501,16 @@ def main():
             image = images[0]
     state = {"k": 0, "pending": None, "gathers": 0, "last": 0, "exchange": True, "mode": xmode}
 
+    # test hooks (tests/test_gpu_parity.py; never set by the driver): modes listed in ADANERF_BENCH_FAIL_MODES raise like a refusing RCCL would;
+    # the rank named by ADANERF_BENCH_HANG_RANK stops for good in front of the timed phase, like a collective that never returns
+    fail_modes = set(filter(None, os.environ.get("ADANERF_BENCH_FAIL_MODES", "").split(",")))
+    hang_rank = int(os.environ.get("ADANERF_BENCH_HANG_RANK", "-1"))
+
     def exchange(b):
         """frame in buffer b: payloads of all ranks -> gathered[b] on rank 0 (enqueued on the current stream = cstream)"""
         mode = state["mode"]
+        if mode in fail_modes:
+            raise RuntimeError("exchange mode %s refused (ADANERF_BENCH_FAIL_MODES)" % mode)
         if mode == "gather":
             dist.gather(outs[b], gather_lists[b], dst=0, group=data_pg)
         elif mode == "all_gather":
@@ -631,6 +638,8 @@ def main():
             state["mode"] = nxt
 
     dog.phase = "warm-up"
+    if use_dist and rank == hang_rank:
+        time.sleep(1e6)
     for _ in range(args.warmup):
         step()
     flush()

@@ -1533,6 +1533,40 @@ def test_bench_plain_python_launches_itself(tmp_path):
     assert np.array_equal(np.load(two), np.load(peer))
 
 
+@pytest.mark.gpu
+def test_bench_survives_a_refusing_and_a_hanging_exchange(tmp_path):
+    """What the first hardware N > 1 run can hit, forced here on one GPU (two ranks over gloo): (1) an exchange mode that raises on every rank
+    is dropped for the next one, agreed over the control plane -- the line names the mode that ran and the errors, the frame is still the
+    single-GPU frame; (2) a rank that never reaches the timed phase: the watchdog makes rank 0 print the render-only fall-back line, flagged,
+    and the launcher returns 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ, ADANERF_BENCH_DIST_BACKEND="gloo", ADANERF_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        base.pop(k, None)
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    a = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--dump-image", one, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-speed-mode",
+                        "--no-guarded-mode", "--no-split-mode", "--no-sustained-probe"], cwd=root, env=base, capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-alternatives", "--dump-image", two], cwd=root,
+                       env=dict(base, ADANERF_BENCH_FAIL_MODES="gather"), capture_output=True, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-3000:]
+    rec = json.loads([ln for ln in b.stdout.splitlines() if ln.startswith("{")][-1])
+    x = rec["config"]["exchange"]
+    assert x["mode"] == "gloo_staged" and len(x["errors"]) == 1 and "gather" in x["errors"][0] and x["error"] is None and rec["value"] > 0
+    assert np.array_equal(np.load(one), np.load(two))
+    c = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-alternatives", "--watchdog", "45"], cwd=root,
+                       env=dict(base, ADANERF_BENCH_HANG_RANK="1"), capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in c.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, c.stdout + c.stderr[-2000:]
+    rec = json.loads(lines[0])
+    x = rec["config"]["exchange"]
+    assert rec["value"] > 0 and x["value_excludes_the_exchange"] is True and "watchdog" in x["error"] and rec["config"]["render_only"]["value"] == rec["value"]
+    assert c.returncode == 0, c.stderr[-2000:]
+
+
 def r1_guard_ok(g):
     """the bench line's record of the guarded selection: band from a 64-pose calibration, monitor silent, audit ran and is clean"""
     return g["band_source"] in ("record", "calibration") and g["calibration_poses"] == 64 and g["monitor_violations"] == 0 and \
