@@ -34,10 +34,10 @@ __device__ __forceinline__ void split_pack(float v0, float v1, uint32_t* hi, uin
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(d1), "s"(kSplitScale));
     *lo = l;
   } else if (tune::kSplitPack == 1) {
-    const float r0 = (v0 - static_cast<float>(h[0])) * kSplitScale, r1 = (v1 - static_cast<float>(h[1])) * kSplitScale;
-    uint32_t l;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));      // asm: keeps the SLP vectoriser from re-packing the two chains
-    *lo = l;
+    // scalar arithmetic, compiler-visible conversion (the library is built with -fno-slp-vectorize, so nothing re-packs the two chains; no
+    // inline asm between MFMAs and their consumers: the hazard recogniser does not look inside asm -- k_mlp16.hip.hpp mfma_guard)
+    const f32x2 r = {(v0 - static_cast<float>(h[0])) * kSplitScale, (v1 - static_cast<float>(h[1])) * kSplitScale};
+    *lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
   } else {
     f32x2 hf = __builtin_convertvector(h, f32x2);
     f32x2 r = (v - hf) * kSplitScale;

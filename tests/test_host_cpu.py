@@ -156,6 +156,47 @@ def test_device_code_has_no_packed_fp32_valu():
     assert text.count("v_mfma_f32_32x32x16") > 10000      # (the text really is the library's assembly)
 
 
+def test_every_inline_asm_conversion_is_behind_its_accumulators_guard():
+    """hipcc's hazard recogniser inserts no wait states between an MFMA and an INLINE-ASM consumer of its result (it pads compiler-visible VALU
+    only): the clamped bf16 conversion of the 16-bit shading kernels (k_mlp16.hip.hpp epilogue_quad_16) therefore names, as an operand, the SGPR a
+    v_readfirstlane of the same accumulator wrote (mfma_guard) -- a visible VALU read the recogniser does pad.  On the assembly: every
+    `v_cvt_pk_bf16_f32 ... clamp` carries its guard's SGPR in the trailing comment, and walking back from it the instruction that wrote that SGPR
+    last is a v_readfirstlane_b32 of a register of the very accumulator tile (16 consecutive VGPRs written by one MFMA) both sources belong to."""
+    text = _device_assembly()
+    if text is None:
+        pytest.skip("no hipcc")
+    checked = 0
+    for k in re.split(r"\n\s*\.globl\s+", text):
+        if "clamp" not in k:
+            continue
+        lines = k.split("\n")
+        for i, ln in enumerate(lines):
+            m = re.match(r"\s+v_cvt_pk_bf16_f32 v\d+, v(\d+), v(\d+) clamp", ln)
+            if not m:
+                continue
+            g = re.search(r"guard (s\d+)", lines[i + 1]) if i + 1 < len(lines) else None
+            assert g, "clamped conversion without a guard operand: %s" % ln
+            a, b = int(m.group(1)), int(m.group(2))
+            for j in range(i - 1, -1, -1):      # the last write of the guard's SGPR
+                w = re.match(r"\s+(\S+) %s, v(\d+)" % g.group(1), lines[j])
+                if w:
+                    assert w.group(1) == "v_readfirstlane_b32", lines[j]
+                    src = int(w.group(2))
+                    # the MFMA that wrote the guard's source: its 16-register destination must hold both conversion sources
+                    for q in range(j - 1, -1, -1):
+                        mm = re.match(r"\s+v_mfma_\S+ v\[(\d+):(\d+)\]", lines[q])
+                        if mm and int(mm.group(1)) <= src <= int(mm.group(2)):
+                            assert int(mm.group(1)) <= a <= int(mm.group(2)) and int(mm.group(1)) <= b <= int(mm.group(2)), (ln, lines[j], lines[q])
+                            break
+                    else:
+                        raise AssertionError("no MFMA writes the guard's source: %s" % lines[j])
+                    checked += 1
+                    break
+            else:
+                raise AssertionError("the guard's SGPR is never written in front of %s" % ln)
+    assert checked > 1000      # 832 in the 8 x 256 kernel alone
+
+
 def test_abi_handshake(lib):
     """adanerf_abi_version / adanerf_struct_sizes against the ctypes mirrors (load_library refuses a library that disagrees)."""
     sizes = (C.c_int32 * 3)()
