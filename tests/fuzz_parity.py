@@ -37,12 +37,13 @@ def bins_of(r, n_rays, n_max):
     return cnt, bins
 
 
-def selection_fragile(orc, sc, n_max, thr, rng, eps_rel=2e-5, trials=4):
+def selection_fragile(orc, sc, n_max, thr, rng, eps_rel=2e-5, trials=4, rays=None):
     """Conditioning of every ray's SELECTION, measured on the oracle's own sampling-network outputs (the harness
     accepted >= 0.98 identical bin sets without saying which rays may differ).  Two correct fp32-class evaluations of the network differ
     by summation-order noise of a few 1e-6 (numpy / torch sgemm 2.4e-6 against fp64, the split-fp16 engine 1.9e-6 on the shipped weights);
     with raw outputs moved by eps_rel (1 + |value|) the values the sampler looks at (after its sigmoid / softmax) move by at most e_r
-    (measured over `trials` draws, doubled).  A ray is fragile iff, at resolution e_r, (a) one of its n_max largest values is within e_r
+    (measured over `trials` draws, doubled); with ``rays`` = (directions, sphere-exit points, the sampling network) the response to +-2 ulp
+    on the ray's own origin and direction is measured the same way and counts too.  A ray is fragile iff, at resolution e_r, (a) one of its n_max largest values is within e_r
     of the threshold, or (b) its n_max-th and (n_max+1)-th values are within e_r of each other while the latter could be kept, or (c) the
     arg-max fallback applies and its two largest values are within e_r.  Every OTHER ray must come out of the device with exactly the
     oracle's count and bins; fragile rays are excused and counted.  Returns (fragile [R] bool, e_r [R])."""
@@ -51,6 +52,18 @@ def selection_fragile(orc, sc, n_max, thr, rng, eps_rel=2e-5, trials=4):
     for _ in range(trials):
         pert = (orc + rng.standard_normal(orc.shape).astype(np.float32) * np.float32(eps_rel) * (1.0 + np.abs(orc))).astype(np.float32)
         e = np.maximum(e, np.abs(O.oracle_transform(pert, sc.losses0).astype(np.float64) - v0).max(axis=1))
+    if rays is not None:
+        # ... and to the last bits of the ray itself: two correct fp32 evaluations of the sphere exit / the unit direction differ by an ulp
+        # or two, and an encoding with F bands multiplies that by 2^(F-1) in front of the first layer (F = 16: 3e4 x 1e-7 rad) -- the sampling
+        # network re-evaluated with origin and direction moved by +-2 ulp (first seen on 4 of 300 cases of the 12-16-band kinds)
+        nds, p, net0 = rays
+        for _ in range(trials):
+            sg_p = rng.choice(np.array([-2.0, 2.0], np.float32), size=p.shape)
+            sg_d = rng.choice(np.array([-2.0, 2.0], np.float32), size=nds.shape)
+            p2 = (p + sg_p * np.spacing(np.abs(p).astype(np.float32))).astype(np.float32)
+            d2 = (nds + sg_d * np.spacing(np.abs(nds).astype(np.float32))).astype(np.float32)
+            orc2 = O.sampling_mlp(O.oracle_features(d2, p2, sc), net0)
+            e = np.maximum(e, np.abs(O.oracle_transform(orc2, sc.losses0).astype(np.float64) - v0).max(axis=1))
     e = 2.0 * e + 1e-12
     v = -np.sort(-v0, axis=1)
     d = v.shape[1]
@@ -248,7 +261,8 @@ def one_case(rng, idx):
     # (selection_fragile); the others are excused and counted.  No floor on the fraction of identical rays any more.
     n_frag = 0
     if rbins is not None and "orc" in ref and thr > 0.0 and not same.all():
-        frag, _ = selection_fragile(ref["orc"], sc, n_max, thr, np.random.default_rng(3000 + idx))
+        rays_in = (ref["nds"], ref["p"], wts.net0) if ("nds" in ref and "p" in ref) else None
+        frag, _ = selection_fragile(ref["orc"], sc, n_max, thr, np.random.default_rng(3000 + idx), rays=rays_in)
         n_frag = int(frag.sum())
         bad = ~same & ~frag
         if bad.any():
