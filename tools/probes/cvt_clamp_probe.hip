@@ -1,3 +1,6 @@
+// What does the clamp modifier do on v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 on gfx950?  (Round 5: the bf16 shading kernels use it as ReLU + conversion in one
+// instruction, k_mlp16.hip.hpp Bf16::kClampRelu.)  Prints input pairs and the clamped conversions: negative -> 0, above 1 -> 1, in between unchanged.
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/cvt_clamp_probe.hip -o /tmp/cvt_clamp && /tmp/cvt_clamp        (profiles/r05_cvt_clamp_probe.log)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
