@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-O=gpurun_out/r05_final7; mkdir -p $O
-FUZZ_ROUND2=1 FUZZ_ROUND3=1 timeout 1500 python tests/fuzz_parity.py 300 40404 > $O/fuzz_300_seed40404.log 2>&1; tail -1 $O/fuzz_300_seed40404.log; grep FAIL $O/fuzz_300_seed40404.log | cut -c1-260 | head -5; grep -c fragile $O/fuzz_300_seed40404.log
+O=gpurun_out/r05_final8; mkdir -p $O
+ADANERF_MEASURED_LOG=$PWD/$O/parity_measured.log timeout 1500 python -m pytest tests -q -x -m gpu 2>&1 | tail -4 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
