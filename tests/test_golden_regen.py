@@ -11,7 +11,7 @@ import pytest
 
 from conftest import GOLD, ROOT
 
-REGEN = ["classroom_n8_thr02", "ndc_synthetic_n8"]
+REGEN = ["classroom_n8_thr02", "ndc_synthetic_n8", "ray_table_ref"]      # ray_table_ref: the reference's own pixel-ray table (round 5)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference is only present in the build container")
@@ -24,7 +24,7 @@ def test_committed_fixtures_equal_a_fresh_generator_run(tmp_path):
         new, old = np.load(os.path.join(out, name + ".npz")), np.load(os.path.join(GOLD, name + ".npz"))
         assert sorted(new.files) == sorted(old.files), (name, sorted(set(new.files) ^ set(old.files)))
         for k in new.files:
-            if k == "meta":
+            if k == "meta" and name != "ray_table_ref":
                 assert json.loads(bytes(new[k]).decode()) == json.loads(bytes(old[k]).decode()), name
             else:
                 assert new[k].dtype == old[k].dtype and new[k].shape == old[k].shape, (name, k)
