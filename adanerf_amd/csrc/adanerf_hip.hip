@@ -1354,6 +1354,9 @@ int adanerf_host_depth_table(const char* model_dir, const adanerf_options* opt, 
 int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precision, void* weights_out, size_t* weights_bytes,
                               float* bias_out, size_t* bias_floats, int32_t* layer_out, int32_t* n_layers) {
   if (!model_dir || !weights_bytes || !bias_floats || !n_layers) return fail(nullptr, ADANERF_EINVAL, "NULL argument");
+  // precision 4 (shading nets only): bf16 WITHOUT the scaled packing -- for the CPU test that replays both blobs; no kernel consumes it
+  const bool unscaled_bf16 = precision == 4 && net == 1;
+  if (unscaled_bf16) precision = ADANERF_PREC_BF16;
   if (net < 0 || net > 1 || precision < 0 || precision > 3 || (precision == 3 && net != 0))
     return fail(nullptr, ADANERF_EINVAL, "net/precision out of range");
   Config cfg;
@@ -1373,7 +1376,7 @@ int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precis
     const NetShape shc = shape_of(sh.fp0, sh.fd0, sh.fp0, sh.fd0, 0, false);
     ok = pack_shading_net(tm, shc, elem_of(precision), &pn, &err);
   } else {
-    ok = net == 0 ? pack_sampling_net(tm, sh, elem_of(precision), &pn, &err) : pack_shading_net(tm, sh, elem_of(precision), &pn, &err);
+    ok = net == 0 ? pack_sampling_net(tm, sh, elem_of(precision), &pn, &err) : pack_shading_net(tm, sh, elem_of(precision), &pn, &err, !unscaled_bf16);
   }
   if (!ok) return fail(nullptr, ADANERF_EIO, err);
   if (weights_out) {

@@ -299,7 +299,7 @@ bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, Pac
   return true;
 }
 
-bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, PackedNet* out, std::string* err) {
+bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, PackedNet* out, std::string* err, bool scale_bf16) {
   *out = PackedNet();
   out->elem = elem;
   const int n_pos = 3 + 6 * sh.fp1, n_dir = 3 + 6 * sh.fd1;
@@ -312,7 +312,7 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
   if (Wr < 2 || T.width == 0) return fail(err, "shading net: width " + std::to_string(Wr) + " (2 .. 256 supported)");
   const int Wd = T.width, Wh = Wr / 2;      // views_linears.0 has W // 2 rows (src/models.py:236)
   // bf16: scaled packing (scale_layer) -- h_bound / h_exp describe the trunk's current activations
-  const bool scaled = elem == Elem::BF16;
+  const bool scaled = elem == Elem::BF16 && scale_bf16;
   out->relu_scaled = scaled;
   double h_bound = 0.0, f_bound = 0.0, v_bound = 0.0;
   int h_exp = 0, v_exp = 0;

@@ -74,7 +74,8 @@ bool pack_sampling_net(const TensorMap& net0, const NetShape& shape, Elem elem, 
 // pts_linears.{0..D-1}, feature_linear(+alpha_linear as row W), views_linears.0, rgb_linear
 // (src/models.py:199-277).  Layer order in the blob: 0..D-1, feature+alpha, views, rgb.  Any topology (any W <= 256, run zero-padded to
 // 64 / 128 / 256; D in 1..8, skips anywhere) and encoding layout packs for every element type (16-bit: k_generic16.hip.hpp).
-bool pack_shading_net(const TensorMap& net1, const NetShape& shape, Elem elem, PackedNet* out, std::string* err);
+bool pack_shading_net(const TensorMap& net1, const NetShape& shape, Elem elem, PackedNet* out, std::string* err, bool scale_bf16 = true);
+// (scale_bf16 = false: the bf16 blob WITHOUT the per-layer powers of two -- no kernel consumes it; the CPU test replays it next to the scaled one)
 
 uint16_t f32_to_bf16(float f);
 uint16_t f32_to_f16(float f);

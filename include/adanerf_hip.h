@@ -478,6 +478,7 @@ int adanerf_host_parse_model(const char* model_dir, const adanerf_options* opt, 
  *                ADANERF_PREC_BF16 has one more record {alpha exponent, rgb exponent, 0, -1}: it is packed SCALED (every ReLU
  *                layer's weights and bias carry a power of two that keeps its activations <= 1, so the kernels' ReLU is a clamped
  *                conversion), and its alpha / rgb outputs x 2^exponent are the network's own.
+ *                (precision 4, net 1 only: the bf16 blob without that scaling, for tests -- no kernel consumes it.)
  * The shading net packs in every precision for every topology.  A sampling net other than 8 x 256 with a 10-4 / 2-2 encoding
  * packs for ADANERF_PREC_FP32 (run-time-shaped fp32 kernel) and, without raySampleInput, as split pairs (3: run-time-shaped
  * split-precision kernel); the plain 16-bit precisions -- and the split pairs with raySampleInput -- return ADANERF_EIO with a message. */

@@ -1022,3 +1022,37 @@ def test_bf16_scaling_bound_refuses_scenes_beyond_it(lib, tmp_path):
         assert (rc == 0) == ok, (k, rc, lib.adanerf_last_error(None))
         if not ok:
             assert rc == -4 and b"kPosIdentityBound" in lib.adanerf_last_error(None)
+
+
+def test_scaled_bf16_packing_is_exact(lib, tmp_path):
+    """The bf16 shading net is packed with per-layer powers of two (pack.cpp scale_layer) so that the kernels' ReLU is a clamped conversion.
+    Powers of two commute with every rounding of the dataflow: the numpy replay of the scaled blob, un-scaled at its two outputs, equals the
+    replay of the unscaled blob (host hook precision 4) BIT FOR BIT -- for the shipped 8 x 256 network and for run-time-shaped topologies --
+    and no scaled ReLU output exceeds 1 (asserted inside the replay)."""
+    rng = np.random.default_rng(5)
+    z, meta, sc = load_case("classroom_n8_thr02")
+    cases = [(case_weights(meta), "classroom", None)]
+    for seed, layers, widths, skip in ((11, (8, 6), (256, 128), 2), (12, (8, 4), (256, 64), 1), (13, (8, 5), (256, 256), [0, 2])):
+        cases.append((O.synthetic_weights(seed, layers=layers, widths=widths, skip1=skip), "syn%d" % seed, (layers[1], widths[1])))
+    n = 64
+    x = rng.uniform(-1.2, 1.2, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for wts, name, shape in cases:
+        md, _, _ = _model_dir(tmp_path, sc, wts, name="scaled_" + name)
+        ws, bs, ls = pack_weights(lib, md, 1, 0)
+        wu, bu, lu = pack_weights(lib, md, 1, 4)
+        assert int(ls[-1][3]) == -1 and int(lu[-1][3]) != -1 and ws.size == wu.size and not np.array_equal(ws, wu)
+        ns, nu = PackedNet(ws, bs, ls, 0), PackedNet(wu, bu, lu, 0)
+        assert ns.scaled and not nu.scaled
+        if shape is None:
+            a, b = run_shading_net(ns, x, d), run_shading_net(nu, x, d)
+        else:
+            depth, skips = O.shading_topology(wts.net1, 63)
+            a, b = (run_shading_net_generic(q, x, d, depth, pad_to(shape[1]), skips) for q in (ns, nu))
+        assert np.isfinite(a).all() and np.array_equal(a, b), (name, float(np.abs(a - b).max()))
+        assert 0.0 < ns.max_relu_out <= 1.0
+
+
+def pad_to(w):
+    return 64 if w <= 64 else 128 if w <= 128 else 256
