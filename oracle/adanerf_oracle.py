@@ -299,9 +299,9 @@ def synthetic_weights(seed: int, n_in0: int = 90, n_in1_pos: int = 63, n_in1_dir
     rng = np.random.default_rng(seed)
 
     def lin(n_out, n_in, scale=1.0):
-        w = (rng.standard_normal((n_out, n_in)) * math.sqrt(2.0 / n_in) * scale).astype(F32)
+        w = (rng.standard_normal((n_out, n_in)) * math.sqrt(2.0 / n_in) * scale).astype(F32, copy=False)
         bnd = 1.0 / math.sqrt(n_in)
-        b = rng.uniform(-bnd, bnd, size=(n_out,)).astype(F32)
+        b = rng.uniform(-bnd, bnd, size=(n_out,)).astype(F32, copy=False)
         return w, b
 
     n0: Dict[str, np.ndarray] = {}
@@ -310,7 +310,7 @@ def synthetic_weights(seed: int, n_in0: int = 90, n_in1_pos: int = 63, n_in1_dir
     for i in range(d0):
         w, b = lin(dims[i + 1], dims[i], oracle_scale if i == d0 - 1 else 1.0)
         if i == d0 - 1:
-            b = (b + oracle_bias).astype(F32)
+            b = (b + oracle_bias).astype(F32, copy=False)
         n0["layers.%d.weight" % i] = w
         n0["layers.%d.bias" % i] = b
     n1: Dict[str, np.ndarray] = {}
@@ -327,7 +327,7 @@ def synthetic_weights(seed: int, n_in0: int = 90, n_in1_pos: int = 63, n_in1_dir
         n1[nm + ".weight"] = w
         n1[nm + ".bias"] = b
     # classic sigma/delta compositing takes relu(density): shift it so that a random-init net is not transparent everywhere
-    n1["alpha_linear.bias"] = (n1["alpha_linear.bias"] + F32(alpha_bias)).astype(F32)
+    n1["alpha_linear.bias"] = (n1["alpha_linear.bias"] + F32(alpha_bias)).astype(F32, copy=False)
     return Weights(n0, n1)
 
 
@@ -402,25 +402,29 @@ def focal_from_fov(w: int, fov: float) -> float:
     return 0.5 * w / math.tan(0.5 * fov)
 
 
-def generate_ray_directions(w: int, h: int, fov: float, focal: Optional[float] = None) -> np.ndarray:
+def generate_ray_directions(w: int, h: int, fov: float, focal: Optional[float] = None,
+                            rows: Optional[Tuple[int, int]] = None) -> np.ndarray:
     """src/util/raygeneration.py:10-26, float64 then cast to float32 by the dataset
-    (src/datasets.py:190-192).  Row-major [h*w, 3]; ray id = row*w + col."""
+    (src/datasets.py:190-192).  Row-major [h*w, 3]; ray id = row*w + col.  ``rows`` = (first, end): only those image rows (the same
+    element-wise arithmetic, so the values are the full table's; bench.py's CPU baseline renders the frame in slices)."""
     if focal is None:
         focal = focal_from_fov(w, fov)
     x_dist = np.tan(fov / 2) * focal
     y_dist = x_dist * (h / w)
     x_pp = x_dist / (w / 2)
     y_pp = y_dist / (h / 2)
-    col = np.arange(w, dtype=np.float64)[None, :].repeat(h, 0)
-    row = np.arange(h, dtype=np.float64)[:, None].repeat(w, 1)
-    v = np.empty((h, w, 3), dtype=np.float64)
+    r0, r1 = rows if rows is not None else (0, h)
+    n = r1 - r0
+    col = np.arange(w, dtype=np.float64)[None, :].repeat(n, 0)
+    row = np.arange(r0, r1, dtype=np.float64)[:, None].repeat(w, 1)
+    v = np.empty((n, w, 3), dtype=np.float64)
     v[..., 0] = -(x_dist - x_pp / 2) + x_pp * col
     v[..., 1] = -(y_dist - y_pp / 2) + y_pp * row
     v[..., 2] = focal
     v /= np.linalg.norm(v, axis=2)[..., None]
     v[..., 1] *= -1.0
     v[..., 2] *= -1.0
-    return v.reshape(h * w, 3).astype(F32)
+    return v.reshape(n * w, 3).astype(F32, copy=False)
 
 
 def camera_rotation(yaw_deg: float, pitch_deg: float) -> np.ndarray:
@@ -433,7 +437,7 @@ def camera_rotation(yaw_deg: float, pitch_deg: float) -> np.ndarray:
     right = np.cross(fwd, np.array([0.0, 0.0, 1.0]))
     right /= np.linalg.norm(right)
     up = np.cross(right, fwd)
-    return np.stack([right, up, -fwd], axis=1).astype(F32)
+    return np.stack([right, up, -fwd], axis=1).astype(F32, copy=False)
 
 
 # --------------------------------------------------------------------------------------
@@ -447,8 +451,8 @@ def positional_encoding(x: np.ndarray, n_freqs: int) -> np.ndarray:
     parts = [x]
     for k in range(n_freqs):
         f = F32(2.0 ** k)
-        parts.append(np.sin(x * f).astype(F32))
-        parts.append(np.cos(x * f).astype(F32))
+        parts.append(np.sin(x * f).astype(F32, copy=False))
+        parts.append(np.cos(x * f).astype(F32, copy=False))
     return np.concatenate(parts, axis=-1)
 
 
@@ -456,18 +460,18 @@ def world_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: S
     """src/features.py:845-866 (bmm) + compute_ray_offset :769-791.
     Returns (nds [R,3] un-normalised world dirs, p [R,3] sphere-exit points)."""
     rot = rot.astype(F32)
-    nds = (dirs_cam.astype(F32) @ rot.T).astype(F32)            # R * d per ray
+    nds = (dirs_cam.astype(F32) @ rot.T).astype(F32, copy=False)            # R * d per ray
     c = np.array(scene.view_cell_center, dtype=F32)
     o = pose.astype(F32)
-    omc = (o - c).astype(F32)
+    omc = (o - c).astype(F32, copy=False)
     udot = np.sum(omc[None, :] * nds, axis=1, dtype=F32)
     # view_cell_radius is a float64 0-d tensor in the reference; radius**2 promotes the
     # scalar term only (result dtype stays float32 because the other operand is a tensor).
     rad2 = F32(np.float64(scene.radius) ** 2)
-    delta = (udot ** 2 - (np.sum(omc ** 2, dtype=F32) - rad2)).astype(F32)
-    sq = np.sqrt(np.maximum(delta, F32(0))).astype(F32)
-    dist = (-udot + sq).astype(F32)
-    p = (o[None, :] + nds * dist[:, None]).astype(F32)
+    delta = (udot ** 2 - (np.sum(omc ** 2, dtype=F32) - rad2)).astype(F32, copy=False)
+    sq = np.sqrt(np.maximum(delta, F32(0))).astype(F32, copy=False)
+    dist = (-udot + sq).astype(F32, copy=False)
+    p = (o[None, :] + nds * dist[:, None]).astype(F32, copy=False)
     return nds, p
 
 
@@ -476,17 +480,17 @@ def oracle_features(nds: np.ndarray, p: np.ndarray, scene: Scene) -> np.ndarray:
     p + nds * z_a (z_a = to_world of the A bin centres of [0,1]) encoded as PE_pos(x / d1) with the identity part
     scaled back by d1 (d1 = upper end of the warped depth range) -- A * (3 + 6 fp) more columns."""
     fp, fd = scene.pos_enc[0]
-    nrm = np.sqrt(np.sum(nds * nds, axis=-1, keepdims=True, dtype=F32)).astype(F32)
-    cols = [positional_encoding((nds / nrm).astype(F32), fd), positional_encoding(p, fp)]
+    nrm = np.sqrt(np.sum(nds * nds, axis=-1, keepdims=True, dtype=F32)).astype(F32, copy=False)
+    cols = [positional_encoding((nds / nrm).astype(F32, copy=False), fd), positional_encoding(p, fp)]
     a = scene.ray_sample_input
     if a:
         zs = ray_sample_depths(scene)
         d1 = F32(scene.depth_range[1])
-        pts = (p[:, None, :] + nds[:, None, :] * zs[None, :, None]).astype(F32)            # [R, A, 3]
-        enc = positional_encoding((pts / d1).astype(F32), fp)                               # [R, A, 3 + 6 fp]
-        enc[..., :3] = (enc[..., :3] * d1).astype(F32)
+        pts = (p[:, None, :] + nds[:, None, :] * zs[None, :, None]).astype(F32, copy=False)            # [R, A, 3]
+        enc = positional_encoding((pts / d1).astype(F32, copy=False), fp)                               # [R, A, 3 + 6 fp]
+        enc[..., :3] = (enc[..., :3] * d1).astype(F32, copy=False)
         cols.append(enc.reshape(pts.shape[0], -1))
-    return np.concatenate(cols, axis=-1).astype(F32)
+    return np.concatenate(cols, axis=-1).astype(F32, copy=False)
 
 
 def ray_sample_depths(scene: Scene) -> np.ndarray:
@@ -497,8 +501,8 @@ def ray_sample_depths(scene: Scene) -> np.ndarray:
     t = np.linspace(step / 2, 1.0 - step / 2, a, dtype=F32)
     d0, d1 = scene.depth_range
     if scene.depth_transform == "log":
-        return (np.power(F32((d1 - d0) + 1), t).astype(F32) - F32(1.0) + F32(d0)).astype(F32)
-    return (t * F32(d1 - d0) + F32(d0)).astype(F32)
+        return (np.power(F32((d1 - d0) + 1), t).astype(F32, copy=False) - F32(1.0) + F32(d0)).astype(F32, copy=False)
+    return (t * F32(d1 - d0) + F32(d0)).astype(F32, copy=False)
 
 
 # --------------------------------------------------------------------------------------
@@ -524,7 +528,7 @@ def _linear(x, w, b):
         with torch.no_grad():
             y = torch.addmm(torch.from_numpy(b), torch.from_numpy(np.ascontiguousarray(x, dtype=F32)), torch.from_numpy(w).t())
         return y.numpy()
-    return (x @ w.T + b).astype(F32)
+    return (x @ w.T + b).astype(F32, copy=False)
 
 
 def sampling_mlp(x: np.ndarray, net0: Dict[str, np.ndarray]) -> np.ndarray:
@@ -566,7 +570,7 @@ def shading_mlp(x: np.ndarray, net1: Dict[str, np.ndarray], n_pos: int = 63) -> 
     h = np.concatenate([feat, views], axis=-1)
     h = np.maximum(_linear(h, net1["views_linears.0.weight"], net1["views_linears.0.bias"]), F32(0))
     rgb = _linear(h, net1["rgb_linear.weight"], net1["rgb_linear.bias"])
-    return np.concatenate([rgb, alpha], axis=-1).astype(F32)
+    return np.concatenate([rgb, alpha], axis=-1).astype(F32, copy=False)
 
 
 # The two networks with every op in torch (multi-threaded addmm / relu / cat, as the reference's own CPU path runs them):
@@ -650,7 +654,7 @@ def guard_undecided(y: np.ndarray, n_max: int, thr: float, eps: float, transform
     srt = -np.sort(-y, axis=1)
     c0 = srt[:, 0]
     if transform == "softmax":
-        e = (F32(1.01) * F32(np.expm1(2.0 * eps)) * c0).astype(F32)
+        e = (F32(1.01) * F32(np.expm1(2.0 * eps)) * c0).astype(F32, copy=False)
     else:
         e = np.full(len(y), F32(0.25 * eps if transform == "sigmoid" else eps), dtype=F32)
     ep = F32(2) * e
@@ -676,7 +680,7 @@ def guard_pair_error(y: np.ndarray, x: np.ndarray, n_max: int, thr: float, eps: 
     max(v_n - 2 eps, thr - eps) (arg-max fallback: v_1 - 2 eps) up to the cut value; 0 where a row has no such pair.  The sign
     that lets j overtake i: x_j >= x_i needs this to reach y_i - y_j."""
     y = y.astype(F32)
-    d = (y - x.astype(F32)).astype(F32)
+    d = (y - x.astype(F32)).astype(F32, copy=False)
     srt = -np.sort(-y, axis=1)
     c0, tn = srt[:, 0], srt[:, n_max - 1]
     none = c0 < F32(thr)
@@ -687,7 +691,7 @@ def guard_pair_error(y: np.ndarray, x: np.ndarray, n_max: int, thr: float, eps: 
     dk = np.where(kept, d, -np.inf).max(axis=1)
     dn = np.where(cand, d, np.inf).min(axis=1)
     pr = dk - dn
-    return np.where(np.isfinite(pr) & (pr > 0), pr, 0).astype(F32)
+    return np.where(np.isfinite(pr) & (pr > 0), pr, 0).astype(F32, copy=False)
 
 
 def guard_audit_bits(period: int, phase: int, seg: int) -> int:
@@ -741,14 +745,14 @@ def compact(count: np.ndarray, bins: np.ndarray, wts: np.ndarray):
 def bin_t(bins: np.ndarray, n_bins: int = D_BINS) -> np.ndarray:
     """(k + .5) * cell_size with cell_size = 1 / multiDepthFeatures (128 in every shipped config) in float32
     (src/nerf_raymarch_common.py:726-727, 737-741)."""
-    return ((bins.astype(F32) + F32(0.5)) * F32(1.0 / n_bins)).astype(F32)
+    return ((bins.astype(F32) + F32(0.5)) * F32(1.0 / n_bins)).astype(F32, copy=False)
 
 
 def dense_t(scene: Scene, n: int = D_BINS) -> np.ndarray:
     """thr == 0 branch, src/nerf_raymarch_common.py:708-720:
     t = linspace(0,1,n+1)[:-1] + .5/n ; z = near*(1-t) + far*t."""
-    t = (np.linspace(0.0, 1.0, n + 1, dtype=F32)[:-1] + F32(0.5 / n)).astype(F32)
-    return (F32(scene.z_near) * (F32(1.0) - t) + F32(scene.z_far) * t).astype(F32)
+    t = (np.linspace(0.0, 1.0, n + 1, dtype=F32)[:-1] + F32(0.5 / n)).astype(F32, copy=False)
+    return (F32(scene.z_near) * (F32(1.0) - t) + F32(scene.z_far) * t).astype(F32, copy=False)
 
 
 def to_world_depth(t: np.ndarray, scene: Scene) -> np.ndarray:
@@ -761,8 +765,8 @@ def to_world_depth(t: np.ndarray, scene: Scene) -> np.ndarray:
     d0, d1 = scene.depth_range
     if scene.depth_transform == "log":
         max_v = d1 - d0
-        return (np.power(F32(max_v + 1), t).astype(F32) - F32(1.0) + F32(d0)).astype(F32)
-    return (t * F32(d1 - d0) + F32(d0)).astype(F32)
+        return (np.power(F32(max_v + 1), t).astype(F32, copy=False) - F32(1.0) + F32(d0)).astype(F32, copy=False)
+    return (t * F32(d1 - d0) + F32(d0)).astype(F32, copy=False)
 
 
 def from_world_depth(z: np.ndarray, scene: Scene) -> np.ndarray:
@@ -771,10 +775,10 @@ def from_world_depth(z: np.ndarray, scene: Scene) -> np.ndarray:
     z = z.astype(F32)
     d0, d1 = scene.depth_range
     if scene.depth_transform == "log":
-        d = (z - F32(d0)).astype(F32)
+        d = (z - F32(d0)).astype(F32, copy=False)
         d = np.where(d <= 0, F32(0.001), d)
-        return (np.log(d + F32(1.0)) / F32(math.log((d1 - d0) + 1))).astype(F32)
-    return ((z - F32(d0)) / F32(d1 - d0)).astype(F32)
+        return (np.log(d + F32(1.0)) / F32(math.log((d1 - d0) + 1))).astype(F32, copy=False)
+    return ((z - F32(d0)) / F32(d1 - d0)).astype(F32, copy=False)
 
 
 def oracle_transform(orc: np.ndarray, losses0: str) -> np.ndarray:
@@ -787,7 +791,7 @@ def oracle_transform(orc: np.ndarray, losses0: str) -> np.ndarray:
         return sigmoid(orc)
     if losses0 in ("CrossEntropyLoss", "CrossEntropyLossWeighted"):
         e = np.exp(orc - np.max(orc, axis=-1, keepdims=True), dtype=F32)
-        return (e / np.sum(e, axis=-1, keepdims=True, dtype=F32)).astype(F32)
+        return (e / np.sum(e, axis=-1, keepdims=True, dtype=F32)).astype(F32, copy=False)
     return orc
 
 
@@ -796,8 +800,8 @@ def sample_pdf(orc: np.ndarray, n: int, losses0: str = "BCEWithLogitsLoss") -> n
     the transform losses[0] selects (oracle_transform; DONeRF trains with BCEWithLogitsLoss -> sigmoid), then
     nerf_sample_pdf (:160-192) with det=True over the 129 bin edges linspace(0,1,129), n+2 uniform u values, first
     and last dropped.  Returns warped depths t [R,n]."""
-    w = (oracle_transform(orc, losses0) + F32(1e-5)).astype(F32)
-    pdf = (w / np.sum(w, axis=-1, keepdims=True, dtype=F32)).astype(F32)
+    w = (oracle_transform(orc, losses0) + F32(1e-5)).astype(F32, copy=False)
+    pdf = (w / np.sum(w, axis=-1, keepdims=True, dtype=F32)).astype(F32, copy=False)
     cdf = np.cumsum(pdf, axis=-1, dtype=F32)
     cdf = np.concatenate([np.zeros_like(cdf[:, :1]), cdf], axis=-1)          # [R,129]
     bins = np.linspace(0.0, 1.0, orc.shape[1] + 1, dtype=F32)
@@ -809,10 +813,10 @@ def sample_pdf(orc: np.ndarray, n: int, losses0: str = "BCEWithLogitsLoss") -> n
         above = np.minimum(inds, cdf.shape[1] - 1)
         c0 = np.take_along_axis(cdf, below[:, None], 1)[:, 0]
         c1 = np.take_along_axis(cdf, above[:, None], 1)[:, 0]
-        denom = (c1 - c0).astype(F32)
+        denom = (c1 - c0).astype(F32, copy=False)
         denom = np.where(denom < F32(1e-5), F32(1.0), denom)
-        t = ((u[k] - c0) / denom).astype(F32)
-        out[:, k] = (bins[below] + t * (bins[above] - bins[below])).astype(F32)
+        t = ((u[k] - c0) / denom).astype(F32, copy=False)
+        out[:, k] = (bins[below] + t * (bins[above] - bins[below])).astype(F32, copy=False)
     return out[:, 1:-1]
 
 
@@ -820,29 +824,29 @@ def coarse_depths(scene: Scene) -> np.ndarray:
     """LinearlySpacedZNearZFar.generate(det) (src/nerf_raymarch_common.py:310-325): t = linspace(0,1,N+1)[:-1] + 0.5/N,
     near (1-t) + far t with zNear/zFar of net 0, then depth_transform.to_world over the depth range -> [N] world depths."""
     n = scene.num_samples_coarse
-    t = (np.linspace(0.0, 1.0, n + 1, dtype=F32)[:-1] + F32(0.5 / n)).astype(F32)
-    zw = (F32(scene.z_near) * (F32(1.0) - t) + F32(scene.z_far) * t).astype(F32)
+    t = (np.linspace(0.0, 1.0, n + 1, dtype=F32)[:-1] + F32(0.5 / n)).astype(F32, copy=False)
+    zw = (F32(scene.z_near) * (F32(1.0) - t) + F32(scene.z_far) * t).astype(F32, copy=False)
     return to_world_depth(zw, scene)
 
 
 def classic_weights(raw: np.ndarray, z: np.ndarray, rays_d: np.ndarray) -> np.ndarray:
     """The `weights` output of nerf_raw2outputs (src/nerf_raymarch_common.py:33-52): alpha_k T_k, [R,N]."""
     raw = raw.astype(F32)
-    dists = np.concatenate([z[:, 1:] - z[:, :-1], np.full((z.shape[0], 1), 1e10, dtype=F32)], -1).astype(F32)
-    dists = (dists * np.sqrt(np.sum(rays_d * rays_d, -1, keepdims=True, dtype=F32))).astype(F32)
-    alpha = (F32(1.0) - np.exp(-np.maximum(raw[..., 3], F32(0)) * dists, dtype=F32)).astype(F32)
+    dists = np.concatenate([z[:, 1:] - z[:, :-1], np.full((z.shape[0], 1), 1e10, dtype=F32)], -1).astype(F32, copy=False)
+    dists = (dists * np.sqrt(np.sum(rays_d * rays_d, -1, keepdims=True, dtype=F32))).astype(F32, copy=False)
+    alpha = (F32(1.0) - np.exp(-np.maximum(raw[..., 3], F32(0)) * dists, dtype=F32)).astype(F32, copy=False)
     # torch.cumprod / cumsum on CPU accumulate in double (acc_type<float, false>) and store float
     trans = np.cumprod(np.concatenate([np.ones((alpha.shape[0], 1), np.float64), (F32(1.0) - alpha + F32(1e-10)).astype(np.float64)], -1),
                        -1)[:, :-1].astype(F32)
-    return (alpha * trans).astype(F32)
+    return (alpha * trans).astype(F32, copy=False)
 
 
 def sample_pdf_bins(bins: np.ndarray, weights: np.ndarray, n: int) -> np.ndarray:
     """nerf_sample_pdf(bins, weights, n, det=True) (src/nerf_raymarch_common.py:160-192) as RayMarchFromCoarse.batch calls it
     (src/features.py:653-654): bins [R,B] edges, weights [R,B-1]; u = linspace(0,1,n); -> [R,n] depths (ascending)."""
-    w = (weights.astype(F32) + F32(1e-5)).astype(F32)
-    pdf = (w / np.sum(w, -1, keepdims=True, dtype=F32)).astype(F32)
-    cdf = np.concatenate([np.zeros((pdf.shape[0], 1), F32), np.cumsum(pdf.astype(np.float64), -1).astype(F32)], -1)
+    w = (weights.astype(F32) + F32(1e-5)).astype(F32, copy=False)
+    pdf = (w / np.sum(w, -1, keepdims=True, dtype=F32)).astype(F32, copy=False)
+    cdf = np.concatenate([np.zeros((pdf.shape[0], 1), F32), np.cumsum(pdf.astype(np.float64), -1).astype(F32, copy=False)], -1)
     u = np.linspace(0.0, 1.0, n, dtype=F32)
     out = np.empty((cdf.shape[0], n), F32)
     nb = cdf.shape[1]
@@ -851,11 +855,11 @@ def sample_pdf_bins(bins: np.ndarray, weights: np.ndarray, n: int) -> np.ndarray
         below = np.maximum(inds - 1, 0)
         above = np.minimum(inds, nb - 1)
         c0, c1 = cdf[r][below], cdf[r][above]
-        denom = (c1 - c0).astype(F32)
-        denom = np.where(denom < F32(1e-5), F32(1.0), denom).astype(F32)
-        t = ((u - c0) / denom).astype(F32)
+        denom = (c1 - c0).astype(F32, copy=False)
+        denom = np.where(denom < F32(1e-5), F32(1.0), denom).astype(F32, copy=False)
+        t = ((u - c0) / denom).astype(F32, copy=False)
         b0, b1 = bins[r][below], bins[r][above]
-        out[r] = (b0 + t * (b1 - b0)).astype(F32)
+        out[r] = (b0 + t * (b1 - b0)).astype(F32, copy=False)
     return out
 
 
@@ -884,9 +888,9 @@ def render_coarse_fine(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, 
             p, rd = ndc_rays(h, w, focal_from_fov(w, scene.fov), 1.0, p, nds)
         w0 = classic_weights(raw0.reshape(r, nc, 4), zc, rd)
         rgb0 = composite_classic(raw0.reshape(r, nc, 4), zc, rd)
-        mid = (F32(0.5) * (zc[:, 1:] + zc[:, :-1])).astype(F32)
+        mid = (F32(0.5) * (zc[:, 1:] + zc[:, :-1])).astype(F32, copy=False)
         zf = sample_pdf_bins(mid, w0[:, 1:-1], nf)
-        za = np.sort(np.concatenate([zc, zf], -1), -1).astype(F32)
+        za = np.sort(np.concatenate([zc, zf], -1), -1).astype(F32, copy=False)
         sray = np.repeat(np.arange(r, dtype=np.int32), nc + nf)
         p_w = np.repeat(pose.astype(F32)[None], r, 0)
         f1 = shading_inputs(p_w, nds, sray, za.reshape(-1), scene, w, h, unit_dir=False)
@@ -905,15 +909,15 @@ def composite_classic(raw: np.ndarray, z: np.ndarray, rays_d: np.ndarray, aux: b
     alpha = 1 - exp(-relu(raw_a) * dist * |d|), dist = z[k+1] - z[k] (last 1e10), rgb = sigmoid(raw).
     raw [R,N,4], z [R,N] world depths, rays_d [R,3] -> [R,3]; aux: (rgb, depth_map = sum w*z, acc_map = sum w)."""
     raw = raw.astype(F32)
-    dists = np.concatenate([z[:, 1:] - z[:, :-1], np.full((z.shape[0], 1), 1e10, dtype=F32)], -1).astype(F32)
-    dists = (dists * np.sqrt(np.sum(rays_d * rays_d, -1, keepdims=True, dtype=F32))).astype(F32)
+    dists = np.concatenate([z[:, 1:] - z[:, :-1], np.full((z.shape[0], 1), 1e10, dtype=F32)], -1).astype(F32, copy=False)
+    dists = (dists * np.sqrt(np.sum(rays_d * rays_d, -1, keepdims=True, dtype=F32))).astype(F32, copy=False)
     rgb = sigmoid(raw[..., :3])
-    alpha = (F32(1.0) - np.exp(-np.maximum(raw[..., 3], F32(0)) * dists, dtype=F32)).astype(F32)
+    alpha = (F32(1.0) - np.exp(-np.maximum(raw[..., 3], F32(0)) * dists, dtype=F32)).astype(F32, copy=False)
     trans = np.cumprod(np.concatenate([np.ones((alpha.shape[0], 1), F32), F32(1.0) - alpha + F32(1e-10)], -1), -1, dtype=F32)[:, :-1]
-    wts = (alpha * trans).astype(F32)
-    out = np.sum(wts[..., None] * rgb, -2, dtype=F32).astype(F32)
+    wts = (alpha * trans).astype(F32, copy=False)
+    out = np.sum(wts[..., None] * rgb, -2, dtype=F32).astype(F32, copy=False)
     if aux:
-        return out, np.sum(wts * z, -1, dtype=F32).astype(F32), np.sum(wts, -1, dtype=F32).astype(F32)
+        return out, np.sum(wts * z, -1, dtype=F32).astype(F32, copy=False), np.sum(wts, -1, dtype=F32).astype(F32, copy=False)
     return out
 
 
@@ -925,8 +929,8 @@ def ndc_rays(h: int, w: int, focal: float, near: float, rays_o: np.ndarray, rays
     """src/nerf_raymarch_common.py:71-88."""
     rays_o = rays_o.astype(F32)
     rays_d = rays_d.astype(F32)
-    t = (-(F32(near) + rays_o[:, 2]) / rays_d[:, 2]).astype(F32)
-    rays_o = (rays_o + t[:, None] * rays_d).astype(F32)
+    t = (-(F32(near) + rays_o[:, 2]) / rays_d[:, 2]).astype(F32, copy=False)
+    rays_o = (rays_o + t[:, None] * rays_d).astype(F32, copy=False)
     sw = F32(-1.0 / (w / (2.0 * focal)))
     sh = F32(-1.0 / (h / (2.0 * focal)))
     o0 = sw * rays_o[:, 0] / rays_o[:, 2]
@@ -935,7 +939,7 @@ def ndc_rays(h: int, w: int, focal: float, near: float, rays_o: np.ndarray, rays
     d0 = sw * (rays_d[:, 0] / rays_d[:, 2] - rays_o[:, 0] / rays_o[:, 2])
     d1 = sh * (rays_d[:, 1] / rays_d[:, 2] - rays_o[:, 1] / rays_o[:, 2])
     d2 = F32(-2.0 * near) / rays_o[:, 2]
-    return (np.stack([o0, o1, o2], -1).astype(F32), np.stack([d0, d1, d2], -1).astype(F32))
+    return (np.stack([o0, o1, o2], -1).astype(F32, copy=False), np.stack([d0, d1, d2], -1).astype(F32, copy=False))
 
 
 def normalize_positions(x: np.ndarray, scene: Scene) -> np.ndarray:
@@ -947,23 +951,23 @@ def normalize_positions(x: np.ndarray, scene: Scene) -> np.ndarray:
     if name == "None":
         return x
     if name == "MaxDepth":
-        return (x / md).astype(F32)
+        return (x / md).astype(F32, copy=False)
     c = np.array(scene.normalization_center if len(scene.normalization_center) == 3 else scene.view_cell_center, dtype=F32)
-    loc = (x - c).astype(F32)
+    loc = (x - c).astype(F32, copy=False)
     if name == "Centered":
         return loc
     if name == "MaxDepthCentered":
-        return (loc / md).astype(F32)
-    n = np.sqrt(np.sum(loc * loc, -1, dtype=F32)).astype(F32)
+        return (loc / md).astype(F32, copy=False)
+    n = np.sqrt(np.sum(loc * loc, -1, dtype=F32)).astype(F32, copy=False)
     if name == "InverseSqrtDistCentered":      # :226-230
-        local = np.sqrt(n).astype(F32)
-        return (loc / (F32(math.sqrt(scene.max_depth)) * local[:, None])).astype(F32)
+        local = np.sqrt(n).astype(F32, copy=False)
+        return (loc / (F32(math.sqrt(scene.max_depth)) * local[:, None])).astype(F32, copy=False)
     if name == "InverseDistCentered":          # :219-223
-        return (loc * (F32(1.0) - F32(1.0) / (F32(1.0) + n))[:, None]).astype(F32)
+        return (loc * (F32(1.0) - F32(1.0) / (F32(1.0) + n))[:, None]).astype(F32, copy=False)
     if name == "LogCentered":                  # :211-216; LogTransform.from_world clamps its argument IN PLACE (util/depth_transformations.py:21-27)
-        n = np.where(n <= 0, F32(0.001), n).astype(F32)
-        lt = (np.log(n + F32(1.0), dtype=F32) / F32(math.log(scene.max_depth + 1.0))).astype(F32)
-        return (loc * (lt / n)[:, None]).astype(F32)
+        n = np.where(n <= 0, F32(0.001), n).astype(F32, copy=False)
+        lt = (np.log(n + F32(1.0), dtype=F32) / F32(math.log(scene.max_depth + 1.0))).astype(F32, copy=False)
+        return (loc * (lt / n)[:, None]).astype(F32, copy=False)
     raise NotImplementedError(name)
 
 
@@ -978,11 +982,11 @@ def shading_inputs(p: np.ndarray, nds: np.ndarray, sample_ray: np.ndarray, z: np
         o, d = ndc_rays(h, w, focal_from_fov(w, scene.fov), 1.0, p, nds)
         # RayMarchFromPoses encodes the normalised NDC direction (src/features.py:431); RayMarchFromCoarse is handed rays_d and
         # encodes it as it is (src/features.py:654-668): unit_dir = False
-        dir_pe = (d / np.sqrt(np.sum(d * d, -1, keepdims=True, dtype=F32))).astype(F32) if unit_dir else d
-    x = (o[sample_ray] + d[sample_ray] * z[:, None]).astype(F32)
+        dir_pe = (d / np.sqrt(np.sum(d * d, -1, keepdims=True, dtype=F32))).astype(F32, copy=False) if unit_dir else d
+    x = (o[sample_ray] + d[sample_ray] * z[:, None]).astype(F32, copy=False)
     x = normalize_positions(x, scene)
     return np.concatenate([positional_encoding(x, fp),
-                           positional_encoding(dir_pe[sample_ray], fd)], -1).astype(F32)
+                           positional_encoding(dir_pe[sample_ray], fd)], -1).astype(F32, copy=False)
 
 
 # --------------------------------------------------------------------------------------
@@ -991,7 +995,7 @@ def shading_inputs(p: np.ndarray, nds: np.ndarray, sample_ray: np.ndarray, z: np
 
 def sigmoid(x):
     x = x.astype(F32)
-    return (F32(1.0) / (F32(1.0) + np.exp(-x, dtype=F32))).astype(F32)
+    return (F32(1.0) / (F32(1.0) + np.exp(-x, dtype=F32))).astype(F32, copy=False)
 
 
 def composite(raw: np.ndarray, sample_w: np.ndarray, ray_offset: np.ndarray, count: np.ndarray,
@@ -1010,17 +1014,17 @@ def composite(raw: np.ndarray, sample_w: np.ndarray, ray_offset: np.ndarray, cou
     for s in range(n):
         act = count > s
         idx = np.where(act, ray_offset + s, 0)
-        a = np.where(act, sg[idx, 3], F32(0)).astype(F32)
+        a = np.where(act, sg[idx, 3], F32(0)).astype(F32, copy=False)
         if accumulation_mult == "alpha":
-            a = (a * np.where(act, sample_w[idx], F32(0))).astype(F32)
-        wgt = (a * trans).astype(F32)
+            a = (a * np.where(act, sample_w[idx], F32(0))).astype(F32, copy=False)
+        wgt = (a * trans).astype(F32, copy=False)
         if accumulation_mult == "weights":
-            wgt = (wgt * np.where(act, sample_w[idx], F32(0))).astype(F32)
-        rgb += (wgt[:, None] * np.where(act[:, None], sg[idx, :3], F32(0))).astype(F32)
+            wgt = (wgt * np.where(act, sample_w[idx], F32(0))).astype(F32, copy=False)
+        rgb += (wgt[:, None] * np.where(act[:, None], sg[idx, :3], F32(0))).astype(F32, copy=False)
         if z is not None:
-            depth += (wgt * np.where(act, z[idx], F32(0))).astype(F32)
+            depth += (wgt * np.where(act, z[idx], F32(0))).astype(F32, copy=False)
             acc += wgt
-        trans = (trans * (F32(1.0) - a + F32(1e-10))).astype(F32)
+        trans = (trans * (F32(1.0) - a + F32(1e-10))).astype(F32, copy=False)
     return rgb if z is None else (rgb, depth, acc)
 
 
@@ -1132,7 +1136,5 @@ def render_rays(dirs_cam: np.ndarray, pose: np.ndarray, rot: np.ndarray, scene: 
 
 def render_frame(scene: Scene, weights: Weights, w: int, h: int, pose: np.ndarray, rot: np.ndarray,
                  chunk: int = 8192, rows: Optional[Tuple[int, int]] = None):
-    dirs = generate_ray_directions(w, h, scene.fov)
-    if rows is not None:
-        dirs = dirs[rows[0] * w: rows[1] * w]
+    dirs = generate_ray_directions(w, h, scene.fov, rows=rows)
     return render_rays(dirs, pose, rot, scene, weights, w, h, chunk)
