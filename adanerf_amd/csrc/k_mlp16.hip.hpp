@@ -93,6 +93,8 @@ struct WStream {
   uint32_t lds_base;     // LDS byte address of the ring
   uint32_t grp;          // 0: this wave synchronises at chunk position 0, 1: at position CF / 2 (see ws_sync)
   uint32_t issuer;       // this wave issues LDS-DMA pieces (all waves, or one group only: tune::kDmaGroup)
+  uint32_t dma_lds;      // the chunk being copied: LDS byte address of this wave's first piece (M0 of its LPW copies) ...
+  uint32_t dma_goff;     // ... and the stream byte offset of that piece (scalar offset of its LPW copies); set at the wave's synchronisation point
   bool stag;             // the workgroup runs its two wave groups half a chunk apart (compile-time constant per kernel)
   u32x4 R[NR];           // register ring: fragment p (position inside the chunk) lives in R[p % NR]
 };
@@ -102,20 +104,41 @@ __device__ __forceinline__ u32x4 lds_read128(uint32_t byte_addr) {
   return *((lds_u32x4_ptr)(uintptr_t)byte_addr);
 }
 
+// One LDS-DMA piece (1 KiB: lane l copies 16 bytes) of the chunk st.dma_lds / st.dma_goff describe.  The instruction's immediate offset
+// moves BOTH the global address and the LDS destination (tools/probes/lds_dma_offset.hip, profiles/r06_lds_dma_offset.log), so the LPW
+// pieces of a chunk share one M0 value and one scalar offset: no per-piece scalar arithmetic, no per-piece M0 write.  Round 5 re-computed
+// both per piece and issued the LPW pieces back to back behind the barrier: 5.0 cycles per MFMA of a wave that is alone on its SIMD;
+// one M0 + immediates: 2.0; the same pieces spread over the chunk, one every CF / LPW fragments: 0.85 (tools/probes/dma_issue_cost.hip,
+// profiles/r06_dma_issue_cost.log).
 template <int CF, int RS, int LPW, int NR>
-__device__ __forceinline__ void ws_issue(WStream<CF, RS, LPW, NR>& st, uint32_t slot) {
-#pragma unroll
-  for (int i = 0; i < LPW; ++i) {
-    const uint32_t dst = st.lds_base + slot * (CF * 1024) + st.wave_off + i * 1024;
+__device__ __forceinline__ void ws_piece(WStream<CF, RS, LPW, NR>& st, int i) {      // i: compile-time after unrolling
+  static_assert(LPW >= 1 && LPW <= 4, "a piece is addressed by the 12-bit immediate offset of buffer_load ... lds");
 #if defined(__HIP_DEVICE_COMPILE__)
-    // buffer form (buffer_load_dwordx4 ... lds): descriptor + wave-uniform byte offset in SGPRs, lane * 16 as the only VGPR
-    // operand -- no 64-bit VALU address per piece (global_load_lds measured 1.3 % slower)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (__attribute__((address_space(3))) void*)static_cast<uintptr_t>(dst), 16,
-                                             static_cast<int>(st.lane_off), static_cast<int>(st.goff + st.wave_off + i * 1024), 0, 0);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  lds_ptr dst = (lds_ptr) static_cast<uintptr_t>(st.dma_lds);
+  // buffer form (buffer_load_dwordx4 ... lds): descriptor + wave-uniform byte offset in SGPRs, lane * 16 as the only VGPR operand
+  if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, static_cast<int>(st.lane_off), static_cast<int>(st.dma_goff), 0, 0);
+  else if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, static_cast<int>(st.lane_off), static_cast<int>(st.dma_goff), 1024, 0);
+  else if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, static_cast<int>(st.lane_off), static_cast<int>(st.dma_goff), 2048, 0);
+  else __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, static_cast<int>(st.lane_off), static_cast<int>(st.dma_goff), 3072, 0);
 #endif
-  }
+}
+
+// the next chunk of the stream goes to ring slot `slot`: describe it (ws_piece copies it) and advance the stream
+template <int CF, int RS, int LPW, int NR>
+__device__ __forceinline__ void ws_chunk_begin(WStream<CF, RS, LPW, NR>& st, uint32_t slot) {
+  st.dma_lds = st.lds_base + slot * (CF * 1024) + st.wave_off;
+  st.dma_goff = st.goff + st.wave_off;
   st.goff += CF * 1024;
   if (st.goff >= st.gbytes) st.goff = 0;
+}
+
+// a whole chunk at once (kernel prologue)
+template <int CF, int RS, int LPW, int NR>
+__device__ __forceinline__ void ws_issue(WStream<CF, RS, LPW, NR>& st, uint32_t slot) {
+  ws_chunk_begin(st, slot);
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) ws_piece(st, i);
 }
 
 // Synchronisation point k of the ring: own pieces of chunk k+1 have landed (<= (RS-3) LPW younger DMAs outstanding);
@@ -132,15 +155,17 @@ __device__ __forceinline__ void ws_skip_pad() {
 }
 
 template <int ABL, int CF, int RS, int LPW, int NR>
-__device__ __forceinline__ void ws_sync(WStream<CF, RS, LPW, NR>& st, bool pad) {
+__device__ __forceinline__ void ws_sync(WStream<CF, RS, LPW, NR>& st, bool pad, int piece) {
   static_assert(RS >= 3 && (RS - 2) * LPW < 64, "vmcnt is a 6-bit counter");
   if (ABL & 1) return;
   if (!(ABL & 32)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 3) * LPW) : "memory");   // 32: no wait/barrier
   // slot of chunk k-1: group 0 is still "in" it (ws_advance follows), group 1 has moved on to chunk k
   const uint32_t slot = (st.grp == 0) ? st.slot_cur : (st.slot_cur == 0 ? RS - 1 : st.slot_cur - 1);
   if (!(ABL & 16)) {                                                                                                      // 16: no DMA
-    if (st.issuer) ws_issue(st, slot);
-    else if (pad) ws_skip_pad();      // a barrier that releases at once is not 11 wait states
+    if (st.issuer) {
+      ws_chunk_begin(st, slot);
+      ws_piece(st, piece);      // the other pieces of the chunk follow at their positions (ws_position)
+    } else if (pad) ws_skip_pad();      // a barrier that releases at once is not 11 wait states
   }
 }
 
@@ -166,15 +191,28 @@ __device__ __forceinline__ void ws_advance(WStream<CF, RS, LPW, NR>& st) {
 // the compiler may have moved behind the branch); mid-tile, the next consumer of the accumulator is the next MFMA of the chain.
 template <int ABL, int CF, int RS, int LPW, int NR>
 __device__ __forceinline__ void ws_position(WStream<CF, RS, LPW, NR>& st, int f, bool tile_start) {
+  // The LPW pieces of a chunk are issued CF / LPW fragment positions apart: piece f / STEP at position f, whichever group the wave is in --
+  // a wave of group 1 starts its chunk at position CF / 2 with piece LPW / 2 and wraps (pieces are independent quarters of the chunk).
+  constexpr int STEP = CF / LPW;
+  static_assert(CF % LPW == 0 && (CF / 2) % STEP == 0, "piece positions: both groups' synchronisation points are piece positions");
   const bool pad = tile_start;
+  const bool piece_pos = f % STEP == 0 && !(ABL & (1 | 16));
   if (f == 0) {
     if (ABL & 1) return;
-    if (st.grp == 0) ws_sync<ABL>(st, pad);
-    else if (pad) ws_skip_pad();
+    if (st.grp == 0) ws_sync<ABL>(st, pad, 0);
+    else {
+      if (pad) ws_skip_pad();
+      if (piece_pos && st.issuer) ws_piece(st, 0);
+    }
     ws_advance(st);
   } else if (f == CF / 2 && st.stag) {
-    if (st.grp != 0) ws_sync<ABL>(st, pad);
-    else if (pad) ws_skip_pad();
+    if (st.grp != 0) ws_sync<ABL>(st, pad, (CF / 2) / STEP);
+    else {
+      if (pad) ws_skip_pad();
+      if (piece_pos && st.issuer) ws_piece(st, (CF / 2) / STEP);
+    }
+  } else if (piece_pos) {
+    if (st.issuer) ws_piece(st, f / STEP);
   }
 }
 
@@ -210,6 +248,9 @@ __device__ __forceinline__ void ws_start(WStream<CF, RS, LPW, NR>& st, const voi
 #pragma unroll
     for (int k = 0; k < RS - 1; ++k) ws_issue(st, k);
   }
+  // st.dma_* now describe chunk RS - 2.  A staggered group-1 wave passes piece positions before its first synchronisation point: those
+  // copies repeat pieces of chunk RS - 2 (same bytes to the same place, long before anyone reads them); being extra YOUNGER copies they
+  // only make the first counted waits stricter.
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 2) * LPW) : "memory");
   st.slot_cur = RS - 1;                       // the first ws_advance moves to slot 0 = chunk 0
   st.rd_cur = st.lds_base + st.lane_off;      // unused until then
@@ -322,23 +363,12 @@ __device__ __forceinline__ void epilogue_quad_16(const f32x16& acc, int m, int g
 
 constexpr int kKeepAllF32 = -2;   // layer_16 KEEP_F32_TILE: every tile's raw accumulator goes to keep[m]
 
-#if ADN_EXPERIMENT_BUILD
-}  // namespace adanerf
-#include "x_handsched.hip.hpp"     // experiment builds only (-DADN_EXPERIMENT): HsLayer / HsLayer3, see profiles/r02_handsched.md
-namespace adanerf {
-#endif
 
 template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
 __device__ __forceinline__ void layer_16(WS& st, uint32_t bias_addr, int lane, const uint32_t* in1, const uint32_t* in2,
                                          uint32_t* out, f32x16* keep = nullptr) {
   constexpr int CF = WS::kChunk;
   constexpr int KS = S1 + S2;
-#if ADN_EXPERIMENT_BUILD
-  if constexpr (tune::kHandSched) {
-    HsLayer<ET, WS, S1, S2, MT, RELU, FPOS, KEEP_F32_TILE>::run(st, bias_addr, in1, in2, out, keep);
-    return;
-  }
-#endif
   // bias_addr: LDS byte address of this layer's bias block for THIS lane-half ([m][h][16] floats)
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -471,16 +501,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
       lds_stash_write<QD / 8>(stash + (QP / 8) * 1024, dirs);
       layer_16<ET, WS, QP / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, lane, pts, pts, hA);
     }
-#if ADN_EXPERIMENT_BUILD
-    if constexpr (tune::kHandSched) ws_settle(st);      // no LDS read in flight into a loop or over its back-edge (HsLayer)
-#endif
 #pragma unroll 1
     for (int l = 1; l <= 3; l += 2) {
       layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l] * 4, lane, hA, hA, hB);
       layer_16<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l + 1] * 4, lane, hB, hB, hA);
-  #if ADN_EXPERIMENT_BUILD
-    if constexpr (tune::kHandSched) ws_settle(st);      // no LDS read in flight over a loop back-edge (HsLayer)
-#endif
     }
     {
       // the skip connection takes the 32 position slots back from the LDS stash instead of holding 16 VGPRs across layers 1-4
@@ -500,9 +524,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
     }
     f32x16 rgb_tile;
     layer_16<ET, WS, 8, 0, 1, false, (32 + 4 * 128 + 160 + 2 * 128 + 144 + 72) % CF, 0>(st, bias0 + bo[10] * 4, lane, hB, hB, hA, &rgb_tile);
-#if ADN_EXPERIMENT_BUILD
-    if constexpr (tune::kHandSched) ws_settle(st);
-#endif
     if (h == 0 && s < total)
       store_raw(a, s, rgb_tile[0], rgb_tile[1], rgb_tile[2], alpha);
   }

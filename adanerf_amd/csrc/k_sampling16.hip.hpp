@@ -61,32 +61,30 @@ __device__ __forceinline__ void epilogue_pair_16x3(const f32x16& acc, const f32x
   }
 }
 
-#if ADN_EXPERIMENT_BUILD
-}  // namespace adanerf
-#define ADN_HANDSCHED_PART2
-#include "x_handsched.hip.hpp"
-namespace adanerf {
-#endif
 
-#if !ADN_EXPERIMENT_BUILD
-static_assert(!tune::kHandSched && !tune::kHandSchedSampling, "the hand-scheduled layers exist in experiment builds only (-DADN_EXPERIMENT)");
-#endif
+// A finished output tile whose epilogue (combine, ReLU, hi / lo' split) has not run yet.  tune::kSplitCarry: the LAST tile of a hidden layer
+// is handed to the next layer this way and converted under the MFMAs of that layer's first tile (its outputs feed k-steps 14 and 15 of the
+// next layer only), instead of 96 VALU instructions + the MFMA -> VALU wait states with the matrix pipe idle at every layer boundary.
+struct PendingTile3 {
+  f32x16 acc, cross;
+};
 
-template <class WS, int KS, int MT, bool LAST, int FPOS>
-__device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane, const uint32_t* in_hi,
-                                           const uint32_t* in_lo, uint32_t* out_hi, uint32_t* out_lo, float* out_f32) {
+// HAS_PEND: `pend` holds tile 7 of the previous (hidden, 8-tile) layer; its outputs go to in_hi / in_lo[56 .. 63].
+template <class WS, int KS, int MT, bool LAST, int FPOS, bool HAS_PEND>
+__device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane, uint32_t* in_hi, uint32_t* in_lo, uint32_t* out_hi,
+                                           uint32_t* out_lo, float* out_f32, PendingTile3& pend) {
   // Software pipeline across output tiles (one wave per SIMD: nothing else hides these latencies):
   //  - the bias block of tile m+1 is requested right after tile m's accumulators are initialised,
   //  - the epilogue of tile m-1 is spread, one accumulator pair per k-step, over tile m's MFMAs.
-#if ADN_EXPERIMENT_BUILD
-  if constexpr (tune::kHandSchedSampling) {
-    HsLayer3<WS, KS, MT, LAST, FPOS>::run(st, bias_addr, in_hi, in_lo, out_hi, out_lo, out_f32);
-    return;
-  }
-#endif
   constexpr bool PIPE = !(tune::kAblateSample & 64);
+  constexpr bool CARRY = tune::kSplitCarry && PIPE && !(tune::kAblateSample & 8);
+  static_assert(!HAS_PEND || KS == 16, "a pending tile writes inputs 56 .. 63: the k-steps 14 and 15 of a 256-wide layer");
   BiasRegs br;
   f32x16 pacc, pcross;   // previous tile's accumulators (PIPE)
+  if (HAS_PEND && CARRY) {
+    pacc = pend.acc;
+    pcross = pend.cross;
+  }
   if (!(tune::kAblateSample & 4)) lds_bias_issue(bias_addr, br);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -96,7 +94,10 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     } else {
-      lds_bias_take(br, &acc);
+      // m > 0: the block was requested at the head of tile m - 1, in front of that tile's 2 KS fragment re-fills
+      constexpr int kYounger = (tune::kSplitBiasCounted && tune::kSchedGroupsSampling && !(tune::kAblateSample & 2) && 2 * KS >= 15) ? 15 : 0;
+      if (m == 0) lds_bias_take<0>(br, &acc);
+      else lds_bias_take<kYounger>(br, &acc);
       if (m + 1 < MT) lds_bias_issue(bias_addr + (m + 1) * 128, br);
     }
 #pragma unroll
@@ -110,15 +111,24 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
       acc = Fp16::mfma(st.R[f % WS::kRegs], bh, acc);
       cross = Fp16::mfma(st.R[f % WS::kRegs], bl, cross);
       cross = Fp16::mfma(st.R[(f + 1) % WS::kRegs], bh, cross);
-      ws_refill<tune::kAblateSample>(st, f);
-      ws_refill<tune::kAblateSample>(st, f + 1);
-      if (PIPE && m > 0 && !(tune::kAblateSample & 8)) {
-        // KS >= 2: spread the 8 pairs over the first k-steps (all 8 in step 0/1 when KS < 8)
-        constexpr int PER = (KS >= 8) ? 1 : (8 + KS - 1) / KS;
+      if (tune::kSplitRefillSwap) {
+        ws_refill<tune::kAblateSample>(st, f + 1);
+        ws_refill<tune::kAblateSample>(st, f);
+      } else {
+        ws_refill<tune::kAblateSample>(st, f);
+        ws_refill<tune::kAblateSample>(st, f + 1);
+      }
+      if (PIPE && !(tune::kAblateSample & 8) && (m > 0 || (HAS_PEND && CARRY))) {
+        // the 8 pairs of the previous tile, spread over the k-steps from E0 on (PER per k-step)
+        constexpr int E0 = (KS > tune::kSplitEpiStart + 1) ? tune::kSplitEpiStart : 0;
+        constexpr int PER = (KS - E0 >= 8) ? 1 : (8 + (KS - E0) - 1) / (KS - E0);
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-          const int pi = s * PER + k;
-          if (pi < 8) epilogue_pair_16x3<LAST>(pacc, pcross, m - 1, pi, out_hi, out_lo, out_f32);
+          const int pi = (s - E0) * PER + k;
+          if (s >= E0 && pi < 8) {
+            if (m > 0) epilogue_pair_16x3<LAST>(pacc, pcross, m - 1, pi, out_hi, out_lo, out_f32);
+            else epilogue_pair_16x3<false>(pacc, pcross, 7, pi, in_hi, in_lo, nullptr);      // the previous layer's last tile: read by k-steps 14, 15
+          }
         }
       }
       if (tune::kSchedGroupsSampling) {
@@ -142,6 +152,10 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
     if (PIPE && m + 1 < MT) {
       pacc = acc;
       pcross = cross;
+    } else if (CARRY && !LAST) {
+      static_assert(LAST || !tune::kSplitCarry || MT == 8, "the carried tile is tile 7");
+      pend.acc = acc;
+      pend.cross = cross;
     } else {
 #pragma unroll
       for (int pi = 0; pi < 8; ++pi) epilogue_pair_16x3<LAST>(acc, cross, m, pi, out_hi, out_lo, out_f32);
@@ -211,23 +225,15 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
 #pragma unroll
       for (int q = 0; q < Q0 / 2; ++q) split_pack(t[2 * q], t[2 * q + 1], &aH[q], &aL[q]);
     }
-    layer_16x3<WS, Q0 / 8, 8, false, 0>(st, bias0 + bo[0] * 4, lane, aH, aL, bH, bL, nullptr);
-#if ADN_EXPERIMENT_BUILD
-    if constexpr (tune::kHandSchedSampling) ws_settle_acc(st);      // ... nor into a loop (the allocator may re-home the ring at the header)
-#endif
+    PendingTile3 pend;      // a hidden layer's last tile, converted under the next layer's first MFMAs (tune::kSplitCarry)
+    layer_16x3<WS, Q0 / 8, 8, false, 0, false>(st, bias0 + bo[0] * 4, lane, aH, aL, bH, bL, nullptr, pend);
 #pragma unroll 1
     for (int l = 1; l <= 5; l += 2) {
-      layer_16x3<WS, 16, 8, false, 0>(st, bias0 + bo[l] * 4, lane, bH, bL, aH, aL, nullptr);
-      layer_16x3<WS, 16, 8, false, 0>(st, bias0 + bo[l + 1] * 4, lane, aH, aL, bH, bL, nullptr);
-#if ADN_EXPERIMENT_BUILD
-      if constexpr (tune::kHandSchedSampling) ws_settle_acc(st);      // no LDS read in flight over a loop back-edge (HsLayer3)
-#endif
+      layer_16x3<WS, 16, 8, false, 0, true>(st, bias0 + bo[l] * 4, lane, bH, bL, aH, aL, nullptr, pend);
+      layer_16x3<WS, 16, 8, false, 0, true>(st, bias0 + bo[l + 1] * 4, lane, aH, aL, bH, bL, nullptr, pend);
     }
     float out[64];
-    layer_16x3<WS, 16, 4, true, 0>(st, bias0 + bo[7] * 4, lane, bH, bL, nullptr, nullptr, out);
-#if ADN_EXPERIMENT_BUILD
-    if constexpr (tune::kHandSchedSampling) ws_settle_acc(st);
-#endif
+    layer_16x3<WS, 16, 4, true, 0, true>(st, bias0 + bo[7] * 4, lane, bH, bL, nullptr, nullptr, out, pend);
 
     if (a.fused_select) {
       // A4 in the epilogue: the 128 raw outputs of ray j sit in lanes j and j + 32 (k_select_pair.hip.hpp)
@@ -236,7 +242,12 @@ __global__ __launch_bounds__(256) void sample_mlp16x3_kernel(SampleArgs a) {
       for (int i = 0; i < 64; ++i) z = __builtin_fmaf(out[i], 0.f, z);    // NaN iff some output is inf / NaN (fp16 range left)
       const bool bad_ray = (z != z) | (pair_xchg(static_cast<uint32_t>(z != z)) != 0u);
       if (bad_ray && valid && h == 0 && a.overflow_flag) atomicAdd(a.overflow_flag, 1);
-      pair_epilogue(out, lane, local, valid, sel_stage, a.sel, false, entry, &gacc);
+      if (tune::kAblateSample & 512) {      // timing ablation (wrong results): no selection, one count per ray from a cheap function of the outputs
+        if (valid && h == 0) a.sel.counts[local] = 1 + (__builtin_bit_cast(int, out[0] + out[17] + out[35] + out[63]) & 3);
+        if (lane == 0 && valid) a.sel.seg_total[local >> kPairSegShift] = 64;
+      } else {
+        pair_epilogue(out, lane, local, valid, sel_stage, a.sel, false, entry, &gacc);
+      }
     }
     if (valid) {
       if (a.oracle_out) {
@@ -325,8 +336,8 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
     if (rd >= q && (wave >= k || wt >= WT)) {      // wave-uniform: an idle wave of the partial round
 #pragma unroll 1
       for (int c = 0; c < FRAGS / CF; ++c) {
-        ws_position<0>(st, 0, false);
-        ws_position<0>(st, CF / 2, false);
+#pragma unroll
+        for (int pp = 0; pp < CF; pp += CF / LPW) ws_position<0>(st, pp, false);      // every synchronisation point and piece position of a chunk
       }
       continue;
     }
@@ -360,22 +371,13 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
       for (int q = 0; q < Q0 / 2; ++q) in0[q] = Fp16::pack(t[2 * q], t[2 * q + 1]);
       layer_16<Fp16, WS, Q0 / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, lane, in0, in0, hA);
     }
-#if ADN_EXPERIMENT_BUILD
-    if constexpr (tune::kHandSched) ws_settle(st);
-#endif
 #pragma unroll 1
     for (int l = 1; l <= 5; l += 2) {
       layer_16<Fp16, WS, 16, 0, 8, true, F0 % CF>(st, bias0 + bo[l] * 4, lane, hA, hA, hB);
       layer_16<Fp16, WS, 16, 0, 8, true, F0 % CF>(st, bias0 + bo[l + 1] * 4, lane, hB, hB, hA);
-#if ADN_EXPERIMENT_BUILD
-      if constexpr (tune::kHandSched) ws_settle(st);      // no LDS read in flight over a loop back-edge (HsLayer)
-#endif
     }
     f32x16 out[4];
     layer_16<Fp16, WS, 16, 0, 4, false, F0 % CF, kKeepAllF32>(st, bias0 + bo[7] * 4, lane, hA, hA, hB, out);
-#if ADN_EXPERIMENT_BUILD
-    if constexpr (tune::kHandSched) ws_settle(st);
-#endif
     if (a.fused_select) {
       float x[64];
       float z = 0.f;

@@ -9,10 +9,8 @@ namespace tune {
 
 #if defined(ADN_EXPERIMENT)
 #define ADN_OVERRIDABLE 1
-#define ADN_EXPERIMENT_BUILD 1      // stays defined: gates the experiment-only code in k_mlp16 / k_sampling16 (x_handsched.hip.hpp)
 #else
 #define ADN_OVERRIDABLE 0
-#define ADN_EXPERIMENT_BUILD 0
 #endif
 
 // ---- LDS weight ring of the 16-bit engines (k_mlp16.hip.hpp) ---------------------------------------------------------
@@ -114,32 +112,6 @@ constexpr int kGenericBlocks256 = ADN_GEN_NB256;
 #else
 constexpr int kGenericBlocks256 = 2;
 #endif
-// layer_16 / layer_16x3 with every LDS read and wait issued by hand (HsLayer, HsLayer3) instead of compiler-scheduled
-// re-fills (the compiler-scheduled forms remain as the experiment baseline)
-#if ADN_OVERRIDABLE && defined(ADN_HANDSCHED)
-constexpr bool kHandSched = ADN_HANDSCHED != 0;
-#else
-constexpr bool kHandSched = false;
-#endif
-#if ADN_OVERRIDABLE && defined(ADN_HANDSCHED_S)
-constexpr bool kHandSchedSampling = ADN_HANDSCHED_S != 0;
-#else
-constexpr bool kHandSchedSampling = false;
-#endif
-// Hand-scheduled layers: every step block starts with s_nop kHsStepNop.  The compiler separates a VALU write from an MFMA
-// that reads the register by 2 wait states (s_nop 1) but cannot see the MFMAs inside the asm blocks; without the nop the
-// split-precision kernel (B operands copied out of AGPRs right in front of a block) gave different results from run to
-// run (tools/probes/determinism.py).  kHsWaitZero: experiment knob, forces every counted LDS wait to 0.
-#if ADN_OVERRIDABLE && defined(ADN_HS_WAIT0)
-constexpr bool kHsWaitZero = ADN_HS_WAIT0 != 0;
-#else
-constexpr bool kHsWaitZero = false;
-#endif
-#if ADN_OVERRIDABLE && defined(ADN_HS_NOP)
-constexpr int kHsStepNop = ADN_HS_NOP;
-#else
-constexpr int kHsStepNop = 1;
-#endif
 // Fragments held in registers per wave (= LDS prefetch distance in MFMAs).  Two waves per SIMD (256-register cap): 4
 // (2: 3.71-3.82 ms, 8: 3.66-3.76 ms with 4 spilled registers, against 3.58-3.62 on the same box).  The one-wave-per-SIMD
 // split sampling kernel keeps a whole chunk (4: 1.42, 8: 1.37, 16: 1.32 ms).
@@ -151,7 +123,7 @@ constexpr int kRegFrags = 4;
 #if ADN_OVERRIDABLE && defined(ADN_NR_S)
 constexpr int kRegFragsSampling = ADN_NR_S;
 #else
-constexpr int kRegFragsSampling = kHandSchedSampling ? 8 : 16;      // hand-scheduled: 4 (hi, lo') pairs = 4 k-steps of 96 cycles ahead
+constexpr int kRegFragsSampling = 16;
 #endif
 // 8-wave workgroups: waves 4-7 synchronise half a chunk after waves 0-3, so the two waves of a SIMD run half an output
 // tile apart (ws_sync); -1 / 0 / 1: every wave / only waves 0-3 / only waves 4-7 DMA-copy the weight pieces.
@@ -211,12 +183,12 @@ constexpr bool kSchedGroups = true;
 #if ADN_OVERRIDABLE && defined(ADN_SGB_S)
 constexpr bool kSchedGroupsSampling = ADN_SGB_S != 0;
 #else
-constexpr bool kSchedGroupsSampling = false;
+constexpr bool kSchedGroupsSampling = true;      // round 6: 1.261 -> 1.219 ms on top of the re-worked ring (profiles/r06_lab_log.md); round 3 saw no effect
 #endif
 #if ADN_OVERRIDABLE && defined(ADN_SGB_S_VALU)
 constexpr int kSgbValuSampling = ADN_SGB_S_VALU;
 #else
-constexpr int kSgbValuSampling = 5;
+constexpr int kSgbValuSampling = 4;
 #endif
 #if ADN_OVERRIDABLE && defined(ADN_NR2)
 constexpr int kRegFrags2 = ADN_NR2;
@@ -233,6 +205,36 @@ constexpr int kSplitPack = ADN_SPLIT_PACK;
 constexpr int kSplitPack = 1;
 #endif
 
+// Split engine, k-step details (k_sampling16.hip.hpp layer_16x3):
+//  kSplitRefillSwap  the lo' fragment register is re-filled before the hi one: LDS returns in order, so the wait in front of the k-step's first
+//                    MFMA (which reads hi, the younger request) covers both -- one s_waitcnt per k-step instead of two
+//  kSplitEpiStart    first k-step of tile m that carries a pair of tile m - 1's epilogue: 1 keeps the MFMA -> VALU wait states of the previous
+//                    tile's last MFMAs out of the stream (0: an s_nop 10 per tile)
+#if ADN_OVERRIDABLE && defined(ADN_REFILL_SWAP)
+constexpr bool kSplitRefillSwap = ADN_REFILL_SWAP != 0;
+#else
+constexpr bool kSplitRefillSwap = false;
+#endif
+//  kSplitBiasCounted the wait in front of a tile's bias block (requested a tile earlier) is lgkmcnt(15) instead of a full drain: the tile's own
+//                    2 KS >= 15 fragment re-fills were issued behind the request (one scheduling region per tile: needs kSchedGroupsSampling)
+//                    and LDS returns in order, so at most 15 outstanding operations means the bias block has arrived
+//  kSplitCarry       the last output tile of a hidden layer is converted under the MFMAs of the NEXT layer's first tile (PendingTile3)
+#if ADN_OVERRIDABLE && defined(ADN_SPLIT_CARRY)
+constexpr bool kSplitCarry = ADN_SPLIT_CARRY != 0;
+#else
+constexpr bool kSplitCarry = true;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_BIASWAIT_S)
+constexpr bool kSplitBiasCounted = ADN_BIASWAIT_S != 0;
+#else
+constexpr bool kSplitBiasCounted = true;
+#endif
+#if ADN_OVERRIDABLE && defined(ADN_EPI_START)
+constexpr int kSplitEpiStart = ADN_EPI_START;
+#else
+constexpr int kSplitEpiStart = 1;
+#endif
+
 // ---- selection (k_compact.hip.hpp) -----------------------------------------------------------------------------------
 // Rays per workgroup of the wave-per-ray select_kernel (4 waves x kSelRaysPerBlock / 4 rays) = rays per segment total
 #if ADN_OVERRIDABLE && defined(ADN_SEL_RPB)
@@ -247,6 +249,7 @@ constexpr int kSelRaysPerBlock = 64;
 //  16: boundary without the DMA issue                   32: boundary without wait + barrier
 //  64: (sampling kernel) no cross-tile software pipeline of bias reads / epilogue
 // 128: (sampling kernels) v_sin_f32 instead of the libm-grade sincosf in the oracle-feature encoding   256: (sampling kernels) no encoding at all
+// 512: (split sampling kernel) no selection epilogue
 // kAblateShade applies to shade_mlp16_kernel, kAblateSample to sample_mlp16x3_kernel.
 #if ADN_OVERRIDABLE && defined(ADN_ABLATE)
 constexpr int kAblateShade = ADN_ABLATE;

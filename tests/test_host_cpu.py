@@ -174,7 +174,7 @@ def test_every_inline_asm_conversion_is_behind_its_accumulators_guard():
             m = re.match(r"\s+v_cvt_pk_bf16_f32 v\d+, v(\d+), v(\d+) clamp", ln)
             if not m:
                 continue
-            g = re.search(r"guard (s\d+)", lines[i + 1]) if i + 1 < len(lines) else None
+            g = re.search(r"guard (s\d+|vcc_lo|vcc_hi)", lines[i + 1]) if i + 1 < len(lines) else None      # the allocator may pick a VCC half
             assert g, "clamped conversion without a guard operand: %s" % ln
             a, b = int(m.group(1)), int(m.group(2))
             for j in range(i - 1, -1, -1):      # the last write of the guard's SGPR
