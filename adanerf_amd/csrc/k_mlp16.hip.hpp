@@ -288,6 +288,14 @@ __device__ __forceinline__ void lds_bias_issue(uint32_t byte_addr, BiasRegs& r) 
                : "=&v"(r.b0), "=&v"(r.b1), "=&v"(r.b2), "=&v"(r.b3)
                : "v"(byte_addr));
 }
+// The same request with the two LDS addresses every fragment re-fill of the wave is computed from passed through the statement ("+v"): a
+// re-fill issued behind it in program order cannot be scheduled in front of it, which is what a COUNTED wait for the block relies on
+// (lds_bias_take<YOUNGER>: the re-fills of the tile are younger than the request).
+__device__ __forceinline__ void lds_bias_issue(uint32_t byte_addr, BiasRegs& r, uint32_t& rd0, uint32_t& rd1) {
+  asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\tds_read_b128 %3, %6 offset:48"
+               : "=&v"(r.b0), "=&v"(r.b1), "=&v"(r.b2), "=&v"(r.b3), "+v"(rd0), "+v"(rd1)
+               : "v"(byte_addr));
+}
 // YOUNGER: LDS reads this wave has issued behind the bias reads that need not have returned (LDS returns in order; the
 // counter has 4 bits).  0 drains every fragment prefetch in flight -- what a wave alone on its SIMD should not do per tile.
 template <int YOUNGER = 0>
@@ -537,20 +545,39 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 2) void shade_mlp16_ke
 // instruction stream hides latencies: the two accumulator chains alternate (no dependent back-to-back MFMAs), the bias block of
 // tile m + 1 is requested while tile m computes, and the epilogue of tile m - 1 (both blocks: 8 quads) is spread over the
 // first k-steps of tile m.  Both chains start from the bias registers as the C operand (no copies).
-template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1>
+// A finished tile pair (both blocks) whose conversion has not run yet: tune::kShadeCarry hands the LAST tile of a layer to the next layer, which
+// converts it under the MFMAs of its own first tile (the outputs feed the last two k-steps of that tile's input segment) instead of at the
+// layer boundary with the matrix pipe idle.
+struct PendingTile2 {
+  f32x16 a, b;
+};
+// PEND_M >= 0: `pend` holds tile PEND_M of the previous layer (ReLU: PEND_RELU); its packed outputs go to pendA / pendB = the arrays this layer
+// reads as (part of) its input.  CARRY_OUT: this layer's last tile is left in `pend` for the next layer.
+template <class ET, class WS, int S1, int S2, int MT, bool RELU, int FPOS, int KEEP_F32_TILE = -1, int PEND_M = -1, bool PEND_RELU = true,
+          bool CARRY_OUT = false>
 __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uint32_t* in1A, const uint32_t* in2A, const uint32_t* in1B,
-                                           const uint32_t* in2B, uint32_t* outA, uint32_t* outB, f32x16* keepA = nullptr,
-                                           f32x16* keepB = nullptr) {
+                                           const uint32_t* in2B, uint32_t* outA, uint32_t* outB, PendingTile2& pend, uint32_t* pendA = nullptr,
+                                           uint32_t* pendB = nullptr, f32x16* keepA = nullptr, f32x16* keepB = nullptr) {
   constexpr int CF = WS::kChunk;
   constexpr int KS = S1 + S2;
   constexpr int ABL = tune::kAblateShade;
   constexpr int PER = (KS >= 8) ? 1 : (8 + KS - 1) / KS;      // epilogue quads of the previous tile per k-step
+  constexpr bool kCarry = tune::kShadeCarry && !(ABL & 8);
+  constexpr bool kHasPend = kCarry && PEND_M >= 0;
+  constexpr int PERP = (KS >= 16) ? 1 : 2;                    // quads of a carried tile per k-step: all converted before the k-steps that read them
+  static_assert(!kHasPend || KS >= 8, "a carried tile is consumed by the last two k-steps of a segment of >= 8");
+  static_assert(!CARRY_OUT || KEEP_F32_TILE != MT - 1, "the kept tile is not converted");
   // LDS reads issued between a bias request and its use: the tile's KS fragment re-fills (none under ablation 2)
-  constexpr int kYounger = (ABL & 2) ? 0 : (tune::kBiasWaitCounted ? KS : 0);
+  constexpr bool kCounted = tune::kBiasWaitCounted && tune::kSchedGroups && !tune::kBiasPlain && !(ABL & (2 | 4));
+  constexpr int kYounger = kCounted ? KS : 0;
   BiasRegs br;
   f32x16 pA, pB;
   int gA = 0, gB = 0;      // mfma_guard of the tile whose conversions are pending
-  if (!(ABL & 4) && !tune::kBiasPlain) lds_bias_issue(bias_addr, br);
+  if (kHasPend) {
+    pA = pend.a;
+    pB = pend.b;
+  }
+  if (!(ABL & 4) && !tune::kBiasPlain) lds_bias_issue(bias_addr, br, st.rd_cur, st.rd_next);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 bias, accA, accB;
@@ -570,7 +597,7 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
     } else {
       if (m == 0) lds_bias_take<0>(br, &bias);              // first tile of the layer: issued just now
       else lds_bias_take<kYounger>(br, &bias);
-      if (m + 1 < MT) lds_bias_issue(bias_addr + (m + 1) * 128, br);
+      if (m + 1 < MT) lds_bias_issue(bias_addr + (m + 1) * 128, br, st.rd_cur, st.rd_next);
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -592,6 +619,18 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
           const int q = s * PER + k;
           if (q < 4) epilogue_quad_16<ET, RELU>(pA, m - 1, q, outA, gA);
           else if (q < 8) epilogue_quad_16<ET, RELU>(pB, m - 1, q - 4, outB, gB);
+        }
+      }
+      if (m == 0 && kHasPend) {      // the previous layer's last tile (its last MFMAs are a k-step behind as well)
+        if (s == 0) {
+          gA = mfma_guard<ET, PEND_RELU>(pA);
+          gB = mfma_guard<ET, PEND_RELU>(pB);
+        }
+#pragma unroll
+        for (int k = 0; k < PERP; ++k) {
+          const int q = s * PERP + k;
+          if (q < 4) epilogue_quad_16<ET, PEND_RELU>(pA, PEND_M < 0 ? 0 : PEND_M, q, pendA, gA);
+          else if (q < 8) epilogue_quad_16<ET, PEND_RELU>(pB, PEND_M < 0 ? 0 : PEND_M, q - 4, pendB, gB);
         }
       }
       if (tune::kSchedGroups) {
@@ -616,12 +655,17 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
       pA = accA;
       pB = accB;
     } else if (KEEP_F32_TILE != m) {
-      gA = mfma_guard<ET, RELU>(accA);
-      gB = mfma_guard<ET, RELU>(accB);
+      if (CARRY_OUT && kCarry) {
+        pend.a = accA;
+        pend.b = accB;
+      } else {
+        gA = mfma_guard<ET, RELU>(accA);
+        gB = mfma_guard<ET, RELU>(accB);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(accA, m, g, outA, gA);
+        for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(accA, m, g, outA, gA);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(accB, m, g, outB, gB);
+        for (int g = 0; g < 4; ++g) epilogue_quad_16<ET, RELU>(accB, m, g, outB, gB);
+      }
     }
   }
 }
@@ -659,6 +703,7 @@ __global__ __launch_bounds__(256) void shade_mlp16x2_kernel(ShadeArgs a) {
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int s0 = tile * TILE + wave * 64 + j, s1 = s0 + 32;
     uint32_t hA0[64], hB0[64], hA1[64], hB1[64];
+    PendingTile2 pend;      // a layer's last tile, converted under the next layer's first MFMAs (tune::kShadeCarry)
     {
       float x[3], dpe[3];
       uint32_t pts0[QP / 2], pts1[QP / 2], dirs[QD / 2];
@@ -672,31 +717,32 @@ __global__ __launch_bounds__(256) void shade_mlp16x2_kernel(ShadeArgs a) {
       pe_pack<ET, FD>(dpe, h, dirs);
       lds_stash_write<QP / 8>(stash + kStashPerBlock, pts1);
       lds_stash_write<QD / 8>(stash + kStashPerBlock + (QP / 8) * 1024, dirs);
-      layer_16x2<ET, WS, QP / 8, 0, 8, true, 0>(st, bias0 + bo[0] * 4, pts0, pts0, pts1, pts1, hA0, hA1);
+      layer_16x2<ET, WS, QP / 8, 0, 8, true, 0, -1, -1, true, true>(st, bias0 + bo[0] * 4, pts0, pts0, pts1, pts1, hA0, hA1, pend);
     }
 #pragma unroll 1
     for (int l = 1; l <= 3; l += 2) {
-      layer_16x2<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l] * 4, hA0, hA0, hA1, hA1, hB0, hB1);
-      layer_16x2<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[l + 1] * 4, hB0, hB0, hB1, hB1, hA0, hA1);
+      layer_16x2<ET, WS, 16, 0, 8, true, 0, -1, 7, true, true>(st, bias0 + bo[l] * 4, hA0, hA0, hA1, hA1, hB0, hB1, pend, hA0, hA1);
+      layer_16x2<ET, WS, 16, 0, 8, true, 0, -1, 7, true, true>(st, bias0 + bo[l + 1] * 4, hB0, hB0, hB1, hB1, hA0, hA1, pend, hB0, hB1);
     }
     {
       uint32_t pts0[QP / 2], pts1[QP / 2];
       lds_stash_read<QP / 8>(stash, pts0);
       lds_stash_read<QP / 8>(stash + kStashPerBlock, pts1);
-      layer_16x2<ET, WS, QP / 8, 16, 8, true, 0>(st, bias0 + bo[5] * 4, pts0, hA0, pts1, hA1, hB0, hB1);   // cat([pts, h])
+      layer_16x2<ET, WS, QP / 8, 16, 8, true, 0, -1, 7, true, true>(st, bias0 + bo[5] * 4, pts0, hA0, pts1, hA1, hB0, hB1, pend, hA0, hA1);   // cat([pts, h])
     }
-    layer_16x2<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[6] * 4, hB0, hB0, hB1, hB1, hA0, hA1);
-    layer_16x2<ET, WS, 16, 0, 8, true, 0>(st, bias0 + bo[7] * 4, hA0, hA0, hA1, hA1, hB0, hB1);
+    layer_16x2<ET, WS, 16, 0, 8, true, 0, -1, 7, true, true>(st, bias0 + bo[6] * 4, hB0, hB0, hB1, hB1, hA0, hA1, pend, hB0, hB1);
+    layer_16x2<ET, WS, 16, 0, 8, true, 0, -1, 7, true, true>(st, bias0 + bo[7] * 4, hA0, hA0, hA1, hA1, hB0, hB1, pend, hA0, hA1);
     f32x16 alpha0, alpha1;
-    layer_16x2<ET, WS, 16, 0, 9, false, 0, 8>(st, bias0 + bo[8] * 4, hB0, hB0, hB1, hB1, hA0, hA1, &alpha0, &alpha1);      // feature (+alpha row)
+    // feature (+alpha row): tile 8 is kept, tile 7 is converted under it -- nothing to carry
+    layer_16x2<ET, WS, 16, 0, 9, false, 0, 8, 7, true, false>(st, bias0 + bo[8] * 4, hB0, hB0, hB1, hB1, hA0, hA1, pend, hB0, hB1, &alpha0, &alpha1);
     {
       uint32_t d0[QD / 2], d1[QD / 2];
       lds_stash_read<QD / 8>(stash + (QP / 8) * 1024, d0);
       lds_stash_read<QD / 8>(stash + kStashPerBlock + (QP / 8) * 1024, d1);
-      layer_16x2<ET, WS, 16, QD / 8, 4, true, (32 + 4 * 128 + 160 + 2 * 128 + 144) % CF>(st, bias0 + bo[9] * 4, hA0, d0, hA1, d1, hB0, hB1);   // cat([feature, dir])
+      layer_16x2<ET, WS, 16, QD / 8, 4, true, (32 + 4 * 128 + 160 + 2 * 128 + 144) % CF, -1, -1, true, true>(st, bias0 + bo[9] * 4, hA0, d0, hA1, d1, hB0, hB1, pend);   // cat([feature, dir])
     }
     f32x16 rgb0, rgb1;
-    layer_16x2<ET, WS, 8, 0, 1, false, (32 + 4 * 128 + 160 + 2 * 128 + 144 + 72) % CF, 0>(st, bias0 + bo[10] * 4, hB0, hB0, hB1, hB1, hA0, hA1, &rgb0, &rgb1);
+    layer_16x2<ET, WS, 8, 0, 1, false, (32 + 4 * 128 + 160 + 2 * 128 + 144 + 72) % CF, 0, 3, true, false>(st, bias0 + bo[10] * 4, hB0, hB0, hB1, hB1, hA0, hA1, pend, hB0, hB1, &rgb0, &rgb1);
     if (h == 0 && s0 < total)
       store_raw(a, s0, rgb0[0], rgb0[1], rgb0[2], alpha0[0]);
     if (h == 0 && s1 < total)

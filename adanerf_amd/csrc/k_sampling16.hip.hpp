@@ -79,13 +79,14 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
   constexpr bool PIPE = !(tune::kAblateSample & 64);
   constexpr bool CARRY = tune::kSplitCarry && PIPE && !(tune::kAblateSample & 8);
   static_assert(!HAS_PEND || KS == 16, "a pending tile writes inputs 56 .. 63: the k-steps 14 and 15 of a 256-wide layer");
+  constexpr bool kCounted = tune::kSplitBiasCounted && tune::kSchedGroupsSampling && !(tune::kAblateSample & 2);
   BiasRegs br;
   f32x16 pacc, pcross;   // previous tile's accumulators (PIPE)
   if (HAS_PEND && CARRY) {
     pacc = pend.acc;
     pcross = pend.cross;
   }
-  if (!(tune::kAblateSample & 4)) lds_bias_issue(bias_addr, br);
+  if (!(tune::kAblateSample & 4)) lds_bias_issue(bias_addr, br, st.rd_cur, st.rd_next);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 acc, cross;
@@ -95,10 +96,10 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     } else {
       // m > 0: the block was requested at the head of tile m - 1, in front of that tile's 2 KS fragment re-fills
-      constexpr int kYounger = (tune::kSplitBiasCounted && tune::kSchedGroupsSampling && !(tune::kAblateSample & 2) && 2 * KS >= 15) ? 15 : 0;
+      constexpr int kYounger = kCounted ? (2 * KS < 15 ? 2 * KS : 15) : 0;
       if (m == 0) lds_bias_take<0>(br, &acc);
       else lds_bias_take<kYounger>(br, &acc);
-      if (m + 1 < MT) lds_bias_issue(bias_addr + (m + 1) * 128, br);
+      if (m + 1 < MT) lds_bias_issue(bias_addr + (m + 1) * 128, br, st.rd_cur, st.rd_next);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) cross[r] = 0.f;

@@ -167,7 +167,15 @@ constexpr int kRingSlots2 = 6;
 #if ADN_OVERRIDABLE && defined(ADN_BIASWAIT)
 constexpr bool kBiasWaitCounted = ADN_BIASWAIT != 0;
 #else
-constexpr bool kBiasWaitCounted = false;     // not safe with compiler-scheduled re-fills (the count assumes they were issued): experiment only
+constexpr bool kBiasWaitCounted = true;      // round 6: the request carries the re-fill addresses as operands (lds_bias_issue), one scheduling region per tile
+#endif
+// kShadeCarry: the last tile of a shading layer is converted under the first tile of the next layer (layer_16x2, PendingTile2).
+// (Requesting the next layer's first bias block a layer ahead, so that the wait at a layer boundary is counted too, was measured and dropped:
+// the 16 bias registers live across the boundary next to the carried tile and both kernels spill -- 512 registers + scratch, sampling 1.23 -> 2.29 ms.)
+#if ADN_OVERRIDABLE && defined(ADN_SHADE_CARRY)
+constexpr bool kShadeCarry = ADN_SHADE_CARRY != 0;
+#else
+constexpr bool kShadeCarry = true;
 #endif
 // bias blocks through compiler-visible LDS loads / the k-step interleave pinned with sched_group_barrier (layer_16x2)
 #if ADN_OVERRIDABLE && defined(ADN_BIASPLAIN)

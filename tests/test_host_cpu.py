@@ -197,6 +197,39 @@ def test_every_inline_asm_conversion_is_behind_its_accumulators_guard():
     assert checked > 1000      # 832 in the 8 x 256 kernel alone
 
 
+def test_counted_bias_waits_have_enough_younger_lds_reads():
+    """A tile's bias block is requested a tile ahead by hand-issued ds_read_b128 (k_mlp16.hip.hpp lds_bias_issue) and taken behind
+    `s_waitcnt lgkmcnt(N)` with N > 0 (lds_bias_take<YOUNGER>): LDS returns in order, so "at most N operations outstanding" proves the block
+    has arrived only if at least N LDS reads were issued BEHIND the request.  On the assembly: walking back from every hand-written counted wait
+    to the bias request in front of it, at least N ds_read instructions lie in between -- whatever the scheduler did with the re-fills."""
+    text = _device_assembly()
+    if text is None:
+        pytest.skip("no hipcc")
+    checked = 0
+    for k in re.split(r"\n\s*\.globl\s+", text):
+        lines = k.split("\n")
+        in_asm = False
+        for i, ln in enumerate(lines):
+            if "#ASMSTART" in ln:
+                in_asm = True
+            elif "#ASMEND" in ln:
+                in_asm = False
+            m = re.match(r"\s+s_waitcnt lgkmcnt\((\d+)\)", ln)
+            if not (in_asm and m and int(m.group(1)) > 0):
+                continue
+            n, younger = int(m.group(1)), 0
+            for j in range(i - 1, -1, -1):
+                if re.match(r"\s+ds_read_b128 v\[\d+:\d+\], v\d+ offset:48", lines[j]) and "#ASMEND" in lines[j + 1]:
+                    break      # the last read of the request (4 x ds_read_b128 at offsets 0 / 16 / 32 / 48 in one asm statement)
+                if re.match(r"\s+ds_read", lines[j]):
+                    younger += 1
+            else:
+                raise AssertionError("counted wait without a bias request in front of it: %s" % ln)
+            assert younger >= n, "lgkmcnt(%d) with only %d LDS reads behind the bias request (%s)" % (n, younger, lines[0][:80])
+            checked += 1
+    assert checked > 100      # 7 per tile and layer in the 8 x 256 kernels
+
+
 def test_abi_handshake(lib):
     """adanerf_abi_version / adanerf_struct_sizes against the ctypes mirrors (load_library refuses a library that disagrees)."""
     sizes = (C.c_int32 * 3)()
