@@ -122,28 +122,8 @@ __device__ __forceinline__ void ndc_ray(const RayGenParams& g, const float o[3],
 // [-pi/4, pi/4] (Cephes sinf/cosf coefficients); cos(a) = sin(a + pi/2) is applied to the integer quadrant, so it is
 // exact.  ~25 VALU instructions; the device libm's sincosf (Payne-Hanek capable, both results) costs ~5x that, which
 // was 0.14 ms per frame in the sampling kernel.
-__device__ __forceinline__ float sin_or_cos(float a, int h) {
-  float r;
-  int n;
-  if (__builtin_expect(fabsf(a) < 1.0e5f, 1)) {
-    const float j = __builtin_rintf(a * 0.636619747f);             // a * 2/pi
-    r = __builtin_fmaf(j, -1.57079601e+00f, a);                    // pi/2 = 1.57079601 + 3.13916473e-7 + 5.39030253e-15
-    r = __builtin_fmaf(j, -3.13916473e-07f, r);
-    r = __builtin_fmaf(j, -5.39030253e-15f, r);
-    n = static_cast<int>(j) + h;
-  } else {
-    // rare: the same reduction in fp64 (two-term pi/2), exact to ~1e-16 while the quotient fits a double's integers
-    // (|a| < ~1e15).  Beyond that the argument's own fp32 spacing spans > 1e7 periods and the value carries no
-    // information: the reduced argument is clamped so the result stays in [-1, 1], but it is not libm's value.
-    // inf/NaN -> NaN like libm.
-    const double ad = static_cast<double>(a);
-    const double k = __builtin_rint(ad * 0.6366197723675814);
-    double rd = __builtin_fma(k, -1.5707963267948966, ad);
-    rd = __builtin_fma(k, -6.123233995736766e-17, rd);
-    rd = __builtin_fmin(__builtin_fmax(rd, -0.7853981633974483), 0.7853981633974483);   // NaN stays NaN: see below
-    r = (a != a || fabsf(a) == INFINITY) ? __builtin_nanf("") : static_cast<float>(rd);
-    n = static_cast<int>(k - 4.0 * __builtin_floor(k * 0.25)) + h;
-  }
+// polynomial part: r in [-pi/4, pi/4], n = quadrant (+ 1 for the cosine)
+__device__ __forceinline__ float sin_or_cos_poly(float r, int n) {
   const float s = r * r;
   float t = __builtin_fmaf(s, -1.9515295891e-4f, 8.3321608736e-3f);
   t = __builtin_fmaf(t, s, -1.6666654611e-1f);
@@ -154,20 +134,54 @@ __device__ __forceinline__ float sin_or_cos(float a, int h) {
   const float v = (n & 1) ? pc : ps;
   return (n & 2) ? -v : v;
 }
+// |a| < 1e5 (the caller knows): no branch
+__device__ __forceinline__ float sin_or_cos_small(float a, int h) {
+  const float j = __builtin_rintf(a * 0.636619747f);             // a * 2/pi
+  float r = __builtin_fmaf(j, -1.57079601e+00f, a);              // pi/2 = 1.57079601 + 3.13916473e-7 + 5.39030253e-15
+  r = __builtin_fmaf(j, -3.13916473e-07f, r);
+  r = __builtin_fmaf(j, -5.39030253e-15f, r);
+  return sin_or_cos_poly(r, static_cast<int>(j) + h);
+}
+__device__ __forceinline__ float sin_or_cos(float a, int h) {
+  if (__builtin_expect(fabsf(a) < 1.0e5f, 1)) return sin_or_cos_small(a, h);
+  // rare: the same reduction in fp64 (two-term pi/2), exact to ~1e-16 while the quotient fits a double's integers
+  // (|a| < ~1e15).  Beyond that the argument's own fp32 spacing spans > 1e7 periods and the value carries no
+  // information: the reduced argument is clamped so the result stays in [-1, 1], but it is not libm's value.
+  // inf/NaN -> NaN like libm.
+  const double ad = static_cast<double>(a);
+  const double k = __builtin_rint(ad * 0.6366197723675814);
+  double rd = __builtin_fma(k, -1.5707963267948966, ad);
+  rd = __builtin_fma(k, -6.123233995736766e-17, rd);
+  rd = __builtin_fmin(__builtin_fmax(rd, -0.7853981633974483), 0.7853981633974483);   // NaN stays NaN: see below
+  const float r = (a != a || fabsf(a) == INFINITY) ? __builtin_nanf("") : static_cast<float>(rd);
+  return sin_or_cos_poly(r, static_cast<int>(k - 4.0 * __builtin_floor(k * 0.25)) + h);
+}
 
 // PE slots of lane-half h (layout.hpp): slot q < 3F -> h ? cos : sin of 2^(q/3) * x[q%3];
 // then two identity slots.  ACCURATE: libm-grade sin_or_cos (fp32 parity path);
 // !ACCURATE: one v_sin_f32 per slot (cos = sin shifted by a quarter revolution).
 template <int F, bool ACCURATE>
 __device__ __forceinline__ void pe_eval(const float x[3], int h, float* out) {
+  // ACCURATE: one wave-uniform range test for all 3 F arguments instead of a branch around every evaluation (round 6: 42 exec-mask branches per
+  // ray block of the sampling kernels); the rare wave with an argument beyond the single-precision reduction (or a NaN) takes the general form.
+  bool small = true;
+  if (ACCURATE) {
+    const float amax = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fabsf(x[2])) * static_cast<float>(1 << (F > 0 ? F - 1 : 0));
+    small = __builtin_amdgcn_ballot_w64(!(amax < 1.0e5f)) == 0ull;
+  }
+  if (ACCURATE && small) {
 #pragma unroll
-  for (int q = 0; q < 3 * F; ++q) {
-    const int b = q / 3, c = q - 3 * b;
-    const float a = x[c] * static_cast<float>(1 << b);
-    if (ACCURATE) {
-      out[q] = sin_or_cos(a, h);
-    } else {
-      out[q] = __builtin_amdgcn_sinf(__builtin_fmaf(a, 0.15915494309189535f, h ? 0.25f : 0.0f));
+    for (int q = 0; q < 3 * F; ++q) out[q] = sin_or_cos_small(x[q % 3] * static_cast<float>(1 << (q / 3)), h);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 3 * F; ++q) {
+      const int b = q / 3, c = q - 3 * b;
+      const float a = x[c] * static_cast<float>(1 << b);
+      if (ACCURATE) {
+        out[q] = sin_or_cos(a, h);
+      } else {
+        out[q] = __builtin_amdgcn_sinf(__builtin_fmaf(a, 0.15915494309189535f, h ? 0.25f : 0.0f));
+      }
     }
   }
   out[3 * F] = h ? x[2] : x[0];

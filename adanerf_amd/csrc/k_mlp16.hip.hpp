@@ -112,15 +112,17 @@ __device__ __forceinline__ u32x4 lds_read128(uint32_t byte_addr) {
 // profiles/r06_dma_issue_cost.log).
 template <int CF, int RS, int LPW, int NR>
 __device__ __forceinline__ void ws_piece(WStream<CF, RS, LPW, NR>& st, int i) {      // i: compile-time after unrolling
-  static_assert(LPW >= 1 && LPW <= 4, "a piece is addressed by the 12-bit immediate offset of buffer_load ... lds");
+  static_assert(LPW >= 1 && LPW <= 8, "a piece is addressed by the 12-bit immediate offset of buffer_load ... lds (pieces 4 .. 7: a second base)");
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  lds_ptr dst = (lds_ptr) static_cast<uintptr_t>(st.dma_lds);
+  const uint32_t far = i >= 4 ? 4096u : 0u;
+  lds_ptr dst = (lds_ptr) static_cast<uintptr_t>(st.dma_lds + far);
+  const int voff = static_cast<int>(st.lane_off), soff = static_cast<int>(st.dma_goff + far);
   // buffer form (buffer_load_dwordx4 ... lds): descriptor + wave-uniform byte offset in SGPRs, lane * 16 as the only VGPR operand
-  if (i == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, static_cast<int>(st.lane_off), static_cast<int>(st.dma_goff), 0, 0);
-  else if (i == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, static_cast<int>(st.lane_off), static_cast<int>(st.dma_goff), 1024, 0);
-  else if (i == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, static_cast<int>(st.lane_off), static_cast<int>(st.dma_goff), 2048, 0);
-  else __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, static_cast<int>(st.lane_off), static_cast<int>(st.dma_goff), 3072, 0);
+  if ((i & 3) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, voff, soff, 0, 0);
+  else if ((i & 3) == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, voff, soff, 1024, 0);
+  else if ((i & 3) == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, voff, soff, 2048, 0);
+  else __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, voff, soff, 3072, 0);
 #endif
 }
 
@@ -193,10 +195,11 @@ template <int ABL, int CF, int RS, int LPW, int NR>
 __device__ __forceinline__ void ws_position(WStream<CF, RS, LPW, NR>& st, int f, bool tile_start) {
   // The LPW pieces of a chunk are issued CF / LPW fragment positions apart: piece f / STEP at position f, whichever group the wave is in --
   // a wave of group 1 starts its chunk at position CF / 2 with piece LPW / 2 and wraps (pieces are independent quarters of the chunk).
-  constexpr int STEP = CF / LPW;
-  static_assert(CF % LPW == 0 && (CF / 2) % STEP == 0, "piece positions: both groups' synchronisation points are piece positions");
+  // RS == 3 leaves a chunk one chunk time to land: its pieces go into the first half of the chunk (STEP halved); such a ring is not staggered.
+  constexpr int STEP = RS == 3 ? CF / LPW / 2 : CF / LPW;
+  static_assert(CF % LPW == 0 && STEP >= 1 && (RS == 3 || (CF / 2) % STEP == 0), "piece positions: both groups' synchronisation points are piece positions");
   const bool pad = tile_start;
-  const bool piece_pos = f % STEP == 0 && !(ABL & (1 | 16));
+  const bool piece_pos = f % STEP == 0 && f / STEP < LPW && !(ABL & (1 | 16));
   if (f == 0) {
     if (ABL & 1) return;
     if (st.grp == 0) ws_sync<ABL>(st, pad, 0);

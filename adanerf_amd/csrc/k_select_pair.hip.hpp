@@ -5,6 +5,7 @@
 // Device code only (gfx950, wave64); part of kernels.hip.hpp.
 #pragma once
 #include "k_common.hip.hpp"
+#include "tuning.hpp"
 
 namespace adanerf {
 
@@ -145,7 +146,10 @@ __device__ __forceinline__ int pair_select(const float* x, int h, int n_max, flo
   for (int k = 0; k < NB; ++k) s[k] = -INFINITY;
 #pragma unroll
   for (int i = 0; i < 64; ++i) {
-    const float v = (x[i] == x[i]) ? x[i] : -INFINITY;   // NaN never ranks (fmaxf in select_ray ignores it, too)
+    // NaN never ranks (fmaxf in select_ray ignores it, too).  tune::kSelScrubNaN == false: no per-value replacement by -inf -- v_max_f32 returns
+    // its non-NaN operand and v_med3_f32 with a NaN operand returns the minimum of the other two, which in a descending list is s[k] itself
+    // (edge-case fixture: NaN / inf rows of test_fused_selection_* and the fuzz cases).
+    const float v = (!tune::kSelScrubNaN || x[i] == x[i]) ? x[i] : -INFINITY;
 #pragma unroll
     for (int k = NB - 1; k >= 1; --k) s[k] = __builtin_amdgcn_fmed3f(s[k - 1], s[k], v);
     s[0] = fmaxf(s[0], v);

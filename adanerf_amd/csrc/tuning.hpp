@@ -30,12 +30,12 @@ constexpr int kRingSlots = 4;
 #if ADN_OVERRIDABLE && defined(ADN_CF_S)
 constexpr int kChunkFragsSampling = ADN_CF_S;
 #else
-constexpr int kChunkFragsSampling = 16;
+constexpr int kChunkFragsSampling = 32;      // round 6: 32 fragments x 3 slots (a barrier every 48 MFMAs, pieces issued in the first half of a chunk): 1.228 -> 1.218 ms
 #endif
 #if ADN_OVERRIDABLE && defined(ADN_RS_S)
 constexpr int kRingSlotsSampling = ADN_RS_S;
 #else
-constexpr int kRingSlotsSampling = 6;
+constexpr int kRingSlotsSampling = 3;
 #endif
 // plain-fp16 sampling kernel (speed mode, first pass of the guarded mode): encoding through one v_sin_f32 per slot instead of the
 // fp32-parity sin_or_cos -- its values are rounded to fp16 right after (2.4e-4), the guard band is calibrated with whatever this
@@ -243,7 +243,13 @@ constexpr int kSplitEpiStart = ADN_EPI_START;
 constexpr int kSplitEpiStart = 1;
 #endif
 
-// ---- selection (k_compact.hip.hpp) -----------------------------------------------------------------------------------
+// ---- selection (k_select_pair.hip.hpp, k_compact.hip.hpp)
+// kSelScrubNaN: the sorted-list insertion of pair_select replaces NaN by -inf first (2 VALU per value); false: relies on v_max / v_med3 ignoring NaN
+#if ADN_OVERRIDABLE && defined(ADN_SEL_SCRUB)
+constexpr bool kSelScrubNaN = ADN_SEL_SCRUB != 0;
+#else
+constexpr bool kSelScrubNaN = false;
+#endif
 // Rays per workgroup of the wave-per-ray select_kernel (4 waves x kSelRaysPerBlock / 4 rays) = rays per segment total
 #if ADN_OVERRIDABLE && defined(ADN_SEL_RPB)
 constexpr int kSelRaysPerBlock = ADN_SEL_RPB;

@@ -9,6 +9,10 @@
 //   (4  8 x dwordx2 does not exist: LDS-DMA sizes are 1, 2, 4, 12 or 16 bytes per lane)
 //   5  16 x dword (256 B per instruction), two behind every 3rd MFMA
 //   6  as 3, but the piece is issued right BEHIND an MFMA pair (two MFMAs back to back, then the copy)
+//   7  as 3 with an s_barrier at the head of every chunk, as the ring has it: the four waves of a workgroup then reach every piece
+//      position in the same cycles and their copies queue up behind each other in the CU's one address unit
+//   8  as 7, and wave w idles 8 w issue cycles (w x s_nop 7) behind the barrier: the waves' copies no longer coincide
+//   9  as 7, 16 w issue cycles
 // Build: hipcc --offload-arch=gfx950 -O3 tools/probes/dma_issue_cost.hip -o adanerf_amd/bin/dma_issue_cost
 #pragma clang diagnostic ignored "-Wunused-value"
 #include <hip/hip_runtime.h>
@@ -72,6 +76,17 @@ __global__ __launch_bounds__(256) void dma_cost(const char* stream, int iters, f
 #pragma unroll
     for (int s = 0; s < 8; ++s) {      // one chunk: 8 k-steps of 3 MFMAs
       const u32x4 &ah = a[s & 3], &al = a[(s + 1) & 3], &bh = b[s & 3], &bl = b[(s + 2) & 3];
+      if ((FORM == 7 || FORM == 8 || FORM == 9) && s == 0) {
+        asm volatile("s_barrier" ::: "memory");
+        // wave-dependent idle time without C++ control flow (a loop here makes hipcc shuffle the accumulators between register files)
+        if (FORM == 8)
+          asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_nop 7\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 1f\n\ts_nop 7\n\t"
+                       "s_cmp_eq_u32 %0, 2\n\ts_cbranch_scc1 1f\n\ts_nop 7\n1:" ::"s"(wave) : "scc");
+        if (FORM == 9)
+          asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_nop 15\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 1f\n\ts_nop 15\n\t"
+                       "s_cmp_eq_u32 %0, 2\n\ts_cbranch_scc1 1f\n\ts_nop 15\n1:" ::"s"(wave) : "scc");
+        __builtin_amdgcn_sched_barrier(0);
+      }
       mf(A, ah, bh);
       if (FORM == 1 && s == 0) {
         PIECE16(dst, v16, goff, 0);
@@ -85,7 +100,7 @@ __global__ __launch_bounds__(256) void dma_cost(const char* stream, int iters, f
         PIECE16(dst, v16, goff, 2048);
         PIECE16(dst, v16, goff, 3072);
       }
-      if (FORM == 3) {
+      if (FORM == 3 || FORM == 7 || FORM == 8 || FORM == 9) {
         if (s == 0) PIECE16(dst, v16, goff, 0);
         if (s == 2) PIECE16(dst, v16, goff, 1024);
         if (s == 4) PIECE16(dst, v16, goff, 2048);
@@ -146,7 +161,7 @@ static void run(int blocks, const char* stream, float* sink, uint64_t* d_cycles)
   const double per = sum / c.size() / (iters * 24.0);
   const double tflops = 2.0 * 32 * 32 * 16 * 24.0 * iters * 4.0 * blocks / ms * 1e-9;
   static const char* names[] = {"no copies", "4 x dwordx4 burst, M0 + offset per piece (round 5)", "4 x dwordx4 burst, one M0, immediate offsets",
-                                "4 x dwordx4, one per 6 MFMAs", "8 x dwordx2, one per 3 MFMAs", "16 x dword, two per 3 MFMAs", "4 x dwordx4 behind an MFMA pair"};
+                                "4 x dwordx4, one per 6 MFMAs", "8 x dwordx2, one per 3 MFMAs", "16 x dword, two per 3 MFMAs", "4 x dwordx4 behind an MFMA pair", "as 3 + s_barrier per chunk", "as 7 + wave w idles 8 w issue cycles", "as 7 + wave w idles 16 w issue cycles"};
   printf("form %d %-52s %d VALU / MFMA: %6.2f cycles / MFMA  %7.1f TFLOP/s  (%.2f ms)\n", FORM, names[FORM], F, per, tflops, ms);
   hipEventDestroy(e0); hipEventDestroy(e1);
 }
@@ -159,6 +174,9 @@ static void run_all(int blocks, const char* stream, float* sink, uint64_t* cyc) 
   run<3, F>(blocks, stream, sink, cyc);
   run<5, F>(blocks, stream, sink, cyc);
   run<6, F>(blocks, stream, sink, cyc);
+  run<7, F>(blocks, stream, sink, cyc);
+  run<8, F>(blocks, stream, sink, cyc);
+  run<9, F>(blocks, stream, sink, cyc);
 }
 
 int main() {
