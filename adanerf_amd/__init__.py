@@ -5,7 +5,7 @@ fallback: if the HIP library is missing or no GPU is present, construction fails
 """
 from .build import build_library, library_path  # noqa: F401
 from .renderer import (AdaNeRFError, NeuralRenderer, Settings, PREC_BF16, PREC_FP16, PREC_FP32,  # noqa: F401
-                       load_library)
+                       choose_sampling, load_library)
 
 __all__ = ["build_library", "library_path", "load_library", "NeuralRenderer", "Settings", "AdaNeRFError",
-           "PREC_BF16", "PREC_FP16", "PREC_FP32"]
+           "PREC_BF16", "PREC_FP16", "PREC_FP32", "choose_sampling"]

@@ -118,6 +118,13 @@ __device__ __forceinline__ void ws_piece(WStream<CF, RS, LPW, NR>& st, int i) { 
   const uint32_t far = i >= 4 ? 4096u : 0u;
   lds_ptr dst = (lds_ptr) static_cast<uintptr_t>(st.dma_lds + far);
   const int voff = static_cast<int>(st.lane_off), soff = static_cast<int>(st.dma_goff + far);
+  if (tune::kAblateDmaBytes) {      // timing ablation (wrong results): the same instructions moving a quarter of the bytes (4 per lane)
+    if ((i & 3) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 4, voff, soff, 0, 0);
+    else if ((i & 3) == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 4, voff, soff, 1024, 0);
+    else if ((i & 3) == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 4, voff, soff, 2048, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 4, voff, soff, 3072, 0);
+    return;
+  }
   // buffer form (buffer_load_dwordx4 ... lds): descriptor + wave-uniform byte offset in SGPRs, lane * 16 as the only VGPR operand
   if ((i & 3) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, voff, soff, 0, 0);
   else if ((i & 3) == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, dst, 16, voff, soff, 1024, 0);

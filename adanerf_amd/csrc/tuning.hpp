@@ -277,6 +277,13 @@ constexpr int kAblateSample = 0;
 #endif
 
 
+// kAblateDmaBytes: every LDS-DMA piece of the weight rings moves 4 instead of 16 bytes per lane (same instruction count, a quarter of the traffic)
+#if ADN_OVERRIDABLE && defined(ADN_ABLATE_DMA_BYTES)
+constexpr bool kAblateDmaBytes = ADN_ABLATE_DMA_BYTES != 0;
+#else
+constexpr bool kAblateDmaBytes = false;
+#endif
+
 // kAblateGeneric (run-time-shaped 16-bit kernels, k_generic16.hip.hpp; wrong results): 1 = the per-tile wait for the staged weights is skipped
 // (barrier only) -- the time the kernel would take if the copies always arrived in time, i.e. the most a deeper prefetch can buy;
 // 2 = no bias loads (accumulators start at 0); 3 = both

@@ -1,5 +1,6 @@
 #include "neuralrenderer.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -32,7 +33,7 @@ static adanerf_options options_of(const Settings& settings) {
   opt.batch_rays = static_cast<int32_t>(settings.batch_size);
   opt.num_samples = settings.num_samples;
   opt.threshold = settings.threshold;
-  opt.sampling_mode = settings.sampling == "split" ? ADANERF_SAMPLING_SPLIT_FP16 : (settings.sampling == "fp32" ? ADANERF_SAMPLING_FP32
+  opt.sampling_mode = (settings.sampling == "split" || settings.sampling == "auto") ? ADANERF_SAMPLING_SPLIT_FP16 : (settings.sampling == "fp32" ? ADANERF_SAMPLING_FP32
                       : (settings.sampling == "fp16" ? ADANERF_SAMPLING_FP16 : ADANERF_SAMPLING_GUARDED));
   opt.shard_world = 1;
   return opt;
@@ -50,6 +51,40 @@ bool NeuralRenderer::initHostOnly() {
   return true;
 }
 
+// --sampling auto: the default rule measured on the workload at hand -- a few frames of this model / frame size / threshold in the
+// split mode (exact by construction) and in the guarded mode (the same frames while its measured band holds), camera at the view-cell centre;
+// guarded only if it is at least 8 % faster here.  One context at a time, on GPU 0.
+static std::string measure_sampling_mode(const adanerf_options& base, const Settings& settings, const Camera& camera) {
+  double fps[2] = {0.0, 0.0};
+  const int modes[2] = {ADANERF_SAMPLING_SPLIT_FP16, ADANERF_SAMPLING_GUARDED};
+  for (int k = 0; k < 2; ++k) {
+    adanerf_options opt = base;
+    opt.sampling_mode = modes[k];
+    adanerf_ctx* c = nullptr;
+    if (adanerf_create(settings.model_path.c_str(), &opt, &c) != ADANERF_OK) break;      // no guarded mode for this model: split
+    adanerf_info info;
+    void* frame = nullptr;
+    float rot[9];
+    camera.getRotMatrix(rot);
+    bool ok = adanerf_get_info(c, &info) == ADANERF_OK && adanerf_malloc(c, static_cast<size_t>(info.rays_local_max) * 4, &frame) == ADANERF_OK &&
+              adanerf_set_camera(c, info.view_cell_center, rot) == ADANERF_OK;
+    const int warm = 2, frames = 6;
+    for (int i = 0; ok && i < warm; ++i) ok = adanerf_render(c, frame, nullptr, nullptr) == ADANERF_OK;
+    ok = ok && adanerf_sync(c) == ADANERF_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; ok && i < frames; ++i) ok = adanerf_render(c, frame, nullptr, nullptr) == ADANERF_OK;
+    ok = ok && adanerf_sync(c) == ADANERF_OK;
+    if (ok) fps[k] = frames / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (frame) adanerf_free(c, frame);
+    adanerf_destroy(c);
+    if (!ok) break;
+  }
+  const bool guarded = fps[0] > 0.0 && fps[1] >= 1.08 * fps[0];
+  std::cout << "--sampling auto: split " << fps[0] << " frames/s, guarded " << fps[1] << " frames/s -> " << (guarded ? "guarded" : "split")
+            << " (guarded only if >= 8 % faster on this workload)" << std::endl;
+  return guarded ? "guarded" : "split";
+}
+
 bool NeuralRenderer::init() {
   std::cout << "Model Path: " << settings.model_path << std::endl;
   adanerf_options opt;
@@ -61,6 +96,10 @@ bool NeuralRenderer::init() {
   opt.precision = settings.precision == "fp32" ? ADANERF_PREC_FP32 : (settings.precision == "fp16" ? ADANERF_PREC_FP16 : ADANERF_PREC_BF16);
   opt.num_samples = settings.num_samples;
   opt.threshold = settings.threshold;
+  opt.shard_world = 1;
+  opt.strip_rows = 8;
+  opt.flags |= ADANERF_FLAG_GUARD_AUDIT_FILL;
+  if (settings.sampling == "auto") settings.sampling = settings.precision == "fp32" ? std::string("split") : measure_sampling_mode(opt, settings, camera);
   opt.sampling_mode = settings.sampling == "split" ? ADANERF_SAMPLING_SPLIT_FP16 : (settings.sampling == "fp32" ? ADANERF_SAMPLING_FP32
                       : (settings.sampling == "fp16" ? ADANERF_SAMPLING_FP16 : ADANERF_SAMPLING_GUARDED));
   // --gpus N: rows are cut into strips, strip s belongs to (virtual) rank s % world; largest strip height <= 8 rows that

@@ -8,7 +8,7 @@
 const char* Settings::usage() {
   return "Usage: adanerf [modelPath] [-s|--size W H] [-ws|--windowSize W H] [-bs|--batchSize N]\n"
          "               [-nb|--numberOfBatches N] [-w|--writeImages] [-d|--debug]\n"
-         "               [--frames N] [--precision bf16|fp16|fp32] [--sampling guarded|split|fp32|fp16]\n"
+         "               [--frames N] [--precision bf16|fp16|fp32] [--sampling auto|guarded|split|fp32|fp16]\n"
          "               [--yaw DEG] [--pitch DEG]\n"
          "               [--samples N] [--threshold T] [--oracle]\n"
          "               [--script FILE] [--log-camera] [--dry-run]     input replay: one line of events per frame\n"
@@ -59,8 +59,8 @@ bool Settings::init(int argc, char** argv, std::string* err) {
     } else if (a == "--sampling") {
       if (!need(i, 1)) return false;
       sampling = argv[++i];
-      if (sampling != "guarded" && sampling != "split" && sampling != "fp32" && sampling != "fp16") {
-        *err = "--sampling must be guarded, split, fp32 or fp16";
+      if (sampling != "auto" && sampling != "guarded" && sampling != "split" && sampling != "fp32" && sampling != "fp16") {
+        *err = "--sampling must be auto, guarded, split, fp32 or fp16";
         return false;
       }
     } else if (a == "--yaw") {

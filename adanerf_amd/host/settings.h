@@ -14,7 +14,7 @@ class Settings {
   // headless extras (not in the reference)
   int frames = 100;             // --frames: frames to render before exiting
   std::string precision = "bf16";
-  std::string sampling;               // --sampling guarded|split|fp32|fp16: arithmetic of the sampling network (ADANERF_SAMPLING_*); the
+  std::string sampling;               // --sampling auto|guarded|split|fp32|fp16: arithmetic of the sampling network (ADANERF_SAMPLING_*; auto = the default rule measured on this workload at start-up); the
                                       // viewer itself has one (TensorRT kFP16 = "fp16"); "guarded" keeps the exact engine's selections while its
                                       // measured band holds.  Not given: split (exact by construction on every ray; DESIGN 1 has the rule)
   float yaw = -80.f, pitch = 0.f;   // Camera::init defaults (camera.cpp:90-91)

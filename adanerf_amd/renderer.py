@@ -27,6 +27,9 @@ FLAG_KEEP_ORACLE, FLAG_WAVE_SELECT, FLAG_NO_GUARD_CACHE, FLAG_GUARD_AUDIT_FILL =
 ABI_VERSION = 4
 GUARD_FROM = {0: "none", 1: "options", 2: "record", 3: "calibration", 4: "monitor"}
 SAMPLING_MODES = {"split": 0, "fp16x3": 0, "fp32": 1, "fp16": 2, "guarded": 3}
+# The default rule: the sampling mode that is exact by construction (split) unless the guarded mode is at least this much faster ON THE
+# WORKLOAD AT HAND -- choose_sampling() measures it; `sampling="auto"` / `adanerf --sampling auto` apply it.
+DEFAULT_RULE_MARGIN = 0.08
 
 
 class AdaNeRFError(RuntimeError):
@@ -201,6 +204,38 @@ def _ptr(x):
     return int(x)
 
 
+def choose_sampling(settings, pos=None, rot_c2w=None, precision="bf16", frames: int = 6, warmup: int = 2, margin: float = DEFAULT_RULE_MARGIN, **kw):
+    """The default rule per workload: renders `frames` frames of this model / frame size / threshold in the split mode (exact by construction) and in
+    the guarded mode (same frames while its measured band holds) and returns ("guarded" | "split", record): guarded only if it is >= margin faster
+    here.  pos / rot_c2w: the camera to measure with (default: view-cell centre, looking down -z).  A configuration the guarded mode does not
+    exist for (N > 16, run-time-shaped sampling networks, fp32) yields "split"."""
+    import time
+    fps, note = {}, None
+    for mode in ("split", "guarded"):
+        try:
+            with NeuralRenderer(settings, precision=precision, sampling=mode, **kw) as r:
+                p = np.asarray(pos if pos is not None else list(r.info.view_cell_center), np.float32)
+                m = np.asarray(rot_c2w if rot_c2w is not None else np.eye(3), np.float32)
+                r.set_camera(p, m)
+                out = r.empty((r.info.rays_local, 4), np.uint8)
+                for _ in range(warmup):
+                    r.render(out, None)
+                r.sync()
+                t0 = time.perf_counter()
+                for _ in range(frames):
+                    r.render(out, None)
+                r.sync()
+                fps[mode] = frames / (time.perf_counter() - t0)
+        except AdaNeRFError as e:
+            if mode == "split":
+                raise
+            note = "guarded mode not available: %s" % e
+    ahead = (fps["guarded"] / fps["split"] - 1.0) if "guarded" in fps else None
+    choice = "guarded" if (ahead is not None and ahead >= margin) else "split"
+    return choice, {"choice": choice, "split_fps": fps.get("split"), "guarded_fps": fps.get("guarded"), "guarded_ahead": ahead, "margin": margin,
+                    "frames": frames, "note": note}
+
+
 class NeuralRenderer:
     """Headless counterpart of the viewer's NeuralRenderer: ``init()`` loads the model directory and
     builds the device state, ``render()`` produces one frame."""
@@ -220,6 +255,13 @@ class NeuralRenderer:
         (ADANERF_FLAG_GUARD_AUDIT_FILL); False: exactly 1 / period of all rays every frame."""
         if sampling is None:
             sampling = "split"
+        self.sampling_choice = None
+        if sampling == "auto":      # the default rule applied to this model / frame size / threshold on this box, camera at the view-cell centre
+            if precision == "fp32" or _PREC.get(precision, precision) == _PREC["fp32"]:
+                sampling = "split"
+            else:
+                sampling, self.sampling_choice = choose_sampling(settings, precision=precision, device_id=device_id, num_samples=num_samples, threshold=threshold,
+                                                                 shard_rank=shard_rank, shard_world=shard_world, strip_rows=strip_rows, lib_path=lib_path)
         self.settings = settings
         self.lib = load_library(lib_path)
         self.handle = None

@@ -1012,23 +1012,27 @@ def test_bench_flop_models_match_the_survey_figures():
 
 
 def test_bench_watchdog_prints_the_line_it_has(tmp_path):
-    """bench.py's Watchdog: a run stuck in a collective still ends with ONE JSON line from rank 0 -- the render-only fallback with the
-    reason under config.exchange.error (exit 0), the finished record if there is one, or an error line with value null (exit 3); ranks
-    other than 0 leave quietly."""
+    """bench.py's Watchdog: a run stuck in a collective still ends with ONE JSON line from rank 0 -- the finished record if there is one (exit 0), else a
+    line with value null and the reason (exit 3; a render-only fall-back record keeps its null value: phase A's rate is not an N-GPU frames/s); ranks other
+    than 0 leave quietly.  Every phase gets the full time: setting `phase` re-arms the timer (a slow build does not eat the exchange's time)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prog = ("import sys, time; sys.path.insert(0, %r); import bench\n"
-            "d = bench.Watchdog(0.3, int(sys.argv[1])); d.phase = 'exchange pre-flight (gather)'\n"
-            "if sys.argv[2] == 'fallback': d.fallback = {'value': 5.0, 'config': {'exchange': {'error': None}}}\n"
+            "d = bench.Watchdog(0.6, int(sys.argv[1])); d.phase = 'exchange pre-flight (gather)'\n"
+            "if sys.argv[2] == 'fallback': d.fallback = {'value': None, 'render_only': {'value': 5.0}, 'config': {'exchange': {'error': None}}}\n"
             "if sys.argv[2] == 'record': d.record = {'value': 7.0, 'config': {}}\n"
+            "if sys.argv[2] == 'phases':\n"
+            "    for k in range(5): time.sleep(0.4); d.phase = 'phase %%d' %% k\n"
+            "    d.cancel(); print('survived'); sys.exit(0)\n"
             "time.sleep(5); print('not reached')\n") % root
     def run(rank, what):
         return subprocess.run([sys.executable, "-c", prog, str(rank), what], capture_output=True, text=True, timeout=60)
     a = run(0, "fallback")
     rec = json.loads(a.stdout.strip())
-    assert a.returncode == 0 and rec["value"] == 5.0 and "exchange pre-flight (gather)" in rec["config"]["exchange"]["error"]
+    assert a.returncode == 3 and rec["value"] is None and rec["render_only"]["value"] == 5.0 and "exchange pre-flight (gather)" in rec["config"]["exchange"]["error"] \
+        and "watchdog" in rec["error"]
     b = run(0, "record")
     rec = json.loads(b.stdout.strip())
     assert b.returncode == 0 and rec["value"] == 7.0 and "watchdog" in rec["notes"][0]
@@ -1036,6 +1040,8 @@ def test_bench_watchdog_prints_the_line_it_has(tmp_path):
     assert c.returncode == 3 and json.loads(c.stdout.strip())["value"] is None
     d = run(1, "fallback")
     assert d.returncode == 0 and d.stdout.strip() == ""
+    e = run(0, "phases")      # 5 x 0.4 s of progress under a 0.6 s per-phase limit
+    assert e.returncode == 0 and e.stdout.strip() == "survived"
 
 
 def test_bf16_scaling_bound_refuses_scenes_beyond_it(lib, tmp_path):
