@@ -37,11 +37,33 @@ struct PackedDev {
   NetParams params{};
 };
 
+// What bounds the sample positions the bf16 shading path's scaled layers may see (pack.hpp kPosIdentityBound): kept so that adanerf_set_camera can
+// check a pose outside the view cell (a free-fly viewer) instead of letting the clamped conversion cut activations silently.
+struct PosBound {
+  bool active = false;      // bf16 shading and not NDC
+  int normalize = 0;
+  double cmax = 0, zmax = 0, off = 0, M = 1, rad = 0;
+  double center[3] = {0, 0, 0};
+  // largest |encoded position| for a camera `dcam` away from the view-cell centre: the ray starts on (or, outside the cell, within dcam + rad of) the
+  // cell's sphere and runs zmax further along a unit direction
+  double at(double dcam) const {
+    const double reach = std::max(2.0 * rad, 2.0 * dcam + rad);
+    const double world = cmax + reach + zmax, local = reach + zmax + off;
+    if (normalize == kNormMaxDepth) return world / M;
+    if (normalize == kNormCentered) return local;
+    if (normalize == kNormMaxDepthCentered) return local / M;
+    if (normalize == kNormInverseSqrtDistCentered) return std::sqrt(local / M);
+    if (normalize != kNormNone) return local;      // InverseDistCentered (<= |l|), LogCentered (<= |l| for max_depth >= e - 1 ... kept loose)
+    return world;
+  }
+};
+
 }  // namespace
 
 struct adanerf_ctx {
   adanerf_options opt{};
   adanerf_info info{};
+  PosBound pos_bound;
   Config cfg;
   std::string err;
   hipStream_t stream = nullptr;       // stream in use
@@ -180,6 +202,7 @@ int upload_net(adanerf_ctx* c, const PackedNet& pn, PackedDev* d) {
 
 
 struct ModelSetup {
+  PosBound pos_bound;
   Config cfg;
   adanerf_info info{};
   RayGenParams rg{};
@@ -478,14 +501,17 @@ int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* m
       cmax = std::max<double>(cmax, std::fabs(cf.viewcellCenter[i]));
       off = std::max<double>(off, std::fabs(static_cast<double>(sp.center[i]) - cf.viewcellCenter[i]));
     }
-    const double world = cmax + 2.0 * rad + zmax, local = 2.0 * rad + zmax + off, M = std::max<double>(cf.max_depth, 1e-30);
-    double bound = world;
+    PosBound& pb = ms->pos_bound;
+    pb.active = !ndc;
+    pb.normalize = sp.normalize;
+    pb.cmax = cmax;
+    pb.zmax = zmax;
+    pb.off = off;
+    pb.M = std::max<double>(cf.max_depth, 1e-30);
+    pb.rad = rad;
+    for (int i = 0; i < 3; ++i) pb.center[i] = cf.viewcellCenter[i];
+    double bound = pb.at(0.5 * rad);      // a camera inside the view cell
     if (ndc) bound = 64.0;      // NDC cube [-1, 1]^3 for rays inside the frustum (positions o' + t d', t in [0, 1])
-    else if (sp.normalize == kNormMaxDepth) bound = world / M;
-    else if (sp.normalize == kNormCentered) bound = local;
-    else if (sp.normalize == kNormMaxDepthCentered) bound = local / M;
-    else if (sp.normalize == kNormInverseSqrtDistCentered) bound = std::sqrt(local / M);
-    else if (sp.normalize != kNormNone) bound = local;      // InverseDistCentered (<= |l|), LogCentered (<= |l| for max_depth >= e - 1 ... kept loose)
     if (!(bound <= kPosIdentityBound)) {
       char msg[256];
       std::snprintf(msg, sizeof(msg), "sample positions of this scene can reach %.3g after rayMarchNormalization: beyond the %.0f the bf16 shading path's "
@@ -1224,6 +1250,7 @@ int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ct
   c->sp = ms.sp;
   c->mult_mode = ms.mult_mode;
   c->transform = ms.transform;
+  c->pos_bound = ms.pos_bound;
   c->dm = ms.dm;
   c->fp0 = ms.fp0;
   c->fd0 = ms.fd0;
@@ -1448,6 +1475,19 @@ int adanerf_get_info(const adanerf_ctx* c, adanerf_info* info) {
 int adanerf_set_camera(adanerf_ctx* c, const float pos[3], const float rot[9]) {
   if (!c) return ADANERF_EINVAL;
   if (!pos || !rot) return fail(c, ADANERF_EINVAL, "pos/rot == NULL");
+  if (c->pos_bound.active) {
+    // bf16 shading: the layers were scaled for positions below kPosIdentityBound with the camera inside the view cell (setup_model); a pose far
+    // outside it (a free-fly viewer) is refused rather than rendered with activations cut by the clamped conversion
+    double d2 = 0.0;
+    for (int i = 0; i < 3; ++i) d2 += (pos[i] - c->pos_bound.center[i]) * (pos[i] - c->pos_bound.center[i]);
+    const double bound = c->pos_bound.at(std::sqrt(d2));
+    if (!(bound <= kPosIdentityBound)) {
+      char msg[256];
+      std::snprintf(msg, sizeof(msg), "camera %.3g away from the view-cell centre: sample positions can reach %.3g, beyond the %.0f the bf16 shading path's "
+                    "layer scaling assumes -- create the context with precision fp16 or fp32 for such poses", std::sqrt(d2), bound, kPosIdentityBound);
+      return fail(c, ADANERF_EUNSUPPORTED, msg);
+    }
+  }
   std::memcpy(c->rg.pos, pos, 3 * sizeof(float));
   std::memcpy(c->rg.rot, rot, 9 * sizeof(float));
   return ADANERF_OK;

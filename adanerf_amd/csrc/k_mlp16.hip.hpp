@@ -574,8 +574,8 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
   constexpr int PER = (KS >= 8) ? 1 : (8 + KS - 1) / KS;      // epilogue quads of the previous tile per k-step
   constexpr bool kCarry = tune::kShadeCarry && !(ABL & 8);
   constexpr bool kHasPend = kCarry && PEND_M >= 0;
-  constexpr int PERP = (KS >= 16) ? 1 : 2;                    // quads of a carried tile per k-step: all converted before the k-steps that read them
-  static_assert(!kHasPend || KS >= 8, "a carried tile is consumed by the last two k-steps of a segment of >= 8");
+  constexpr int PERP = 1;                                     // quads of a carried tile per k-step: all converted before the k-steps that read them
+  static_assert(!kHasPend || KS >= 16, "a carried tile is consumed by the last two k-steps of a 16-k-step input segment, 6 k-steps behind its last conversion");
   static_assert(!CARRY_OUT || KEEP_F32_TILE != MT - 1, "the kept tile is not converted");
   // LDS reads issued between a bias request and its use: the tile's KS fragment re-fills (none under ablation 2)
   constexpr bool kCounted = tune::kBiasWaitCounted && tune::kSchedGroups && !tune::kBiasPlain && !(ABL & (2 | 4));
@@ -749,10 +749,12 @@ __global__ __launch_bounds__(256) void shade_mlp16x2_kernel(ShadeArgs a) {
       uint32_t d0[QD / 2], d1[QD / 2];
       lds_stash_read<QD / 8>(stash + (QP / 8) * 1024, d0);
       lds_stash_read<QD / 8>(stash + kStashPerBlock + (QP / 8) * 1024, d1);
-      layer_16x2<ET, WS, 16, QD / 8, 4, true, (32 + 4 * 128 + 160 + 2 * 128 + 144) % CF, -1, -1, true, true>(st, bias0 + bo[9] * 4, hA0, d0, hA1, d1, hB0, hB1, pend);   // cat([feature, dir])
+      layer_16x2<ET, WS, 16, QD / 8, 4, true, (32 + 4 * 128 + 160 + 2 * 128 + 144) % CF>(st, bias0 + bo[9] * 4, hA0, d0, hA1, d1, hB0, hB1, pend);   // cat([feature, dir])
     }
     f32x16 rgb0, rgb1;
-    layer_16x2<ET, WS, 8, 0, 1, false, (32 + 4 * 128 + 160 + 2 * 128 + 144 + 72) % CF, 0, 3, true, false>(st, bias0 + bo[10] * 4, hB0, hB0, hB1, hB1, hA0, hA1, pend, hB0, hB1, &rgb0, &rgb1);
+    // (the view layer's last tile is NOT carried into the 8-k-step colour layer: hipcc sinks the conversions to one wait state in front of the MFMAs
+    // that read them -- tests/test_host_cpu.py test_asm_conversions_are_two_wait_states_ahead_of_the_mfma_that_reads_them)
+    layer_16x2<ET, WS, 8, 0, 1, false, (32 + 4 * 128 + 160 + 2 * 128 + 144 + 72) % CF, 0>(st, bias0 + bo[10] * 4, hB0, hB0, hB1, hB1, hA0, hA1, pend, nullptr, nullptr, &rgb0, &rgb1);
     if (h == 0 && s0 < total)
       store_raw(a, s0, rgb0[0], rgb0[1], rgb0[2], alpha0[0]);
     if (h == 0 && s1 < total)

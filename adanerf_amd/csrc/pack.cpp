@@ -135,6 +135,9 @@ int pad_width(int w) { return w <= 64 ? 64 : (w <= 128 ? 128 : (w <= 256 ? 256 :
 // choose: the output exponent e becomes the smallest with bound 2^-e <= 1 (ReLU layers: the kernel's clamped conversion must never
 // clamp); else it is given (layers without an activation keep their input's exponent).  Weights and bias are rescaled in place by exact
 // powers of two -- w_rc 2^(ce[c] - e), b_r 2^-e -- so the packed layer computes y 2^-e with the roundings of the unscaled one.
+// Returns a negative value when no exponent within +-kMaxScaleExp brings the bound under 1 (or the bound is not finite): the clamped conversion would
+// then cut real activations, so the caller refuses the bf16 packing of this network (never a silent clamp).
+constexpr int kMaxScaleExp = 100;
 double scale_layer(VLayer* L, const std::vector<double>& cb, const std::vector<int>& ce, bool choose, int* e) {
   double bound = 0.0;
   for (int r = 0; r < L->rows; ++r) {
@@ -143,10 +146,11 @@ double scale_layer(VLayer* L, const std::vector<double>& cb, const std::vector<i
     bound = std::max(bound, s);
   }
   bound *= 1.03125;
+  if (!(bound < 1e300)) return -1.0;      // inf / NaN weights
   if (choose) {
     *e = bound > 0.0 ? static_cast<int>(std::ceil(std::log2(bound))) : 0;
-    if (*e > 100) *e = 100;      // (a network whose bound leaves the fp32 range has no finite outputs to protect)
-    if (*e < -100) *e = -100;
+    if (*e > kMaxScaleExp) return -1.0;      // the bound is loose by construction (products of L1 row norms): beyond this range it proves nothing any more
+    if (*e < -kMaxScaleExp) *e = -kMaxScaleExp;      // a (near-)zero layer: scaling UP less than possible is always safe
   }
   for (int r = 0; r < L->rows; ++r) {
     L->b[r] = std::ldexp(L->b[r], -*e);
@@ -218,6 +222,8 @@ int count_layers(const TensorMap& m, const std::string& prefix) {
   return n;
 }
 
+const std::string kScaleRefused = "shading net (bf16): the activation bound of a layer leaves the range the scaled packing can prove anything in (2^100): "
+                                  "use fp16 / fp32 shading for this network; layer ";
 bool fail(std::string* err, const std::string& msg) {
   if (err) *err = msg;
   return false;
@@ -356,6 +362,7 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
         ce.insert(ce.end(), Wr, h_exp);
       }
       h_bound = scale_layer(&L, cb, ce, true, &h_exp);
+      if (h_bound < 0.0) return fail(err, kScaleRefused + ("pts_linears." + std::to_string(i)));
     }
     emit(L, elem, out);
   }
@@ -379,6 +386,7 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
       const std::vector<int> ce(Wr, h_exp);
       int e = h_exp;
       f_bound = scale_layer(&L, cb, ce, false, &e);
+      if (f_bound < 0.0) return fail(err, kScaleRefused + std::string("feature_linear"));
       out->out_exp[0] = h_exp;
     }
     emit(L, elem, out);
@@ -401,6 +409,7 @@ bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, Pack
       std::vector<int> ce(Wr, h_exp);
       pe_col_scale(n_dir, kDirIdentityBound, &cb, &ce);
       v_bound = scale_layer(&L, cb, ce, true, &v_exp);
+      if (v_bound < 0.0) return fail(err, kScaleRefused + std::string("views_linears.0"));
     }
     emit(L, elem, out);
   }

@@ -255,7 +255,11 @@ int adanerf_struct_sizes(int32_t sizes_out[3]);
 /* ---- per frame ---------------------------------------------------------------------------- */
 
 /* pos: camera position (world).  rot_c2w: row-major 3x3 camera-to-world rotation; camera looks
- * along -z, +y up (the convention of src/util/raygeneration.py:24-25). */
+ * along -z, +y up (the convention of src/util/raygeneration.py:24-25).
+ * ADANERF_PREC_BF16 contexts: the shading network's layers are scaled for sample positions the scene can produce with the camera in or
+ * near its view cell (adanerf_create refuses a scene beyond that range).  A pose so far outside the cell that positions could leave the range
+ * returns ADANERF_EUNSUPPORTED and leaves the previous camera in place -- render such poses with an fp16 / fp32 context.  NDC scenes
+ * (useNDC) assume rays inside the frustum of the recorded cameras (positions in the NDC cube); that is not checked per pose. */
 int adanerf_set_camera(adanerf_ctx* ctx, const float pos[3], const float rot_c2w[9]);
 
 /* Renders this context's rays.  d_rgba8_out: [rays_local] uchar4 (A=255), row-major over the shard's

@@ -1239,6 +1239,31 @@ def test_headless_cli_matches_library(cases, tmp_path):
     assert diff.max() <= 1 and (diff == 0).mean() > 0.99     # the CLI builds its rotation in float64 -> a few LSB flips
 
 
+def test_bf16_context_refuses_a_camera_beyond_its_position_bound(cases, tmp_path):
+    """adanerf_set_camera on a bf16 context: a pose so far outside the view cell that sample positions could leave the range the scaled layers were
+    packed for is refused (EUNSUPPORTED, previous camera kept, frame unchanged) -- never rendered with clamped activations; an fp16 context takes it."""
+    import dataclasses
+    z, meta, sc, wts, d = cases["classroom_n8_thr02"]
+    sc = dataclasses.replace(sc, normalization="None")      # un-normalised positions (the shipped InverseSqrtDistCentered compresses any pose into range)
+    md = str(tmp_path / "model")
+    O.write_model_dir(md, sc, wts)
+    pose = np.array(sc.view_cell_center, dtype=np.float32)
+    rot = O.camera_rotation(100.0, 0.0)
+    far = pose + np.array([1.0e4, 0.0, 0.0], np.float32)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, 64, 48), precision="bf16") as r:
+        r.set_camera(pose, rot)
+        _, a, _ = r.render_numpy()
+        r.set_camera(pose + np.array([3.0, 0.0, 0.0], np.float32), rot)      # a free-fly pose a few cell sizes out: fine
+        r.set_camera(pose, rot)
+        with pytest.raises(adanerf_amd.AdaNeRFError, match="view-cell centre"):
+            r.set_camera(far, rot)
+        _, b, _ = r.render_numpy()
+        assert np.array_equal(a, b)
+    with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, 64, 48), precision="fp16") as r:
+        r.set_camera(far, rot)
+        r.render_numpy()
+
+
 def test_sampling_auto_applies_the_default_rule_per_workload(cases, tmp_path):
     """--sampling auto (both hosts): the default rule measured on the workload at hand -- a few frames in the split mode (exact by construction) and in
     the guarded mode; guarded only if it is >= 8 % faster.  Whatever it picks, the frame is the split mode's frame (the guarded mode keeps the exact

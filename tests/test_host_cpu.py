@@ -197,6 +197,44 @@ def test_every_inline_asm_conversion_is_behind_its_accumulators_guard():
     assert checked > 1000      # 832 in the 8 x 256 kernel alone
 
 
+def test_asm_conversions_are_two_wait_states_ahead_of_the_mfma_that_reads_them():
+    """The other edge of the inline-asm conversion: `v_cvt_pk_bf16_f32 ... clamp` is a VALU write the hazard recogniser cannot see, and
+    its result is the B operand of the next layer's MFMAs -- a VALU write followed by an MFMA read of the register needs 2 wait states on gfx9 matrix
+    cores, which hipcc inserts for compiler-visible VALU only.  On the assembly: between every clamped conversion and the first v_mfma that reads its
+    destination VGPR there are at least 2 wait states (an instruction counts 1, `s_nop N` counts N + 1)."""
+    text = _device_assembly()
+    if text is None:
+        pytest.skip("no hipcc")
+    checked, closest = 0, 10 ** 9
+    rng = re.compile(r"v\[(\d+):(\d+)\]")
+    for k in re.split(r"\n\s*\.globl\s+", text):
+        if "clamp" not in k:
+            continue
+        lines = [ln for ln in k.split("\n") if re.match(r"\s+[a-z]", ln)]
+        for i, ln in enumerate(lines):
+            m = re.match(r"\s+v_cvt_pk_bf16_f32 v(\d+), v\d+, v\d+ clamp", ln)
+            if not m:
+                continue
+            d, states = int(m.group(1)), 0
+            for nxt in lines[i + 1:i + 400]:
+                ops = nxt.split(None, 1)
+                args = ops[1] if len(ops) > 1 else ""
+                if ops[0].startswith("v_mfma"):
+                    srcs = args.split(",", 1)[1] if "," in args else ""      # everything behind the destination
+                    if any(int(a) <= d <= int(b) for a, b in rng.findall(srcs)):
+                        assert states >= 2, "an MFMA reads v%d %d wait state(s) behind its clamped conversion in %s" % (d, states, lines[0][:80])
+                        closest = min(closest, states)
+                        checked += 1
+                        break
+                # any other instruction that overwrites or consumes the register ends the search (a compiler-visible reader is padded by hipcc)
+                if re.search(r"\bv%d\b" % d, args) or any(int(a) <= d <= int(b) for a, b in rng.findall(args)):
+                    break
+                sn = re.match(r"\s+s_nop (\d+)", nxt)
+                states += int(sn.group(1)) + 1 if sn else 1
+    assert checked > 300, checked
+    print("closest clamped conversion -> MFMA read: %d wait states over %d pairs" % (closest, checked))
+
+
 def test_counted_bias_waits_have_enough_younger_lds_reads():
     """A tile's bias block is requested a tile ahead by hand-issued ds_read_b128 (k_mlp16.hip.hpp lds_bias_issue) and taken behind
     `s_waitcnt lgkmcnt(N)` with N > 0 (lds_bias_take<YOUNGER>): LDS returns in order, so "at most N operations outstanding" proves the block
@@ -1091,6 +1129,25 @@ def test_scaled_bf16_packing_is_exact(lib, tmp_path):
             a, b = (run_shading_net_generic(q, x, d, depth, pad_to(shape[1]), skips) for q in (ns, nu))
         assert np.isfinite(a).all() and np.array_equal(a, b), (name, float(np.abs(a - b).max()))
         assert 0.0 < ns.max_relu_out <= 1.0
+
+
+def test_scaled_bf16_packing_refuses_a_bound_beyond_its_range(lib, tmp_path):
+    """pack.cpp scale_layer: the per-layer activation bound is a product of L1 row norms and is loose by construction; when it leaves 2^100 the
+    scaled packing can prove nothing about what the clamped conversion would cut, so a bf16 shading net like that is REFUSED with a message (it used
+    to clamp the exponent silently: ADVICE round 5) -- the same network still packs for fp16 and unscaled (host hook precision 4)."""
+    z, meta, sc = load_case("classroom_n8_thr02")
+    wts = O.synthetic_weights(21)
+    big = {k: (v * np.float32(3.0e4) if k.startswith("pts_linears.") and k.endswith(".weight") else v) for k, v in wts.net1.items()}
+    import dataclasses
+    md, _, _ = _model_dir(tmp_path, sc, dataclasses.replace(wts, net1=big), name="hugebound")
+    f = lib.adanerf_host_pack_weights
+    f.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_int32)]
+    f.restype = C.c_int
+    wb, bf, nl = C.c_size_t(0), C.c_size_t(0), C.c_int32(0)
+    rc = f(md.encode(), 1, 0, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl))
+    assert rc != 0 and b"activation bound" in lib.adanerf_last_error(None) and b"pts_linears." in lib.adanerf_last_error(None), lib.adanerf_last_error(None)
+    for prec in (1, 4):      # fp16; bf16 without the scaling
+        assert f(md.encode(), 1, prec, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl)) == 0, lib.adanerf_last_error(None)
 
 
 def pad_to(w):
