@@ -15,7 +15,9 @@ namespace adanerf {
 // kSplitScale (2^11) is defined in pack.hpp
 
 
-// Three bit-identical forms (v - hi is exact in fp32, and so is its product with 2^11; tune::kSplitPack, profiles/r05_lab_log.md):
+// Three forms (v - hi is exact in fp32, and so is its product with 2^11; tune::kSplitPack, profiles/r05_lab_log.md).  0 and 1 are bit-identical; the
+// v_fma_mix forms (2, and a compiler-visible v_fma_mixlo / mixhi variant tried in round 6) round a SUBNORMAL lo' differently from v_cvt_pk_f16_f32 and fail
+// the NDC fixture (profiles/r06_variants_split_pack3.log) -- and are no faster:
 //  0  packed fp32 (v_pk_add_f32 + v_pk_mul_f32 on the pair): 6 instructions, two of them packed-fp32 ops inside an MFMA stream
 //  1  the same with scalar fp32 ops: 8 instructions
 //  2  v_fma_mix: the fp16 halves of hi are read as fp16 operands (no v_cvt_f32_f16), the scaled residual is rounded to fp16 by

@@ -448,7 +448,10 @@ __device__ __forceinline__ void pair_epilogue(const float* x_raw, int lane, int 
     }
     return;
   }
-  pair_emit(x, lo, hi, h, stage, valid, static_cast<size_t>(local) * so.n_max, so.selbin, so.selw);
+  // (tune::kAblateSample & 2048: timing ablation without the rows.  Round 6 priced pair_emit at 0.024 of the kernel's 1.21 ms this way, but neither
+  // fetching the staged values eight at a time (one LDS wait per pass) nor writing the rows through an LDS tile with two full-wave stores instead of up
+  // to 32 partial ones moved the kernel: profiles/r06_variants_emit_ablation.log, _emit2.log, _emit_tile.log.  The simple form stays.)
+  if (!(tune::kAblateSample & 2048)) pair_emit(x, lo, hi, h, stage, valid, static_cast<size_t>(local) * so.n_max, so.selbin, so.selw);
   int t = (valid && h == 0) ? total : 0;
   if (valid && h == 0) so.counts[local] = total;
   t = wave_sum_dpp_i32(t);      // lanes 0..31 hold the rays, lanes 32..63 contribute 0

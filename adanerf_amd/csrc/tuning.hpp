@@ -263,7 +263,7 @@ constexpr int kSelRaysPerBlock = 64;
 //  16: boundary without the DMA issue                   32: boundary without wait + barrier
 //  64: (sampling kernel) no cross-tile software pipeline of bias reads / epilogue
 // 128: (sampling kernels) v_sin_f32 instead of the libm-grade sincosf in the oracle-feature encoding   256: (sampling kernels) no encoding at all
-// 512: (split sampling kernel) no selection epilogue
+// 512: (split sampling kernel) no selection epilogue   2048: (fused selection) the kept (bin, value) rows are not written (pair_emit skipped)
 // kAblateShade applies to shade_mlp16_kernel, kAblateSample to sample_mlp16x3_kernel.
 #if ADN_OVERRIDABLE && defined(ADN_ABLATE)
 constexpr int kAblateShade = ADN_ABLATE;
