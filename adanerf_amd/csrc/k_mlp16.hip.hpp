@@ -578,7 +578,7 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
   static_assert(!kHasPend || KS >= 16, "a carried tile is consumed by the last two k-steps of a 16-k-step input segment, 6 k-steps behind its last conversion");
   static_assert(!CARRY_OUT || KEEP_F32_TILE != MT - 1, "the kept tile is not converted");
   // LDS reads issued between a bias request and its use: the tile's KS fragment re-fills (none under ablation 2)
-  constexpr bool kCounted = tune::kBiasWaitCounted && tune::kSchedGroups && !tune::kBiasPlain && !(ABL & (2 | 4));
+  constexpr bool kCounted = tune::kBiasWaitCounted && tune::kSchedGroups && !(ABL & (2 | 4));
   constexpr int kYounger = kCounted ? KS : 0;
   BiasRegs br;
   f32x16 pA, pB;
@@ -587,7 +587,7 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
     pA = pend.a;
     pB = pend.b;
   }
-  if (!(ABL & 4) && !tune::kBiasPlain) lds_bias_issue(bias_addr, br, st.rd_cur, st.rd_next);
+  if (!(ABL & 4)) lds_bias_issue(bias_addr, br, st.rd_cur, st.rd_next);
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     f32x16 bias, accA, accB;
@@ -595,15 +595,6 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
     if (ABL & 4) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) bias[r] = 0.f;
-    } else if (tune::kBiasPlain) {
-      // compiler-visible LDS loads: hipcc counts them in its own lgkmcnt ladder (no full drain in front of a tile) and is
-      // free to issue them early
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const u32x4 t = lds_read128(bias_addr + m * 128 + 16 * g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bias[4 * g + e] = __builtin_bit_cast(float, t[e]);
-      }
     } else {
       if (m == 0) lds_bias_take<0>(br, &bias);              // first tile of the layer: issued just now
       else lds_bias_take<kYounger>(br, &bias);

@@ -15,36 +15,17 @@ namespace adanerf {
 // kSplitScale (2^11) is defined in pack.hpp
 
 
-// Three forms (v - hi is exact in fp32, and so is its product with 2^11; tune::kSplitPack, profiles/r05_lab_log.md).  0 and 1 are bit-identical; the
-// v_fma_mix forms (2, and a compiler-visible v_fma_mixlo / mixhi variant tried in round 6) round a SUBNORMAL lo' differently from v_cvt_pk_f16_f32 and fail
-// the NDC fixture (profiles/r06_variants_split_pack3.log) -- and are no faster:
-//  0  packed fp32 (v_pk_add_f32 + v_pk_mul_f32 on the pair): 6 instructions, two of them packed-fp32 ops inside an MFMA stream
-//  1  the same with scalar fp32 ops: 8 instructions
-//  2  v_fma_mix: the fp16 halves of hi are read as fp16 operands (no v_cvt_f32_f16), the scaled residual is rounded to fp16 by
-//     v_fma_mixlo / mixhi (no v_cvt_pk): 5 instructions, none packed
+// hi = fp16(v), lo' = fp16((v - hi) * 2^11): v - hi is exact in fp32, and so is its product with 2^11.  Scalar arithmetic with compiler-visible
+// conversions (8 instructions per pair; the library is built with -fno-slp-vectorize, so nothing re-packs the two chains into v_pk_*_f32, and there is
+// no inline asm between MFMAs and their consumers: the hazard recogniser does not look inside asm -- k_mlp16.hip.hpp mfma_guard).  Forms measured and
+// dropped: packed fp32 (round 5: same speed, and the library holds no packed-fp32 VALU since), v_fma_mix / v_fma_mixlo (rounds 5 / 6: 5-7 instructions,
+// not faster, and they round a SUBNORMAL lo' differently from v_cvt_pk_f16_f32: the NDC fixture fails -- profiles/r06_variants_split_pack3.log).
 __device__ __forceinline__ void split_pack(float v0, float v1, uint32_t* hi, uint32_t* lo) {
-  f32x2 v = {v0, v1};
-  f16x2 h = __builtin_convertvector(v, f16x2);
+  const f32x2 v = {v0, v1};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
   *hi = __builtin_bit_cast(uint32_t, h);
-  if (tune::kSplitPack == 2) {
-    const uint32_t hb = __builtin_bit_cast(uint32_t, h);
-    float d0, d1;
-    uint32_t l;
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(d0) : "v"(v0), "v"(hb));
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d1) : "v"(v1), "v"(hb));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l) : "v"(d0), "s"(kSplitScale));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l) : "v"(d1), "s"(kSplitScale));
-    *lo = l;
-  } else if (tune::kSplitPack == 1) {
-    // scalar arithmetic, compiler-visible conversion (the library is built with -fno-slp-vectorize, so nothing re-packs the two chains; no
-    // inline asm between MFMAs and their consumers: the hazard recogniser does not look inside asm -- k_mlp16.hip.hpp mfma_guard)
-    const f32x2 r = {(v0 - static_cast<float>(h[0])) * kSplitScale, (v1 - static_cast<float>(h[1])) * kSplitScale};
-    *lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
-  } else {
-    f32x2 hf = __builtin_convertvector(h, f32x2);
-    f32x2 r = (v - hf) * kSplitScale;
-    *lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
-  }
+  const f32x2 r = {(v0 - static_cast<float>(h[0])) * kSplitScale, (v1 - static_cast<float>(h[1])) * kSplitScale};
+  *lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
 }
 
 // One layer, fragments arrive as (hi, lo') pairs per k-step.  FPOS: first fragment position mod the chunk size.
@@ -114,16 +95,12 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
       acc = Fp16::mfma(st.R[f % WS::kRegs], bh, acc);
       cross = Fp16::mfma(st.R[f % WS::kRegs], bl, cross);
       cross = Fp16::mfma(st.R[(f + 1) % WS::kRegs], bh, cross);
-      if (tune::kSplitRefillSwap) {
-        ws_refill<tune::kAblateSample>(st, f + 1);
-        ws_refill<tune::kAblateSample>(st, f);
-      } else {
-        ws_refill<tune::kAblateSample>(st, f);
-        ws_refill<tune::kAblateSample>(st, f + 1);
-      }
+      ws_refill<tune::kAblateSample>(st, f);
+      ws_refill<tune::kAblateSample>(st, f + 1);
       if (PIPE && !(tune::kAblateSample & 8) && (m > 0 || (HAS_PEND && CARRY))) {
-        // the 8 pairs of the previous tile, spread over the k-steps from E0 on (PER per k-step)
-        constexpr int E0 = (KS > tune::kSplitEpiStart + 1) ? tune::kSplitEpiStart : 0;
+        // the 8 pairs of the previous tile, spread over the k-steps from E0 = 1 on (PER per k-step): the first k-step keeps the MFMA -> VALU wait
+        // states of the previous tile's last MFMAs out of the stream
+        constexpr int E0 = KS > 2 ? 1 : 0;
         constexpr int PER = (KS - E0 >= 8) ? 1 : (8 + (KS - E0) - 1) / (KS - E0);
 #pragma unroll
         for (int k = 0; k < PER; ++k) {

@@ -177,12 +177,7 @@ constexpr bool kShadeCarry = ADN_SHADE_CARRY != 0;
 #else
 constexpr bool kShadeCarry = true;
 #endif
-// bias blocks through compiler-visible LDS loads / the k-step interleave pinned with sched_group_barrier (layer_16x2)
-#if ADN_OVERRIDABLE && defined(ADN_BIASPLAIN)
-constexpr bool kBiasPlain = ADN_BIASPLAIN != 0;
-#else
-constexpr bool kBiasPlain = false;
-#endif
+// the k-step interleave pinned with sched_group_barrier (layer_16x2; bias blocks through compiler-visible LDS loads were measured slower in round 3 and are gone)
 #if ADN_OVERRIDABLE && defined(ADN_SGB)
 constexpr bool kSchedGroups = ADN_SGB != 0;
 #else
@@ -204,29 +199,13 @@ constexpr int kRegFrags2 = ADN_NR2;
 constexpr int kRegFrags2 = 16;
 #endif
 
-// split_pack form of the split-precision engines' epilogue (k_sampling16.hip.hpp): 0 packed fp32, 1 scalar fp32, 2 v_fma_mix.  Bit-identical;
-// measured the same within noise (profiles/r05_variants_slp_splitpack.log: split-on-every-ray sampling stage 1.293 / 1.291 / 1.336 ms).  Shipped: 1,
-// so that the device code holds no packed-fp32 instruction at all (build.py HIPCC_FLAGS, tools/probes/pk_mul_fault/).
-#if ADN_OVERRIDABLE && defined(ADN_SPLIT_PACK)
-constexpr int kSplitPack = ADN_SPLIT_PACK;
-#else
-constexpr int kSplitPack = 1;
-#endif
-
 // Split engine, k-step details (k_sampling16.hip.hpp layer_16x3):
-//  kSplitRefillSwap  the lo' fragment register is re-filled before the hi one: LDS returns in order, so the wait in front of the k-step's first
-//                    MFMA (which reads hi, the younger request) covers both -- one s_waitcnt per k-step instead of two
-//  kSplitEpiStart    first k-step of tile m that carries a pair of tile m - 1's epilogue: 1 keeps the MFMA -> VALU wait states of the previous
-//                    tile's last MFMAs out of the stream (0: an s_nop 10 per tile)
-#if ADN_OVERRIDABLE && defined(ADN_REFILL_SWAP)
-constexpr bool kSplitRefillSwap = ADN_REFILL_SWAP != 0;
-#else
-constexpr bool kSplitRefillSwap = false;
-#endif
-//  kSplitBiasCounted the wait in front of a tile's bias block (requested a tile earlier) is lgkmcnt(15) instead of a full drain: the tile's own
-//                    2 KS >= 15 fragment re-fills were issued behind the request (one scheduling region per tile: needs kSchedGroupsSampling)
-//                    and LDS returns in order, so at most 15 outstanding operations means the bias block has arrived
+//  kSplitBiasCounted the wait in front of a tile's bias block (requested a tile earlier) is lgkmcnt(min(15, 2 KS)) instead of a full drain: the tile's
+//                    own 2 KS fragment re-fills were issued behind the request (one scheduling region per tile: needs kSchedGroupsSampling; the request
+//                    carries the re-fill addresses as operands) and LDS returns in order -- tests/test_host_cpu.py counts them on the assembly
 //  kSplitCarry       the last output tile of a hidden layer is converted under the MFMAs of the NEXT layer's first tile (PendingTile3)
+// (measured in round 6 and not kept as knobs: re-filling the lo' fragment register first so that one wait covers both -- no effect; the first k-step of a
+// tile that carries a pair of the previous tile's epilogue -- 1, fixed; profiles/r06_variants_ring_2.log)
 #if ADN_OVERRIDABLE && defined(ADN_SPLIT_CARRY)
 constexpr bool kSplitCarry = ADN_SPLIT_CARRY != 0;
 #else
@@ -236,11 +215,6 @@ constexpr bool kSplitCarry = true;
 constexpr bool kSplitBiasCounted = ADN_BIASWAIT_S != 0;
 #else
 constexpr bool kSplitBiasCounted = true;
-#endif
-#if ADN_OVERRIDABLE && defined(ADN_EPI_START)
-constexpr int kSplitEpiStart = ADN_EPI_START;
-#else
-constexpr int kSplitEpiStart = 1;
 #endif
 
 // ---- selection (k_select_pair.hip.hpp, k_compact.hip.hpp)
