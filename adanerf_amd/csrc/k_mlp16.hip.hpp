@@ -642,6 +642,11 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // VALU
+        // The clamped conversions are inline asm: no group mask matches them, so they float -- and hipcc sinks them to ONE wait state in front of the
+        // MFMA that reads their result (a VALU write the hazard recogniser cannot see needs 2: tests/test_host_cpu.py
+        // test_asm_conversions_are_two_wait_states_ahead_of_the_mfma_that_reads_them caught a carried tile's conversions there).  A scheduling barrier per
+        // k-step keeps every conversion in the k-step the source puts it in, k-steps away from its first reader.
+        if (tune::kShadeKstepFence) __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (KEEP_F32_TILE == m) {

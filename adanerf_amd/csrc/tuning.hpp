@@ -156,18 +156,24 @@ constexpr int kShadeBlocks = 2;
 #if ADN_OVERRIDABLE && defined(ADN_CF2)
 constexpr int kChunkFrags2 = ADN_CF2;
 #else
-constexpr int kChunkFrags2 = 16;
+constexpr int kChunkFrags2 = 32;      // round 6: 32 fragments x 3 slots (a barrier every 64 MFMAs, the 8 pieces in the first half of a chunk): 3.52 -> 3.48 ms
 #endif
 #if ADN_OVERRIDABLE && defined(ADN_RS2)
 constexpr int kRingSlots2 = ADN_RS2;
 #else
-constexpr int kRingSlots2 = 6;
+constexpr int kRingSlots2 = 3;
 #endif
 // counted lgkmcnt wait in front of a tile's bias block instead of a full drain (layer_16x2)
 #if ADN_OVERRIDABLE && defined(ADN_BIASWAIT)
 constexpr bool kBiasWaitCounted = ADN_BIASWAIT != 0;
 #else
 constexpr bool kBiasWaitCounted = true;      // round 6: the request carries the re-fill addresses as operands (lds_bias_issue), one scheduling region per tile
+#endif
+// kShadeKstepFence: a scheduling barrier behind every k-step of layer_16x2 (the inline-asm conversions stay in their k-step)
+#if ADN_OVERRIDABLE && defined(ADN_KSTEP_FENCE)
+constexpr bool kShadeKstepFence = ADN_KSTEP_FENCE != 0;
+#else
+constexpr bool kShadeKstepFence = true;
 #endif
 // kShadeCarry: the last tile of a shading layer is converted under the first tile of the next layer (layer_16x2, PendingTile2).
 // (Requesting the next layer's first bias block a layer ahead, so that the wait at a layer boundary is counted too, was measured and dropped:
