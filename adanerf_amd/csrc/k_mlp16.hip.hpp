@@ -610,26 +610,30 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
       accA = ET::mfma(st.R[f % WS::kRegs], ba, s == 0 ? bias : accA);
       accB = ET::mfma(st.R[f % WS::kRegs], bb, s == 0 ? bias : accB);
       ws_refill<ABL>(st, f);
-      if (m > 0 && KEEP_F32_TILE != m - 1 && !(ABL & 8)) {
-        if (s == 0) {      // the previous tile's guards, taken HERE: its last MFMAs are a k-step behind, so the read costs no wait states
+      // The previous tile's guards are taken in k-step E0: with a scheduling fence per k-step (below) a guard in k-step 0 sits right behind the tile's
+      // first MFMA, one or two MFMAs after the accumulator's last write, and costs an `s_nop 6` per tile (hipcc counts an MFMA as ONE wait state of the 11 it
+      // wants between the write and a VALU read); tune::kShadeGuardStep k-steps later the distance is there by itself.
+      constexpr int E0 = (tune::kShadeKstepFence && KS >= 8 + tune::kShadeGuardStep) ? tune::kShadeGuardStep : 0;
+      if (m > 0 && KEEP_F32_TILE != m - 1 && !(ABL & 8) && s >= E0) {
+        if (s == E0) {
           gA = mfma_guard<ET, RELU>(pA);
           gB = mfma_guard<ET, RELU>(pB);
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-          const int q = s * PER + k;
+          const int q = (s - E0) * PER + k;
           if (q < 4) epilogue_quad_16<ET, RELU>(pA, m - 1, q, outA, gA);
           else if (q < 8) epilogue_quad_16<ET, RELU>(pB, m - 1, q - 4, outB, gB);
         }
       }
-      if (m == 0 && kHasPend) {      // the previous layer's last tile (its last MFMAs are a k-step behind as well)
-        if (s == 0) {
+      if (m == 0 && kHasPend && s >= E0) {      // the previous layer's last tile
+        if (s == E0) {
           gA = mfma_guard<ET, PEND_RELU>(pA);
           gB = mfma_guard<ET, PEND_RELU>(pB);
         }
 #pragma unroll
         for (int k = 0; k < PERP; ++k) {
-          const int q = s * PERP + k;
+          const int q = (s - E0) * PERP + k;
           if (q < 4) epilogue_quad_16<ET, PEND_RELU>(pA, PEND_M < 0 ? 0 : PEND_M, q, pendA, gA);
           else if (q < 8) epilogue_quad_16<ET, PEND_RELU>(pB, PEND_M < 0 ? 0 : PEND_M, q - 4, pendB, gB);
         }

@@ -121,6 +121,7 @@ __device__ __forceinline__ void layer_16x3(WS& st, uint32_t bias_addr, int lane,
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, tune::kSgbValuSampling, 0);
+        if (tune::kSplitKstepFence) __builtin_amdgcn_sched_barrier(0);
       }
     }
     if ((tune::kAblateSample & 8) && !LAST) {

@@ -175,6 +175,12 @@ constexpr bool kShadeKstepFence = ADN_KSTEP_FENCE != 0;
 #else
 constexpr bool kShadeKstepFence = true;
 #endif
+// kShadeGuardStep: k-step of a tile in which the previous tile's mfma_guards are taken and its first conversions run (layer_16x2)
+#if ADN_OVERRIDABLE && defined(ADN_GUARD_STEP)
+constexpr int kShadeGuardStep = ADN_GUARD_STEP;
+#else
+constexpr int kShadeGuardStep = 2;      // round 6: 0 -> 1 -> 2: 3.357 -> 3.327 -> 3.285 ms (3: no further gain)
+#endif
 // kShadeCarry: the last tile of a shading layer is converted under the first tile of the next layer (layer_16x2, PendingTile2).
 // (Requesting the next layer's first bias block a layer ahead, so that the wait at a layer boundary is counted too, was measured and dropped:
 // the 16 bias registers live across the boundary next to the carried tile and both kernels spill -- 512 registers + scratch, sampling 1.23 -> 2.29 ms.)
@@ -212,6 +218,11 @@ constexpr int kRegFrags2 = 16;
 //  kSplitCarry       the last output tile of a hidden layer is converted under the MFMAs of the NEXT layer's first tile (PendingTile3)
 // (measured in round 6 and not kept as knobs: re-filling the lo' fragment register first so that one wait covers both -- no effect; the first k-step of a
 // tile that carries a pair of the previous tile's epilogue -- 1, fixed; profiles/r06_variants_ring_2.log)
+#if ADN_OVERRIDABLE && defined(ADN_KSTEP_FENCE_S)
+constexpr bool kSplitKstepFence = ADN_KSTEP_FENCE_S != 0;      // a scheduling fence per k-step of layer_16x3 as in layer_16x2
+#else
+constexpr bool kSplitKstepFence = true;       // round 6: 1.247 -> 1.231 ms
+#endif
 #if ADN_OVERRIDABLE && defined(ADN_SPLIT_CARRY)
 constexpr bool kSplitCarry = ADN_SPLIT_CARRY != 0;
 #else
