@@ -1239,6 +1239,30 @@ def test_headless_cli_matches_library(cases, tmp_path):
     assert diff.max() <= 1 and (diff == 0).mean() > 0.99     # the CLI builds its rotation in float64 -> a few LSB flips
 
 
+def test_far_scene_takes_the_general_encoding_path(tmp_path):
+    """pe_eval (round 6): ONE wave-uniform range test decides between the branch-free sin / cos of arguments below 1e5 and the general form (fp64
+    reduction per value).  A scene 300 units from the origin puts 2^9 x position above 1e5 for every ray, a scene at the origin below it for every ray,
+    a scene whose view cell straddles the limit mixes both inside waves: the sampling network's raw outputs must match the oracle's in all three."""
+    wts = O.synthetic_weights(5, oracle_bias=0.1, oracle_scale=0.3)
+    w, h = 64, 48
+    rot = O.camera_rotation(100.0, 0.0)
+    for k, centre in enumerate([(300.0, -3.19, 1.39), (0.0, 0.0, 0.0), (195.3, 0.0, 0.0)]):
+        sc = O.Scene(centre, (0.7, 0.7, 0.2), (0.1542200982570648, 8.358194804191589), 1.1386263370513916, 8.79825210571289, 8, 0.2)
+        md = str(tmp_path / ("far%d" % k))
+        O.write_model_dir(md, sc, wts)
+        pose = np.array(centre, dtype=np.float32)
+        ref = O.render_rays(O.generate_ray_directions(w, h, sc.fov), pose, rot, sc, wts, w, h, keep=True)
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(md, w, h), precision="fp32", sampling="split") as r:
+            r.set_camera(pose, rot)
+            orc = r.empty((w * h, 128), np.float32)
+            r.sample_mlp(0, w * h, orc, None)
+            got = orc.numpy()
+        # 2^9 x 300 = 153 600: one fp32 ulp of the argument is 1.6e-2 rad, so the encoding itself is only defined to that; the oracle (numpy float32 sin of
+        # the same float32 product) and the device agree on the argument bit for bit, hence on the value to libm accuracy
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref["orc"]).max() < 2e-4, (centre, float(np.abs(got - ref["orc"]).max()))
+
+
 def test_bf16_context_refuses_a_camera_beyond_its_position_bound(cases, tmp_path):
     """adanerf_set_camera on a bf16 context: a pose so far outside the view cell that sample positions could leave the range the scaled layers were
     packed for is refused (EUNSUPPORTED, previous camera kept, frame unchanged) -- never rendered with clamped activations; an fp16 context takes it."""
