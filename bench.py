@@ -154,9 +154,13 @@ def cpu_baseline(model_dir, w, h, pose, rot, budget_s=10.0):
     rows_done = int(sum(int(o["rows_done"]) for o in outs))
     wall = max(float(o["seconds"]) for o in outs)
     fps = (rows_done / float(h)) / wall
-    mid = outs[P // 2]                                   # the band the quality check compares against the GPU frame
-    res = {"rgb": mid["rgb"], "count": mid["count"]}
-    row0, rows = int(mid["row0"]), int(mid["rows_done"])
+    # what the quality check compares against the GPU frame: EVERY row the workers finished (round 6; one band of 12 rows = 9 600 rays before).  `sel` =
+    # indices of those rays in the frame, in band order
+    done = [(int(o["row0"]), int(o["rows_done"])) for o in outs]
+    res = {"rgb": np.concatenate([o["rgb"][:n * w] for o, (_, n) in zip(outs, done)]),
+           "count": np.concatenate([o["count"][:n * w] for o, (_, n) in zip(outs, done)]),
+           "sel": np.concatenate([np.arange(r0 * w, (r0 + n) * w) for r0, n in done])}
+    row0, rows = done[P // 2]
     spp = float(np.mean(np.concatenate([o["count"] for o in outs])))
     backend = str(outs[0]["backend"])
     shutil.rmtree(sync, ignore_errors=True)
@@ -961,8 +965,8 @@ def main():
                 with torch.cuda.stream(tstream):
                     r.render(outs[0][0], rgb)
                 torch.cuda.synchronize()
-            mine = rgb.cpu().numpy()[row0 * w:(row0 + rows) * w]
-            cnt = r.buffer(3, np.int32, (r.info.rays_local,))[row0 * w:(row0 + rows) * w] if r.info.batch_rays >= r.info.rays_local else None
+            mine = rgb.cpu().numpy()[ref["sel"]]
+            cnt = r.buffer(3, np.int32, (r.info.rays_local,))[ref["sel"]] if r.info.batch_rays >= r.info.rays_local else None
             if cnt is not None:
                 same = cnt == ref["count"]
                 quality = {"psnr_vs_oracle_db": psnr(mine[same], ref["rgb"][same]),
@@ -989,8 +993,8 @@ def main():
                 speed = {"sampling": "plain fp16 (ADANERF_SAMPLING_FP16)", "value": args.steps / dt2, "unit": "frames/s",
                          "sample_mlp_ms": st2.ms_sample_mlp, "mean_samples_per_ray": st2.total_samples / float(w * h)}
                 if cpu is not None:
-                    mine2 = rgb2.numpy()[row0 * w:(row0 + rows) * w]
-                    cnt2 = r2.buffer(3, np.int32, (w * h,))[row0 * w:(row0 + rows) * w] if r2.info.batch_rays >= w * h else None
+                    mine2 = rgb2.numpy()[ref["sel"]]
+                    cnt2 = r2.buffer(3, np.int32, (w * h,))[ref["sel"]] if r2.info.batch_rays >= w * h else None
                     speed["psnr_vs_oracle_db_all_rays"] = psnr(mine2, ref["rgb"])
                     if cnt2 is not None:
                         speed["rays_with_identical_sample_count"] = float((cnt2 == ref["count"]).mean())
