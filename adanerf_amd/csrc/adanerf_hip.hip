@@ -83,7 +83,8 @@ struct adanerf_ctx {
   int guard_mism_seen = 0;
   int guard_widened = 0;
   uint32_t guard_frame = 0;              // frames rendered in guarded mode: the audit's rotating phase
-  int debug_guard = 0;                   // $ADANERF_DEBUG_GUARD at create (measurement knob, bit 0: no whole-row monitor)
+  int debug_guard = 0;                   // $ADANERF_DEBUG_GUARD at create (measurement knobs, bit 0: no whole-row monitor; bits 1 / 2: which plain-fp16 sampling kernel)
+  int sample16x2_grid = 0;
   std::string model_dir;
   uint64_t model0_hash = 0;              // FNV-1a 64 of model0.onnx: key of the calibration record
   adanerf_stats folded{};                // profiling record folded out of a full event pool (see adanerf_render)
@@ -700,10 +701,24 @@ int launch_sample_mlp(adanerf_ctx* c, int first_ray, int n_rays, float* d_oracle
                     : occupancy_grid(c, sample_mlp16_kernel<2, 2>, 512, &c->sample16_grid);
       if (rc) return rc;
     }
+    // large batches with the fused selection: two ray blocks per wave (sample_mlp16x2_kernel, bit-identical outputs); $ADANERF_DEBUG_GUARD bit 1 keeps
+    // the 8-wave kernel, bit 2 takes the two-block kernel whatever the batch size (tests)
+    const bool two_blocks = sel != nullptr && a.fused_select && !a.oracle_out && !(c->debug_guard & 2) && (n_rays >= kSample16x2MinRays || (c->debug_guard & 4));
+    if (two_blocks) {
+      if (!c->sample16x2_grid) {
+        int rc = full ? occupancy_grid(c, sample_mlp16x2_kernel<10, 4>, 256, &c->sample16x2_grid)
+                      : occupancy_grid(c, sample_mlp16x2_kernel<2, 2>, 256, &c->sample16x2_grid);
+        if (rc) return rc;
+      }
+      dim3 g2(std::min<unsigned>((n_rays + 255) / 256, static_cast<unsigned>(c->sample16x2_grid))), b2(256);
+      if (full) hipLaunchKernelGGL((sample_mlp16x2_kernel<10, 4>), g2, b2, 0, c->stream, a);
+      else hipLaunchKernelGGL((sample_mlp16x2_kernel<2, 2>), g2, b2, 0, c->stream, a);
+    } else {
     // wave tiles are dealt out evenly over the grid (sample_mlp16_kernel): every workgroup of a small batch gets a share
     dim3 g16(std::min<unsigned>((n_rays + 255) / 256, static_cast<unsigned>(c->sample16_grid))), b16(512);
     if (full) hipLaunchKernelGGL((sample_mlp16_kernel<10, 4>), g16, b16, 0, c->stream, a);
     else hipLaunchKernelGGL((sample_mlp16_kernel<2, 2>), g16, b16, 0, c->stream, a);
+    }
     if (guarded) {
       // undecided rays -> ascending list (+ count at total[4]) -> split engine over the list, rows overwritten in place
       const int n_words = (n_rays + 31) / 32;

@@ -572,11 +572,13 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
   constexpr int KS = S1 + S2;
   constexpr int ABL = tune::kAblateShade;
   constexpr int PER = (KS >= 8) ? 1 : (8 + KS - 1) / KS;      // epilogue quads of the previous tile per k-step
+  constexpr bool kKeepAll = KEEP_F32_TILE == kKeepAllF32;     // every tile's raw accumulators go to keepA[m] / keepB[m] (the sampling net's 128 raw outputs)
+  auto kept = [](int m) { return kKeepAll || KEEP_F32_TILE == m; };
   constexpr bool kCarry = tune::kShadeCarry && !(ABL & 8);
   constexpr bool kHasPend = kCarry && PEND_M >= 0;
   constexpr int PERP = 1;                                     // quads of a carried tile per k-step: all converted before the k-steps that read them
   static_assert(!kHasPend || KS >= 16, "a carried tile is consumed by the last two k-steps of a 16-k-step input segment, 6 k-steps behind its last conversion");
-  static_assert(!CARRY_OUT || KEEP_F32_TILE != MT - 1, "the kept tile is not converted");
+  static_assert(!CARRY_OUT || (KEEP_F32_TILE != MT - 1 && KEEP_F32_TILE != kKeepAllF32), "the kept tile is not converted");
   // LDS reads issued between a bias request and its use: the tile's KS fragment re-fills (none under ablation 2)
   constexpr bool kCounted = tune::kBiasWaitCounted && tune::kSchedGroups && !(ABL & (2 | 4));
   constexpr int kYounger = kCounted ? KS : 0;
@@ -614,7 +616,7 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
       // first MFMA, one or two MFMAs after the accumulator's last write, and costs an `s_nop 6` per tile (hipcc counts an MFMA as ONE wait state of the 11 it
       // wants between the write and a VALU read); tune::kShadeGuardStep k-steps later the distance is there by itself.
       constexpr int E0 = (tune::kShadeKstepFence && KS >= 8 + tune::kShadeGuardStep) ? tune::kShadeGuardStep : 0;
-      if (m > 0 && KEEP_F32_TILE != m - 1 && !(ABL & 8) && s >= E0) {
+      if (m > 0 && !kept(m - 1) && !(ABL & 8) && s >= E0) {
         if (s == E0) {
           gA = mfma_guard<ET, RELU>(pA);
           gB = mfma_guard<ET, RELU>(pB);
@@ -653,18 +655,18 @@ __device__ __forceinline__ void layer_16x2(WS& st, uint32_t bias_addr, const uin
         if (tune::kShadeKstepFence) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (KEEP_F32_TILE == m) {
-      *keepA = accA;
-      *keepB = accB;
+    if (kept(m)) {
+      keepA[kKeepAll ? m : 0] = accA;
+      keepB[kKeepAll ? m : 0] = accB;
     }
-    if ((ABL & 8) && KEEP_F32_TILE != m) {
+    if ((ABL & 8) && !kept(m)) {
       asm volatile("" ::"v"(accA), "v"(accB));
 #pragma unroll
       for (int g = 0; g < 8; ++g) asm volatile("" : "=v"(outA[8 * m + g]), "=v"(outB[8 * m + g]));
     } else if (m + 1 < MT) {
       pA = accA;
       pB = accB;
-    } else if (KEEP_F32_TILE != m) {
+    } else if (!kept(m)) {
       if (CARRY_OUT && kCarry) {
         pend.a = accA;
         pend.b = accB;

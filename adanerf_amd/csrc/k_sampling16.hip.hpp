@@ -390,4 +390,95 @@ __global__ __launch_bounds__(512, 2) void sample_mlp16_kernel(SampleArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// The same network in plain fp16 with TWO 32-ray blocks per wave (layer_16x2, the shading kernel's engine): 4 waves x 64 rays = 256 rays per weight pass,
+// every fragment read from LDS feeds two MFMAs, half the LDS-DMA bytes / barriers / bias reads per ray of sample_mlp16_kernel.  Same packed weights, same
+// k-step order, same epilogue arithmetic: the raw outputs are sample_mlp16_kernel's bit for bit (so the guard band's calibration record holds for both,
+// kGuardEngineRev unchanged; tests/test_gpu_parity.py compares the two).  Used for batches of at least kSample16x2MinRays rays with the fused selection (the
+// first pass of the guarded mode, the plain-fp16 speed mode); smaller batches -- the strip shares of an N-GPU frame -- keep sample_mlp16_kernel, whose last
+// round is dealt out wave by wave.
+constexpr int kSample16x2MinRays = 4 * 256 * 256;      // four full rounds of a 256-CU grid
+
+template <int FP, int FD>
+__global__ __launch_bounds__(256) void sample_mlp16x2_kernel(SampleArgs a) {
+  constexpr int QD = pe_slots(FD), QP = pe_slots(FP), Q0 = QD + QP;
+  constexpr int WAVES = 4, CF = 16, RS = 6, LPW = CF / WAVES, TILE = WAVES * 64;
+  constexpr int F0 = (Q0 / 8) * 8, FRAGS = sample16_frags<FP, FD>();
+  static_assert(F0 % CF == 0 && FRAGS % CF == 0 && CF % tune::kRegFrags2 == 0, "chunk geometry");
+  typedef WStream<CF, RS, LPW, tune::kRegFrags2> WS;
+  constexpr int kRingBytes = CF * RS * 1024, kBiasFloats = 7 * 256 + 128;
+  __shared__ __attribute__((aligned(16))) char lds[kRingBytes + kBiasFloats * 4 + WAVES * kPairLdsBytesPerWave];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int ntiles = (a.n_rays + TILE - 1) / TILE;
+  if (static_cast<int>(blockIdx.x) >= ntiles) return;
+  const uint32_t sel_stage = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + kBiasFloats * 4 +
+                             wave * kPairLdsBytesPerWave + lane * 16;
+  {
+    float* lds_bias = reinterpret_cast<float*>(lds + kRingBytes);
+    for (int i = threadIdx.x; i < kBiasFloats; i += blockDim.x) lds_bias[i] = a.net16.bias[i];
+  }
+  __syncthreads();
+  WS st;
+  ws_start(st, a.net16.w, FRAGS * 1024, lds, wave, lane);
+  const uint32_t bias0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)) + kRingBytes + h * 64;
+  const uint32_t* bo = a.net16.b_off;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    uint32_t hA0[64], hB0[64], hA1[64], hB1[64];
+    PendingTile2 pend;
+    int local[2];
+    bool valid[2];
+    {
+      uint32_t in0[2][Q0 / 2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        local[b] = tile * TILE + wave * 64 + 32 * b + j;
+        valid[b] = local[b] < a.n_rays;
+        const int ray = a.first_ray + (valid[b] ? local[b] : a.n_rays - 1);
+        int col, row;
+        ray_pixel(a.g, ray, &col, &row);
+        float nds[3], p[3], u[3];
+        gen_ray(a.g, col, row, nds, p);
+        unit3(nds, u);
+        if (valid[b] && a.rays_out) {
+          float ro[3] = {p[0], p[1], p[2]}, rd[3] = {nds[0], nds[1], nds[2]};
+          if (a.g.use_ndc) ndc_ray(a.g, p, nds, ro, rd);
+          float4* r = reinterpret_cast<float4*>(a.rays_out + static_cast<size_t>(local[b]) * 8);
+          if (h == 0) r[0] = make_float4(ro[0], ro[1], ro[2], 0.f);
+          else r[1] = make_float4(rd[0], rd[1], rd[2], 0.f);
+        }
+        float t[Q0];
+        pe_eval<FD, !tune::kFastPeFp16Pass>(u, h, t);            // [dir PE | pos PE]  (src/features.py:868-874), as sample_mlp16_kernel
+        pe_eval<FP, !tune::kFastPeFp16Pass>(p, h, t + QD);
+#pragma unroll
+        for (int q = 0; q < Q0 / 2; ++q) in0[b][q] = Fp16::pack(t[2 * q], t[2 * q + 1]);
+      }
+      layer_16x2<Fp16, WS, Q0 / 8, 0, 8, true, 0, -1, -1, true, true>(st, bias0 + bo[0] * 4, in0[0], in0[0], in0[1], in0[1], hA0, hA1, pend);
+    }
+#pragma unroll 1
+    for (int l = 1; l <= 5; l += 2) {
+      layer_16x2<Fp16, WS, 16, 0, 8, true, 0, -1, 7, true, true>(st, bias0 + bo[l] * 4, hA0, hA0, hA1, hA1, hB0, hB1, pend, hA0, hA1);
+      layer_16x2<Fp16, WS, 16, 0, 8, true, 0, -1, 7, true, true>(st, bias0 + bo[l + 1] * 4, hB0, hB0, hB1, hB1, hA0, hA1, pend, hB0, hB1);
+    }
+    f32x16 outA[4], outB[4];
+    layer_16x2<Fp16, WS, 16, 0, 4, false, 0, kKeepAllF32, 7, true, false>(st, bias0 + bo[7] * 4, hA0, hA0, hA1, hA1, hB0, hB1, pend, hA0, hA1, outA, outB);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float x[64];
+      float z = 0.f;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        x[i] = b ? outB[i >> 4][i & 15] : outA[i >> 4][i & 15];
+        z = __builtin_fmaf(x[i], 0.f, z);
+      }
+      const bool bad_ray = (z != z) | (pair_xchg(static_cast<uint32_t>(z != z)) != 0u);
+      // guard mode: a non-finite ray goes to the refinement pass, which does the counting
+      if (bad_ray && valid[b] && h == 0 && a.overflow_flag && !a.sel.guard_mask) atomicAdd(a.overflow_flag, 1);
+      pair_epilogue<false>(x, lane, local[b], valid[b], sel_stage, a.sel, bad_ray);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace adanerf

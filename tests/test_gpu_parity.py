@@ -1239,6 +1239,28 @@ def test_headless_cli_matches_library(cases, tmp_path):
     assert diff.max() <= 1 and (diff == 0).mean() > 0.99     # the CLI builds its rotation in float64 -> a few LSB flips
 
 
+@pytest.mark.parametrize("name", ["classroom_n8_thr02", "ndc_synthetic_n8"])
+@pytest.mark.parametrize("mode", ["fp16", "guarded"])
+def test_two_block_fp16_sampling_kernel_equals_the_eight_wave_one(cases, name, mode, monkeypatch):
+    """sample_mlp16x2_kernel (two ray blocks per wave, large batches) and sample_mlp16_kernel (8 waves x 32 rays) are the same arithmetic: same packed
+    weights, k-step order and epilogue.  $ADANERF_DEBUG_GUARD bit 1 forces the 8-wave kernel, bit 2 the two-block one: per-ray sample counts, kept bins and the
+    frame must be identical, in the plain-fp16 speed mode and as the first pass of the guarded mode (the band's calibration record is shared)."""
+    z, meta, sc, wts, d = cases[name]
+    w, h = 200, 131      # 26 200 rays: 102 tiles of 256 + a ragged one
+    got = {}
+    for bits in (2, 4):
+        monkeypatch.setenv("ADANERF_DEBUG_GUARD", str(bits))
+        with adanerf_amd.NeuralRenderer(adanerf_amd.Settings(d, w, h), precision="bf16", sampling=mode) as r:
+            r.set_camera(z["pose"], z["rot"])
+            rgb, rgba, st = r.render_numpy()
+            cnt = r.buffer(R.BUF_RAY_COUNTS, np.int32, (w * h,))
+            key = r.buffer(R.BUF_SAMPLE_KEY, np.uint32, (int(cnt.sum()),))
+            got[bits] = (rgba.copy(), cnt, key, st.rays_refined, st.sampling_overflow)
+    a, b = got[2], got[4]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0])
+    assert a[3] == b[3] and a[4] == b[4] == 0
+
+
 def test_far_scene_takes_the_general_encoding_path(tmp_path):
     """pe_eval (round 6): ONE wave-uniform range test decides between the branch-free sin / cos of arguments below 1e5 and the general form (fp64
     reduction per value).  A scene 300 units from the origin puts 2^9 x position above 1e5 for every ray, a scene at the origin below it for every ray,
