@@ -276,7 +276,11 @@ class GpuTelemetry:
 
         def loop():
             while not self._stop.is_set():
-                self.samples.append(self.read())
+                try:
+                    self.samples.append(self.read())
+                except Exception as e:      # noqa: BLE001 -- telemetry must never take the measurement with it
+                    self.err = "rsmi read: %s" % e
+                    return
                 self._stop.wait(self.period)
         self._thread = threading.Thread(target=loop, daemon=True)
         self._thread.start()
@@ -285,7 +289,9 @@ class GpuTelemetry:
     def stop(self):
         if self._thread:
             self._stop.set()
-            self._thread.join()
+            self._thread.join(timeout=2.0)      # a management-library call that hangs must not hang the bench: the daemon thread is abandoned
+            if self._thread.is_alive():
+                return {"sclk_mhz_mean": None, "power_w_mean": None, "error": "librocm_smi64 call did not return", "samples": len(self.samples)}
         if not self.lib:
             return {"sclk_mhz_mean": None, "power_w_mean": None, "error": self.err}
         clk = [m for m, _ in self.samples if m]
