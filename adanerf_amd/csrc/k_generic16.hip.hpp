@@ -227,9 +227,8 @@ __device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], 
   const int h = lane >> 5;
   // Where do a tile's conversions (ReLU + pack, 16 x NB values) go?  tune::kGenericSpread<W>: spread, a quad at a time, over the k-steps of
   // the NEXT tile, between its MFMAs -- with one wave per SIMD (width 256) nothing else would issue while the pipe works, and nothing
-  // else would keep the pipe working while they issue; costs a second accumulator set.  tune::kGenericDefer: in one piece behind the
-  // next tile's wait + barrier and first fragment requests (no second set; measured: no effect).  Otherwise right behind the tile's own
-  // MFMAs.  A layer's last tile always converts at once: the next layer reads its outputs.
+  // else would keep the pipe working while they issue; costs a second accumulator set.  Otherwise right behind the tile's own
+  // MFMAs (in one piece behind the next tile's barrier: measured in round 4, no effect, removed).  A layer's last tile always converts at once: the next layer reads its outputs.
   constexpr bool SPREAD = tune::kGenericSpread != 0 && (tune::kGenericSpread >= 2 || O >= 64);      // O = W / 4 (+ 8): 1 = width 256 only
   constexpr int QUADS = 4 * NB, QPS = (QUADS + KS - 1) / KS;      // quads of the previous tile converted per k-step
   f32x16 accs[SPREAD ? 2 : 1][NB];
@@ -253,13 +252,6 @@ __device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], 
     u32x4 fr[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) fr[i] = lds_read128(rd + i * 1024);
-    if (!SPREAD && tune::kGenericDefer) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (m > 0) {
-#pragma unroll
-        for (int q = 0; q < QUADS; ++q) convert_quad(acc, gacc, m - 1, q);
-      }
-    }
     if (LDSB && tune::kGenericBiasDirect && !(tune::kAblateGeneric & 2)) {
       // the tile's own bias block straight into its accumulators (no copy a tile ahead, no 16 moves per block): the first MFMA
       // waits for these reads and its first fragment together
@@ -305,11 +297,11 @@ __device__ __forceinline__ void layer_16_staged(TileStage& st, float (&br)[16], 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (KEEP_F32_TILE != m && (last || !SPREAD)) {      // converted right here (or, deferred, behind the next tile's barrier)
+    if (KEEP_F32_TILE != m && (last || !SPREAD)) {      // converted right here
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) gacc[nb] = mfma_guard<ET, RELU>(acc[nb]);
     }
-    if (last || !(SPREAD || tune::kGenericDefer)) {
+    if (last || !SPREAD) {
 #pragma unroll
       for (int q = 0; q < QUADS; ++q) convert_quad(acc, gacc, m, q);
     }
@@ -507,10 +499,6 @@ __device__ __forceinline__ void layer_16x3_staged(TileStage& st, float (&br)[16]
       fh[i] = lds_read128(rd + (2 * i) * 1024);
       fl[i] = lds_read128(rd + (2 * i + 1) * 1024);
     }
-    if (tune::kGenericDefer) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (m > 0) convert(m - 1);
-    }
     if (tune::kGenericBiasDirect && !(tune::kAblateGeneric & 2)) {
       float b16[16];
       bias_request_lds(bias + m * 128, h, b16);
@@ -547,7 +535,7 @@ __device__ __forceinline__ void layer_16x3_staged(TileStage& st, float (&br)[16]
       cross = Fp16::mfma(wlo, bh, cross);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!tune::kGenericDefer || last) convert(m);
+    convert(m);
   }
 }
 

@@ -146,10 +146,10 @@ __device__ __forceinline__ int pair_select(const float* x, int h, int n_max, flo
   for (int k = 0; k < NB; ++k) s[k] = -INFINITY;
 #pragma unroll
   for (int i = 0; i < 64; ++i) {
-    // NaN never ranks (fmaxf in select_ray ignores it, too).  tune::kSelScrubNaN == false: no per-value replacement by -inf -- v_max_f32 returns
-    // its non-NaN operand and v_med3_f32 with a NaN operand returns the minimum of the other two, which in a descending list is s[k] itself
-    // (edge-case fixture: NaN / inf rows of test_fused_selection_* and the fuzz cases).
-    const float v = (!tune::kSelScrubNaN || x[i] == x[i]) ? x[i] : -INFINITY;
+    // NaN never ranks (fmaxf in select_ray ignores it, too) and needs no per-value replacement by -inf: v_max_f32 returns its non-NaN operand
+    // and v_med3_f32 with a NaN operand returns the minimum of the other two, which in a descending list is s[k] itself (edge-case fixture:
+    // NaN / inf rows of test_fused_selection_* and the fuzz cases; round 6: 2 VALU per value less, profiles/r06_variants_pe_scrub.log).
+    const float v = x[i];
 #pragma unroll
     for (int k = NB - 1; k >= 1; --k) s[k] = __builtin_amdgcn_fmed3f(s[k - 1], s[k], v);
     s[0] = fmaxf(s[0], v);

@@ -1,6 +1,6 @@
 """Model check of the LDS weight-ring protocol of k_mlp16.hip.hpp (ws_start / ws_sync / ws_advance / ws_refill) under
-arbitrary latencies: 8 waves, group 1 (waves 4-7) synchronising half a chunk after group 0 (ADN_STAGGER), DMA pieces
-issued by every wave or by one group only (ADN_DMA_GRP), NR fragment registers, RS ring slots.  Every LDS read must see
+arbitrary latencies: 8 waves, group 1 (waves 4-7) synchronising half a chunk after group 0 (tune::kStagger), DMA pieces
+issued by every wave or by one group only (tune::kDmaGroup), NR fragment registers, RS ring slots.  Every LDS read must see
 the chunk it expects.  Pure Python, no GPU: python tools/probes/ring_model.py"""
 import bisect
 import random
