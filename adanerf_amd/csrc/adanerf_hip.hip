@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -251,7 +252,18 @@ int rows_of_rank(int h, int strip_rows, int world, int rank) {
 bool contains(const std::string& s, const char* sub) { return s.find(sub) != std::string::npos; }
 
 // Host-only: parse + validate the model directory and derive every per-context constant.
+int setup_model_unguarded(const char* model_dir, const adanerf_options* opt, ModelSetup* ms, std::string* err);
+// No exception leaves the C ABI: whatever a damaged or hostile model directory makes the loader throw (std::bad_alloc, std::length_error)
+// comes back as a status + message (tests/host_sanitize_fuzz.cpp runs the loader itself under ASan / UBSan on mutated directories).
 int setup_model(const char* model_dir, const adanerf_options* opt, ModelSetup* ms, std::string* err) {
+  try {
+    return setup_model_unguarded(model_dir, opt, ms, err);
+  } catch (const std::exception& e) {
+    *err = std::string("model directory: ") + e.what();
+    return ADANERF_EIO;
+  }
+}
+int setup_model_unguarded(const char* model_dir, const adanerf_options* opt, ModelSetup* ms, std::string* err) {
   auto bad = [&](int code, const std::string& msg) {
     *err = msg;
     return code;
@@ -1244,11 +1256,24 @@ extern "C" {
 
 const char* adanerf_last_error(const adanerf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+static int create_on(adanerf_ctx* c, const char* model_dir, const adanerf_options* opt, adanerf_ctx** out);
+
 int adanerf_create(const char* model_dir, const adanerf_options* opt, adanerf_ctx** out) {
   if (!out) return fail(nullptr, ADANERF_EINVAL, "out == NULL");
   *out = nullptr;
   if (!model_dir || !opt) return fail(nullptr, ADANERF_EINVAL, "model_dir/opt == NULL");
-  adanerf_ctx* c = new adanerf_ctx();
+  adanerf_ctx* c = nullptr;
+  try {
+    c = new adanerf_ctx();
+    return create_on(c, model_dir, opt, out);
+  } catch (const std::exception& e) {      // see setup_model: the loader's exceptions end here, with the context released
+    *out = nullptr;
+    adanerf_destroy(c);
+    return fail(nullptr, ADANERF_EIO, std::string("adanerf_create: ") + e.what());
+  }
+}
+
+static int create_on(adanerf_ctx* c, const char* model_dir, const adanerf_options* opt, adanerf_ctx** out) {
   auto bail = [&](int code, const std::string& msg) {
     g_create_error = msg;
     adanerf_destroy(c);
@@ -1394,7 +1419,7 @@ int adanerf_host_depth_table(const char* model_dir, const adanerf_options* opt, 
 }
 
 int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precision, void* weights_out, size_t* weights_bytes,
-                              float* bias_out, size_t* bias_floats, int32_t* layer_out, int32_t* n_layers) {
+                              float* bias_out, size_t* bias_floats, int32_t* layer_out, int32_t* n_layers) try {
   if (!model_dir || !weights_bytes || !bias_floats || !n_layers) return fail(nullptr, ADANERF_EINVAL, "NULL argument");
   // precision 4 (shading nets only): bf16 WITHOUT the scaled packing -- for the CPU test that replays both blobs; no kernel consumes it
   const bool unscaled_bf16 = precision == 4 && net == 1;
@@ -1459,6 +1484,8 @@ int adanerf_host_pack_weights(const char* model_dir, int32_t net, int32_t precis
   *bias_floats = pn.bias.size();
   *n_layers = n_rec;
   return ADANERF_OK;
+} catch (const std::exception& e) {
+  return fail(nullptr, ADANERF_EIO, std::string("adanerf_host_pack_weights: ") + e.what());
 }
 
 int adanerf_destroy(adanerf_ctx* c) {

@@ -54,8 +54,17 @@ static std::vector<float> to_floats(const std::vector<std::string>& v) {
 }
 static std::vector<int> to_ints(const std::vector<std::string>& v) {
   std::vector<int> o;
-  for (auto& s : v) o.push_back(s.empty() ? 0 : std::atoi(s.c_str()));
+  for (auto& s : v) {      // out-of-range text saturates (atoi's behaviour there is undefined)
+    const long x = s.empty() ? 0 : std::strtol(s.c_str(), nullptr, 10);
+    o.push_back(static_cast<int>(std::max(-2147483647L - 1, std::min(2147483647L, x))));
+  }
   return o;
+}
+// a frequency-band count of posEncArgs: the callers convert it to int, so anything that is no small non-negative number (nan, 1e39, a
+// damaged file) becomes -1, which every range check downstream refuses
+static float band_count(const std::string& s) {
+  const double v = std::atof(s.c_str());
+  return (v >= 0.0 && v <= 1024.0) ? static_cast<float>(v) : -1.0f;
 }
 
 // Keys consumed: the set of adanerf_real_time_viewer/src/config.cpp:206-266.  Unknown keys are
@@ -75,10 +84,9 @@ void Config::store(std::string key, std::string value) {
       } else {
         size_t d = item.find('-');
         if (d == std::string::npos) {
-          tf = {static_cast<float>(std::atof(item.c_str())), 0.f};
+          tf = {band_count(item), 0.f};
         } else {
-          tf = {static_cast<float>(std::atof(item.substr(0, d).c_str())),
-                static_cast<float>(std::atof(item.substr(d + 1).c_str()))};
+          tf = {band_count(item.substr(0, d)), band_count(item.substr(d + 1))};
         }
       }
       posEncArgs.push_back(tf);
@@ -220,14 +228,19 @@ bool read_onnx_initializers(const std::string& path, TensorMap* out, std::string
       int dtype = 1;
       Span raw{nullptr, 0};
       std::vector<float> fdata;
+      bool bad_dims = false;      // a dimension that is no non-negative int (a hostile or damaged file): the tensor is refused below
+      auto push_dim = [&](uint64_t d) {
+        if (d > 0x7FFFFFFFull) bad_dims = true;
+        else t.dims.push_back(static_cast<int>(d));
+      };
       ok &= for_each_field(f2.bytes, [&](const Field& f3) {
         if (f3.num == 1) {
           if (f3.wire == 0) {
-            t.dims.push_back(static_cast<int>(f3.varint));
+            push_dim(f3.varint);
           } else if (f3.wire == 2) {
             size_t j = 0;
             uint64_t d;
-            while (j < f3.bytes.n && read_varint(f3.bytes.p, f3.bytes.n, &j, &d)) t.dims.push_back(static_cast<int>(d));
+            while (j < f3.bytes.n && read_varint(f3.bytes.p, f3.bytes.n, &j, &d)) push_dim(d);
           }
         } else if (f3.num == 2 && f3.wire == 0) {
           dtype = static_cast<int>(f3.varint);
@@ -245,15 +258,26 @@ bool read_onnx_initializers(const std::string& path, TensorMap* out, std::string
         }
       });
       if (dtype != 1 || name.empty()) return;
+      // element count, bounded by what the file can hold (no product that wraps, no allocation a few crafted bytes can ask for)
       size_t count = 1;
-      for (int d : t.dims) count *= static_cast<size_t>(d);
+      for (int d : t.dims) {
+        if (bad_dims || (d != 0 && count > buf.size() / static_cast<size_t>(d))) {
+          ok = false;
+          return;
+        }
+        count *= static_cast<size_t>(d);
+      }
+      if (bad_dims) {
+        ok = false;
+        return;
+      }
       if (raw.p) {
         if (raw.n != count * 4) {
           ok = false;
           return;
         }
         t.data.resize(count);
-        std::memcpy(t.data.data(), raw.p, raw.n);   // little-endian fp32, host is little-endian
+        if (raw.n) std::memcpy(t.data.data(), raw.p, raw.n);   // little-endian fp32, host is little-endian
       } else {
         if (fdata.size() != count) {
           ok = false;

@@ -1167,3 +1167,79 @@ def test_scaled_bf16_packing_refuses_a_bound_beyond_its_range(lib, tmp_path):
 
 def pad_to(w):
     return 64 if w <= 64 else 128 if w <= 128 else 256
+
+
+# ---- the host-side loader on damaged and hostile model directories (round 6) ---------------------------------------------------
+
+def _pb_varint(v):
+    out = bytearray()
+    while True:
+        out.append((v & 0x7F) | (0x80 if v > 0x7F else 0))
+        v >>= 7
+        if not v:
+            return bytes(out)
+
+
+def _pb_bytes(num, payload):
+    return bytes([(num << 3) | 2]) + _pb_varint(len(payload)) + payload
+
+
+def _crafted_onnx(name, dims, raw=b""):
+    """ModelProto{graph{initializer{dims..., data_type FLOAT, name, raw_data}}} as torch.onnx.export writes them (format.cpp's wire reader)."""
+    t = b"".join(bytes([1 << 3]) + _pb_varint(d) for d in dims) + bytes([2 << 3, 1]) + _pb_bytes(8, name.encode()) + _pb_bytes(9, raw)
+    return _pb_bytes(7, _pb_bytes(5, t))
+
+
+def test_crafted_initializers_are_refused_through_the_c_abi(lib, tmp_path):
+    """A model0.onnx whose tensor dimensions wrap (int(2^31) x int(2^31) elements x 4 bytes = 0 = the empty raw_data), are negative as
+    int32 or exceed what the file can hold used to reach std::vector::resize with 2^62 elements -- an exception through the C ABI ends the host
+    process.  Now: refused as malformed, and no loader exception leaves adanerf_host_* / adanerf_create (they return ADANERF_EIO + message)."""
+    f = lib.adanerf_host_pack_weights
+    f.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_int32)]
+    f.restype = C.c_int
+    lib.adanerf_host_parse_model.argtypes = [C.c_char_p, C.POINTER(R._Options), C.POINTER(R.Info)]
+    d, _, _ = _model_dir(tmp_path, name="crafted")
+    good = open(os.path.join(d, "model0.onnx"), "rb").read()
+    M = 1 << 31
+    for dims, raw in (((M, M), b""), ((0xFFFFFFFF, 4), b""), ((1 << 30, 1 << 30, 4), b""), ((2, 3), b"\0" * 8), (((1 << 64) - 1,), b"")):
+        with open(os.path.join(d, "model0.onnx"), "wb") as fh:
+            fh.write(_crafted_onnx("layers.0.weight", dims, raw))
+        wb, bf, nl = C.c_size_t(0), C.c_size_t(0), C.c_int32(0)
+        rc = f(d.encode(), 0, 0, None, C.byref(wb), None, C.byref(bf), None, C.byref(nl))
+        assert rc != 0 and b"malformed ONNX" in lib.adanerf_last_error(None), (dims, rc, lib.adanerf_last_error(None))
+    # a band count no int can hold (the callers convert posEncArgs to int) is refused by the range check, not converted
+    with open(os.path.join(d, "model0.onnx"), "wb") as fh:
+        fh.write(good)
+    cfg = open(os.path.join(d, "config.ini")).read()
+    assert "posEncArgs" in cfg
+    import re
+    for bad in ("1e39-4", "nan-4", "10-99999999999"):
+        with open(os.path.join(d, "config.ini"), "w") as fh:
+            fh.write(re.sub(r"posEncArgs\s*=.*", "posEncArgs = [%s, 10-4]" % bad, cfg))
+        info, o = R.Info(), _opts()
+        rc = lib.adanerf_host_parse_model(d.encode(), C.byref(o), C.byref(info))
+        assert rc != 0 and b"posEncArgs" in lib.adanerf_last_error(None), (bad, rc, lib.adanerf_last_error(None))
+
+
+def test_host_loader_under_sanitizers_on_mutated_model_directories(tmp_path):
+    """tests/host_sanitize_fuzz.cpp: format.cpp + pack.cpp built with g++ -fsanitize=address,undefined,float-cast-overflow and run on crafted
+    initializers, 76 well-formed files of odd topologies and 150 randomly damaged model directories.  Any outcome but a fault is fine."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not available")
+    from adanerf_amd.build import CSRC
+    exe = str(tmp_path / "host_sanitize_fuzz")
+    san = "-fsanitize=address,undefined,float-cast-overflow"
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-Wall", "-Werror", san, "-fno-sanitize-recover=undefined,float-cast-overflow", "-I", CSRC,
+           os.path.join(ROOT, "tests", "host_sanitize_fuzz.cpp"), os.path.join(CSRC, "format.cpp"), os.path.join(CSRC, "pack.cpp"), "-o", exe]
+    built = subprocess.run(cmd, capture_output=True, text=True)
+    if built.returncode != 0 and ("asan" in built.stderr or "ubsan" in built.stderr) and "error:" not in built.stderr.replace("ld: error", ""):
+        pytest.skip("sanitizer runtimes not installed: " + built.stderr[-200:])
+    assert built.returncode == 0, built.stderr[-2000:]
+    d, _, _ = _model_dir(tmp_path, name="fuzzed")
+    work = tmp_path / "work"
+    work.mkdir()
+    out = subprocess.run([exe, d, str(work), "150", "606"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "0 faults" in out.stdout, out.stdout[-500:] + out.stderr[-3000:]
