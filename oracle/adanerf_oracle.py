@@ -972,9 +972,11 @@ def normalize_positions(x: np.ndarray, scene: Scene) -> np.ndarray:
 
 
 def shading_inputs(p: np.ndarray, nds: np.ndarray, sample_ray: np.ndarray, z: np.ndarray,
-                   scene: Scene, w: int = 0, h: int = 0, unit_dir: bool = True) -> np.ndarray:
+                   scene: Scene, w: int = 0, h: int = 0, unit_dir: bool = True, position_ulp: Optional[np.ndarray] = None) -> np.ndarray:
     """src/features.py:420-479: x = o + d*z; normalise; [PE_pos(x^) | PE_dir(dir)].
-    ``z`` is the per-sample world depth (to_world_depth of the bin's t)."""
+    ``z`` is the per-sample world depth (to_world_depth of the bin's t).  ``position_ulp`` ([S,3], not part of the reference): the
+    normalised positions moved by that many ulp before the encoding -- the conditioning analysis of tests/fuzz_parity.py (two correct fp32
+    evaluations of o + d z and of the normalisation differ in their last bits, and an encoding with F bands multiplies that by 2^(F-1))."""
     fp, fd = scene.pos_enc[1]
     o, d = p, nds
     dir_pe = nds
@@ -985,6 +987,8 @@ def shading_inputs(p: np.ndarray, nds: np.ndarray, sample_ray: np.ndarray, z: np
         dir_pe = (d / np.sqrt(np.sum(d * d, -1, keepdims=True, dtype=F32))).astype(F32, copy=False) if unit_dir else d
     x = (o[sample_ray] + d[sample_ray] * z[:, None]).astype(F32, copy=False)
     x = normalize_positions(x, scene)
+    if position_ulp is not None:
+        x = (x + position_ulp.astype(F32) * np.spacing(np.abs(x).astype(F32))).astype(F32, copy=False)
     return np.concatenate([positional_encoding(x, fp),
                            positional_encoding(dir_pe[sample_ray], fd)], -1).astype(F32, copy=False)
 

@@ -75,7 +75,7 @@ def selection_fragile(orc, sc, n_max, thr, rng, eps_rel=2e-5, trials=4, rays=Non
     return frag, e
 
 
-def colour_sensitivity(ref, sc, kind, w, h, eps_rel, rng, trials=6, wts=None):
+def colour_sensitivity(ref, sc, kind, w, h, eps_rel, rng, trials=6, wts=None, w_err=None):
     """Conditioning of every ray's colour, measured on the reference itself: the largest change of the oracle's OWN composite when its
     raw shading outputs move by a relative eps_rel (gaussian, eps_rel (1 + |raw|) per value; `trials` draws).  An engine whose raw
     outputs are accurate to eps_rel cannot be asked to land closer than that on a ray -- and need not be excused anywhere else: a
@@ -104,7 +104,7 @@ def colour_sensitivity(ref, sc, kind, w, h, eps_rel, rng, trials=6, wts=None):
         mask = np.arange(ref["wts"].shape[1])[None, :] < cnt[:, None]
         sw = ref["wts"][mask].astype(np.float32)
         mult = O.effective_mult(sc)
-        comp = lambda rw: O.composite(rw, sw, off, cnt, mult)
+        comp = lambda rw, sw_=sw: O.composite(rw, sw_, off, cnt, mult)
     with np.errstate(over="ignore", invalid="ignore"):
         base = comp(raw)
         spread = np.zeros(r, np.float32)
@@ -118,6 +118,29 @@ def colour_sensitivity(ref, sc, kind, w, h, eps_rel, rng, trials=6, wts=None):
                 zz = (ref["z"].astype(np.float32) * np.float32(1.0 + sgn * 2.0 ** -22)).astype(np.float32)
                 raw2 = O.shading_mlp(O.shading_inputs(ref["p"], ref["nds"], sray, zz, sc, w, h), wts.net1, n_pos)
                 spread = spread + np.nan_to_num(np.abs(comp(raw2.astype(np.float32)) - base).max(axis=1), nan=np.inf, posinf=np.inf)
+            # ... and of the ray itself, as selection_fragile does for the sampling network: origin and direction moved by +-2 ulp (a sample
+            # sits at origin + depth x direction: at depth 8 one ulp of a direction component is as large as two ulp of the depth; round 6:
+            # 2 of 1000 cases of the 12-16-band kind were 1.2 x / 2.0 x over a bound that knew about the depth's last bits only)
+            if os.environ.get("FUZZ_NO_RAY_ULP") is None:
+                for _ in range(2):
+                    sg_p = rng.choice(np.array([-2.0, 2.0], np.float32), size=ref["p"].shape)
+                    sg_d = rng.choice(np.array([-2.0, 2.0], np.float32), size=ref["nds"].shape)
+                    p2 = (ref["p"] + sg_p * np.spacing(np.abs(ref["p"]).astype(np.float32))).astype(np.float32)
+                    d2 = (ref["nds"] + sg_d * np.spacing(np.abs(ref["nds"]).astype(np.float32))).astype(np.float32)
+                    raw2 = O.shading_mlp(O.shading_inputs(p2, d2, sray, ref["z"].astype(np.float32), sc, w, h), wts.net1, n_pos)
+                    spread = spread + np.nan_to_num(np.abs(comp(raw2.astype(np.float32)) - base).max(axis=1), nan=np.inf, posinf=np.inf)
+                # ... and of every sample's own position arithmetic (fma or not, the order of the normalisation's operations): the normalised
+                # positions moved by +-2 ulp, independently per sample and component
+                for _ in range(2):
+                    jit = rng.choice(np.array([-2.0, 2.0], np.float32), size=(sray.shape[0], 3))
+                    raw2 = O.shading_mlp(O.shading_inputs(ref["p"], ref["nds"], sray, ref["z"].astype(np.float32), sc, w, h, position_ulp=jit), wts.net1, n_pos)
+                    spread = spread + np.nan_to_num(np.abs(comp(raw2.astype(np.float32)) - base).max(axis=1), nan=np.inf, posinf=np.inf)
+        if w_err is not None and not classic:
+            # ... and of the KEPT sampling-network values that multiply alpha / the weights: a ray whose selection is well determined still
+            # carries values that two correct evaluations of a 16-band sampling encoding give differently (w_err [R]: selection_fragile's e_r)
+            we = np.repeat(np.asarray(w_err, np.float32), cnt)
+            for sgn in (1.0, -1.0):
+                spread = spread + np.nan_to_num(np.abs(comp(raw, (sw + np.float32(sgn) * we).astype(np.float32)) - base).max(axis=1), nan=np.inf, posinf=np.inf)
     return spread
 
 
@@ -274,10 +297,10 @@ def one_case(rng, idx):
     # engine's size (colour_sensitivity).  Rays whose selection differs from the oracle's are not comparable and are left out where the
     # frame was one batch; batched renders leave only the last batch's buffers behind, so there the bound applies to the 97th
     # percentile of the excess instead of its maximum.
-    def excess(a, b, prec, tol):
+    def excess(a, b, prec, tol, w_err=None):
         if a.shape[0] == 0:
             return 0.0, 0.0
-        sens = colour_sensitivity(ref, sc, kind, w, h, ENGINE_EPS[prec], np.random.default_rng(1000 + idx), wts=wts)
+        sens = colour_sensitivity(ref, sc, kind, w, h, ENGINE_EPS[prec], np.random.default_rng(1000 + idx), wts=wts, w_err=w_err)
         e = np.abs(a - b).max(axis=1)
         allow = tol * np.maximum(1.0, np.abs(b).max(axis=1)) + SPREADS * sens
         with np.errstate(invalid="ignore"):
@@ -303,6 +326,12 @@ def one_case(rng, idx):
             ok = False; msg.append("fp32 rgb err q90 %.2e q99 %.2e, %.2f %% of rays > 0.02" % (q90, q99, 100 * big))
     else:
         x32, err32 = excess(rgb, ref["rgb"], "fp32", 5e-4)
+        if x32 > 1.0 and rbins is not None and "orc" in ref and thr > 0.0 and "nds" in ref and "p" in ref:
+            # second look with the kept values' own conditioning (the sampling network re-evaluated under +-2 ulp of the ray: only computed
+            # where the first bound did not hold -- round 6: 1 of 1000 cases, a 16-15-band sampling encoding in front of an un-trained net)
+            _, e_r = selection_fragile(ref["orc"], sc, n_max, thr, np.random.default_rng(3000 + idx), rays=(ref["nds"], ref["p"], wts.net0))
+            x32, err32 = excess(rgb, ref["rgb"], "fp32", 5e-4, w_err=e_r)
+            msg.append("fp32 bound with the kept values' conditioning")
         if x32 > 1.0:
             ok = False; msg.append("fp32 rgb err %.2e = %.2f x its conditioned bound" % (err32, x32))
     rgb16 = out["bf16"][0]
@@ -377,6 +406,23 @@ def one_case(rng, idx):
         dz = np.abs(zs - zr) / zr
         print("worst fp32 ray", i, "err", e[i], "depths differing by > 1e-5 rel on that ray:", int((dz[i] > 1e-5).sum()), "max rel", float(dz[i].max()),
               "| rays with any differing depth:", int((dz > 1e-5).any(axis=1).sum()), "of", w * h, "| rays with err > 5e-4:", int((e > 5e-4).sum()))
+    if os.environ.get("FUZZ_ONLY") is not None and not classic:
+        e = np.where(same, np.abs(rgb - ref["rgb"]).max(axis=1), 0.0)
+        i = int(np.argmax(e))
+        os.environ["FUZZ_NO_RAY_ULP"] = "1"
+        s0 = colour_sensitivity(ref, sc, kind, w, h, ENGINE_EPS["fp32"], np.random.default_rng(1000 + idx), wts=wts)[i]
+        del os.environ["FUZZ_NO_RAY_ULP"]
+        s1 = colour_sensitivity(ref, sc, kind, w, h, ENGINE_EPS["fp32"], np.random.default_rng(1000 + idx), wts=wts)[i]
+        if rbins is not None and "orc" in ref and thr > 0.0 and "nds" in ref and "p" in ref:
+            _, e_r = selection_fragile(ref["orc"], sc, n_max, thr, np.random.default_rng(3000 + idx), rays=(ref["nds"], ref["p"], wts.net0))
+            s2 = colour_sensitivity(ref, sc, kind, w, h, ENGINE_EPS["fp32"], np.random.default_rng(1000 + idx), wts=wts, w_err=e_r)
+            sens0 = colour_sensitivity(ref, sc, kind, w, h, ENGINE_EPS["fp32"], np.random.default_rng(1000 + idx), wts=wts)
+            al0 = 5e-4 * np.maximum(1.0, np.abs(ref["rgb"]).max(axis=1)) + SPREADS * sens0
+            j = int(np.argmax(np.where(same & np.isfinite(al0), np.abs(rgb - ref["rgb"]).max(axis=1) / al0, 0.0)))
+            print("ray with the largest excess", j, "err", float(np.abs(rgb[j] - ref["rgb"][j]).max()), "allowed", float(al0[j]), "| its kept values' e_r", float(e_r[j]),
+                  "| spread with them", float(s2[j]), "| kept values", ref["wts"][j][:int(ref["count"][j])])
+        print("worst fp32 ray among identical selections", i, "err", e[i], "| its spread: raw outputs + depth ulp", s0, ", + ray ulp", s1, "| posEncArgs", sc.pos_enc,
+              "| allowed", 5e-4 * max(1.0, float(np.abs(ref["rgb"][i]).max())) + SPREADS * s1)
     if os.environ.get("FUZZ_ONLY") is not None:
         e = np.abs(rgb16 - ref["rgb"]).max(axis=1)
         i = int(np.argmax(e))
