@@ -326,7 +326,7 @@ def one_case(rng, idx):
             ok = False; msg.append("fp32 rgb err q90 %.2e q99 %.2e, %.2f %% of rays > 0.02" % (q90, q99, 100 * big))
     else:
         x32, err32 = excess(rgb, ref["rgb"], "fp32", 5e-4)
-        if x32 > 1.0 and rbins is not None and "orc" in ref and thr > 0.0 and "nds" in ref and "p" in ref:
+        if x32 > 1.0 and "orc" in ref and "wts" in ref and "nds" in ref and "p" in ref:      # (dense mode too: there every output is a kept value)
             # second look with the kept values' own conditioning (the sampling network re-evaluated under +-2 ulp of the ray: only computed
             # where the first bound did not hold -- round 6: 1 of 1000 cases, a 16-15-band sampling encoding in front of an un-trained net)
             _, e_r = selection_fragile(ref["orc"], sc, n_max, thr, np.random.default_rng(3000 + idx), rays=(ref["nds"], ref["p"], wts.net0))
@@ -413,7 +413,7 @@ def one_case(rng, idx):
         s0 = colour_sensitivity(ref, sc, kind, w, h, ENGINE_EPS["fp32"], np.random.default_rng(1000 + idx), wts=wts)[i]
         del os.environ["FUZZ_NO_RAY_ULP"]
         s1 = colour_sensitivity(ref, sc, kind, w, h, ENGINE_EPS["fp32"], np.random.default_rng(1000 + idx), wts=wts)[i]
-        if rbins is not None and "orc" in ref and thr > 0.0 and "nds" in ref and "p" in ref:
+        if "orc" in ref and "wts" in ref and "nds" in ref and "p" in ref:
             _, e_r = selection_fragile(ref["orc"], sc, n_max, thr, np.random.default_rng(3000 + idx), rays=(ref["nds"], ref["p"], wts.net0))
             s2 = colour_sensitivity(ref, sc, kind, w, h, ENGINE_EPS["fp32"], np.random.default_rng(1000 + idx), wts=wts, w_err=e_r)
             sens0 = colour_sensitivity(ref, sc, kind, w, h, ENGINE_EPS["fp32"], np.random.default_rng(1000 + idx), wts=wts)
