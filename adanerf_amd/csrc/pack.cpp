@@ -254,9 +254,19 @@ void emit_ray_samples(const VLayer& L, int A, int fp, int col_base, PackedNet* o
 
 }  // namespace
 
+// what every caller's NetShape must satisfy before any arithmetic on it (adanerf_create checks the same in setup_model; the host-only entry
+// point adanerf_host_pack_weights builds its shape straight from config.ini): band counts the slot layouts exist for, raySampleInput in range
+static bool shape_ok(const NetShape& sh, std::string* err) {
+  for (int f : {sh.fp0, sh.fd0, sh.fp1, sh.fd1})
+    if (f < 0 || f > kMaxBands) return fail(err, "posEncArgs: 0.." + std::to_string(kMaxBands) + " frequency bands are supported");
+  if (sh.ray_samples < 0 || sh.ray_samples > 1024) return fail(err, "raySampleInput[0] must be in 0..1024");
+  return true;
+}
+
 bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, PackedNet* out, std::string* err) {
   *out = PackedNet();
   out->elem = elem;
+  if (!shape_ok(sh, err)) return false;
   const int n_dir = 3 + 6 * sh.fd0, n_pos = 3 + 6 * sh.fp0;
   const int n_in = n_dir + n_pos + sh.ray_samples * n_pos;
   NetTopology& T = out->topo;
@@ -308,6 +318,7 @@ bool pack_sampling_net(const TensorMap& net0, const NetShape& sh, Elem elem, Pac
 bool pack_shading_net(const TensorMap& net1, const NetShape& sh, Elem elem, PackedNet* out, std::string* err, bool scale_bf16) {
   *out = PackedNet();
   out->elem = elem;
+  if (!shape_ok(sh, err)) return false;
   const int n_pos = 3 + 6 * sh.fp1, n_dir = 3 + 6 * sh.fd1;
   NetTopology& T = out->topo;
   T.depth = count_layers(net1, "pts_linears.");

@@ -42,9 +42,7 @@ int load_and_pack(const std::string& dir, std::string* why) {
   if (cfg.posEncArgs.size() != 2) return *why = "posEncArgs", 0;
   NetShape sh{static_cast<int>(cfg.posEncArgs[0][0]), static_cast<int>(cfg.posEncArgs[0][1]), static_cast<int>(cfg.posEncArgs[1][0]),
               static_cast<int>(cfg.posEncArgs[1][1]), cfg.raySampleInput.empty() ? 0 : cfg.raySampleInput[0]};
-  for (int f : {sh.fp0, sh.fd0, sh.fp1, sh.fd1})
-    if (f < 0 || f > 16) return *why = "bands", 0;                        // setup_model's range check (kMaxBands)
-  if (sh.ray_samples < 0 || sh.ray_samples > 1024) return *why = "raySampleInput", 0;
+  // no range checks here: adanerf_host_pack_weights hands the packer whatever config.ini says, and the packer must refuse it itself
   if (!((sh.fp0 == 10 && sh.fd0 == 4) || (sh.fp0 == 2 && sh.fd0 == 2))) sh.lp0 = sh.ld0 = 16;
   if (!(sh.fp1 == 10 && sh.fd1 == 4)) sh.lp1 = sh.ld1 = 16;
   TensorMap n0, n1;

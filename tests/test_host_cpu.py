@@ -1243,3 +1243,27 @@ def test_host_loader_under_sanitizers_on_mutated_model_directories(tmp_path):
     work.mkdir()
     out = subprocess.run([exe, d, str(work), "150", "606"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "0 faults" in out.stdout, out.stdout[-500:] + out.stderr[-3000:]
+
+
+def test_host_only_entry_points_under_sanitizers(tmp_path):
+    """tools/host_abi_sanitize.sh: the library's own host code (both .hip translation units compiled --cuda-host-only, format.cpp, pack.cpp)
+    with -fsanitize=address,undefined, and adanerf_host_parse_model / _depth_table / _pack_weights called through the C ABI on 200 randomly
+    damaged model directories (tests/host_abi_fuzz.cpp).  Covers what the g++ harness above cannot: setup_model, i.e. every check
+    adanerf_create makes on config.ini / dataset_info.txt, and the shape adanerf_host_pack_weights derives from them (round 6: a saturated
+    raySampleInput overflowed an int in the packer there)."""
+    import shutil
+    import subprocess
+    if not shutil.which("hipcc") or not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("hipcc / clang++ not available")
+    import glob
+    if not glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.*"):
+        pytest.skip("clang sanitizer runtimes not installed")
+    out_dir = str(tmp_path / "audit")
+    built = subprocess.run(["bash", os.path.join(ROOT, "tools", "host_abi_sanitize.sh"), out_dir], capture_output=True, text=True, timeout=600)
+    assert built.returncode == 0, built.stdout[-1000:] + built.stderr[-3000:]
+    d, _, _ = _model_dir(tmp_path, name="abi_fuzzed")
+    work = tmp_path / "work_abi"
+    work.mkdir()
+    out = subprocess.run([os.path.join(out_dir, "host_abi_fuzz"), d, str(work), "200", "707"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert out.returncode == 0 and "0 faults" in out.stdout and "untouched: 10 calls ok" in out.stdout, out.stdout[-500:] + out.stderr[-3000:]
